@@ -1,0 +1,201 @@
+/*
+ * pcc_hip.h -- C ABI of libpcc_hip.so, the MI355X (gfx950) sparse-voxel codec hot path.
+ *
+ * This is the drop-in boundary.  The reference
+ * (ikt-luh/Unified-Point-Cloud-Compression) reaches this path through two Python import
+ * surfaces, `import MinkowskiEngine as ME` and `compressai.*`; the Python shims in
+ * unified_point_cloud_compression_amd/{MinkowskiEngine,compressai}/ bind these entry points
+ * with ctypes.  Every entry point names the reference interface it replaces (file:line in
+ * /root/reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with `h_`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - functions return 0 on success, a negative PCC_E* code otherwise; pcc_last_error()
+ *     gives the message of the calling thread's last failure; no exceptions, no ownership
+ *     transfer, no allocation: outputs and workspaces are caller-allocated (sizes from the
+ *     *_ws_bytes / *_elems queries); nothing here synchronises the stream;
+ *   - coordinates are packed int64 keys  b<<48 | (x+2^15)<<32 | (y+2^15)<<16 | (z+2^15);
+ *     a coordinate set is a strictly ascending key array ("canonical order" = the order
+ *     `utils.sort_tensor` produces, utils.py:142-165);
+ *   - features are row-major float32 [N, C].
+ */
+#ifndef PCC_HIP_H
+#define PCC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCC_OK 0
+#define PCC_EINVAL (-1)   /* bad argument / unsupported shape */
+#define PCC_EHIP (-2)     /* HIP runtime error              */
+#define PCC_EWS (-3)      /* workspace too small            */
+
+#define PCC_ACT_NONE 0
+#define PCC_ACT_RELU 1    /* ME.MinkowskiReLU      (model/transforms.py:148,153,158)          */
+#define PCC_ACT_LEAKY 2   /* ME.MinkowskiLeakyReLU (model/entropy_models.py:179,181,187,189)  */
+
+#define PCC_MAP_HDR_INTS 256  /* int32 words of a kernel-map header (device resident)        */
+#define PCC_MAP_MAX_SEG 8
+
+int pcc_version(void);
+const char* pcc_last_error(void);
+/* number of compute units / name of the current device (sanity: must be gfx950). */
+int pcc_device_info(int* h_cu_count, char* h_arch, int h_arch_len);
+
+/* ------------------------------------------------------------------------------------------
+ * a1 / a11  coordinate keys            (ME.SparseTensor ctor: model/model.py:66-70,147-161,227;
+ *                                       ME.utils.sparse_quantize: model/model.py:152-156)
+ * ---------------------------------------------------------------------------------------- */
+/* int32 [n,4] (b,x,y,z) -> keys */
+int pcc_keys_pack_i32(const int32_t* coords, int64_t n, int64_t* keys, void* stream);
+/* float [n,4] -> floor -> keys (the reference passes float coordinates, model/model.py:142-149) */
+int pcc_keys_pack_f32(const float* coords, int64_t n, int64_t* keys, void* stream);
+int pcc_keys_unpack(const int64_t* keys, int64_t n, int32_t* coords, void* stream);
+
+/* LSD radix sort of keys (stable), optional payload perm_out[i] = input index of output i.
+ * Only 8-bit digits intersecting `bit_mask` (bits that may differ between keys) are sorted. */
+size_t pcc_sort_ws_bytes(int64_t n);
+int pcc_sort_keys(const int64_t* keys_in, int64_t n, uint64_t bit_mask, int64_t* keys_out,
+                  int32_t* perm_out /*nullable*/, void* ws, size_t ws_bytes, void* stream);
+
+/* adjacent-unique of a sorted key array.  uniq[] (capacity n), first[] (nullable; index in the
+ * sorted array of the first occurrence), *d_count = number of unique keys (device int64). */
+size_t pcc_unique_ws_bytes(int64_t n);
+int pcc_unique_sorted(const int64_t* sorted_keys, int64_t n, int64_t* uniq, int32_t* first,
+                      int64_t* d_count, void* ws, size_t ws_bytes, void* stream);
+
+/* *d_flag != 0 when keys[] is strictly ascending, else 0 (device int32). */
+int pcc_keys_is_canonical(const int64_t* keys, int64_t n, int32_t* d_flag, void* stream);
+
+/* a2(i)  strided output set, ME stride map: out = unique(floor(c/m)*m), m = new tensor stride
+ * (power of two).  (ME.MinkowskiConvolution stride=2: model/transforms.py:33,37,41;
+ * model/entropy_models.py:180,182; coordinate-only use model/model.py:227-229 = row a12.) */
+size_t pcc_stride_ws_bytes(int64_t n);
+int pcc_coords_stride(const int64_t* keys, int64_t n, int32_t new_stride, uint64_t bit_mask,
+                      int64_t* out_keys /*cap n*/, int64_t* d_count, void* ws, size_t ws_bytes,
+                      void* stream);
+
+/* a3(i)  generative output set: unique{ c + off_k * ts_out }, K = kernel_size^3 offsets
+ * (ME.MinkowskiGenerativeConvolutionTranspose: model/transforms.py:129,133,137;
+ * model/entropy_models.py:186,188). out_keys capacity n*K. */
+size_t pcc_expand_ws_bytes(int64_t n, int32_t kernel_size);
+int pcc_coords_expand(const int64_t* keys, int64_t n, int32_t kernel_size, int32_t ts_out,
+                      uint64_t bit_mask, int64_t* out_keys /*cap n*K*/, int64_t* d_count, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a2(ii) / a3  kernel map              (ME kernel map behind every conv forward)
+ *
+ * A map is three device arrays:
+ *   hdr  int32[PCC_MAP_HDR_INTS]  segment table (written by the build kernels)
+ *   nbr  int32[...]               per segment a [k_count][pos_count] table of input rows (-1 none)
+ *   rows int32[n_out] or NULL     output row of each position (NULL: position == output row)
+ * conv:       one segment, all K offsets, positions = output rows.
+ * transposed: outputs are grouped by their residue class modulo the up-sampling stride
+ *             (stride^3 segments); a class only lists the offsets that can reach it.
+ * ---------------------------------------------------------------------------------------- */
+/* number of int32 the nbr array needs (upper bound for transposed maps) */
+int64_t pcc_map_nbr_elems(int64_t n_out, int32_t kernel_size, int32_t stride, int32_t transposed);
+size_t pcc_map_ws_bytes(int64_t n_out);
+/* in = out + off_k*step (conv, step = input tensor stride)
+ * out = in + off_k*step (transposed, step = output tensor stride, stride = up-sampling factor)
+ * *d_pairs (device int64, nullable) receives the number of valid (in,out) pairs. */
+int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys, int64_t n_out,
+                         int32_t kernel_size, int32_t step, int32_t stride, int32_t transposed,
+                         int32_t* hdr, int32_t* nbr, int32_t* rows /*transposed only*/,
+                         int64_t* d_pairs, void* ws, size_t ws_bytes, void* stream);
+/* dense [K][n_out] view of any map (testing / inspection): -1 where no pair */
+int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows, int64_t n_out,
+                     int32_t K, int32_t* dense, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a2(iii) / a3  sparse convolution forward, output stationary, fp32 MFMA
+ *   out[o] = act( bias + sum_k feat_in[nbr_k(o)] @ W[k] )
+ * (ME.MinkowskiConvolution / MinkowskiGenerativeConvolutionTranspose forward, 17+5 sites:
+ *  model/transforms.py:33-43,127-166; model/entropy_models.py:178-190.)
+ * Weights are consumed in a packed layout produced once per parameter update.
+ * ---------------------------------------------------------------------------------------- */
+int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
+/* W: ME layout [K, cin, cout] row-major (state_dict `kernel`) */
+int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
+                          void* stream);
+int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                 const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* hdr,
+                 const int32_t* nbr, const int32_t* rows, int64_t n_out, float* out, int32_t act,
+                 float slope, void* stream);
+
+/* a5  fused GDN / IGDN (GDN1 form), MinkowskiGDN.forward model/blocks.py:26-57:
+ *   norm = beta + |x| @ gamma^T ; out = x / norm (inverse=0) or x * norm (inverse=1)
+ * beta_raw/gamma_raw are the raw (un-reparametrised) CompressAI parameters; the
+ * NonNegativeParametrizer is applied by pcc_gdn_pack. packed: pcc_conv_packed_elems(1,c,c)
+ * floats, beta_eff: c floats. */
+int pcc_gdn_pack(const float* beta_raw, const float* gamma_raw, int32_t c, float beta_min,
+                 float* packed, float* beta_eff, void* stream);
+int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* packed, const float* beta_eff,
+                int32_t inverse, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a4  top-k occupancy mask + pruning   (model/transforms.py:228-282, ME.MinkowskiPruning :163)
+ * Total order: logit descending, then canonical row ascending.
+ * seg_begin: h_ host array [nb+1] of row ranges per batch index, h_k: host array [nb].
+ * ---------------------------------------------------------------------------------------- */
+size_t pcc_topk_ws_bytes(int64_t n);
+int pcc_topk_mask(const float* logits, int64_t stride_elems, const int64_t* h_seg_begin,
+                  const int64_t* h_k, int32_t nb, uint8_t* mask, void* ws, size_t ws_bytes,
+                  void* stream);
+/* row compaction by mask: keys_out/feat_out capacity n; *d_count device int64 */
+size_t pcc_prune_ws_bytes(int64_t n);
+int pcc_prune_rows(const uint8_t* mask, int64_t n, const int64_t* keys, const float* feat, int32_t c,
+                   int64_t* keys_out, float* feat_out, int64_t* d_count, void* ws, size_t ws_bytes,
+                   void* stream);
+
+/* a6  SparseTensor.features_at_coordinates for on-grid queries
+ * (model/entropy_models.py:294,381,446): out[q] = feat[row(query_keys[q])] or zeros. */
+int pcc_lookup_gather(const int64_t* keys, int64_t n, const float* feat, int32_t c,
+                      const int64_t* query_keys, int64_t nq, float* out, void* stream);
+/* row index of each query (-1 absent) */
+int pcc_lookup_rows(const int64_t* keys, int64_t n, const int64_t* query_keys, int64_t nq,
+                    int32_t* rows_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a7  Gaussian conditional, fused      (compressai GaussianConditional as used at
+ *                                       model/entropy_models.py:299-333,396-400,468-484)
+ * y [n,c]; params [n,2c] = (scales_hat | means_hat) as h_s emits them; gain [nb,c] nullable
+ * (scale_nn(q)+eps rows, indexed by the batch field of keys[]; NULL = 1).
+ *   s   = max(scales*gain, 0.11)
+ *   sym = rint(y*gain - means*gain)            idx = 63 - #{t<63 : s <= table[t]}
+ *   lik = max(Phi((.5-|sym|)/s) - Phi((-.5-|sym|)/s), 1e-9)
+ * Any of sym/idx/lik may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+int pcc_gauss_encode(const float* y, const float* params, const int64_t* keys, const float* gain,
+                     int64_t n, int32_t c, const float* table, int32_t n_table, int32_t* sym,
+                     int32_t* idx, float* lik, void* stream);
+/* decode side: y_hat = sym + means*gain (no offsets, model/entropy_models.py:484), idx as above */
+int pcc_gauss_decode(const int32_t* sym, const float* params, const int64_t* keys, const float* gain,
+                     int64_t n, int32_t c, const float* table, int32_t n_table, float* y_hat,
+                     int32_t* idx, void* stream);
+
+/* a8  factorised prior on z            (compressai EntropyBottleneck, model/entropy_models.py:272,
+ *                                       282-285,371-372,438); filters (3,3,3,3).
+ * eb_packed [c,58]: softplus(matrices) (3,9,9,9,3) | biases (3,3,3,3,1) | tanh(factors) (3,3,3,3);
+ * medians [c]. sym = rint(z - med), z_hat = sym + med, lik = |sig(s*u) - sig(s*l)| >= 1e-9. */
+int pcc_eb_encode(const float* z, int64_t n, int32_t c, const float* eb_packed, const float* medians,
+                  int32_t* sym, float* z_hat, float* lik, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * measurement support: per-launch HIP-event timing of the conv kernel (bench.py roofline)
+ * ---------------------------------------------------------------------------------------- */
+int pcc_prof_enable(int32_t on);
+/* sums over launches since the last reset; also resets. flops = 2*P*Cin*Cout needs the pair
+ * counts, which the caller accumulates itself (d_pairs). Synchronises the recorded events. */
+int pcc_prof_collect(double* h_conv_ms, int64_t* h_conv_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCC_HIP_H */

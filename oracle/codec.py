@@ -425,8 +425,9 @@ R2_CONFIG = {
 }
 
 
-def small_config(n=16, cb=16, ch=24, adaptive=False, offsets=False, inverse=False):
-    """Narrow variant of the same architecture for fast CPU tests."""
+def small_config(n=16, cb=64, ch=32, adaptive=False, offsets=False, inverse=False):
+    """Narrow variant of the same architecture for fast tests (channel counts the MFMA tiling takes:
+    4/8/16 or multiples of 32, including C_bottleneck*3//2)."""
     return {
         "entropy_model": dict(C_bottleneck=cb, C_hyper_bottleneck=ch, quantization_mode="ste",
                               inverse_rescaling=inverse, quantization_offset=offsets,

@@ -1,0 +1,105 @@
+"""a1 / a2-i / a3-i / a11: coordinate keys on the GPU against the oracle -- bit exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as co
+from tests.util import dev, t, n, cloud_keys
+
+pytestmark = pytest.mark.gpu
+
+
+def _S():
+    from unified_point_cloud_compression_amd import sparse as S, lib as L
+    return S, L
+
+
+def test_pack_unpack_roundtrip_and_negatives():
+    S, L = _S()
+    rng = np.random.default_rng(0)
+    C = rng.integers(-300, 2048, size=(5000, 4)).astype(np.int32)
+    C[:, 0] = rng.integers(0, 3, size=5000)
+    keys = S.pack_keys(t(C))
+    assert np.array_equal(n(keys)[:5000], co.pack_keys(C))
+    Cf = C.astype(np.float32) + rng.random((5000, 4)).astype(np.float32) * 0.99
+    Cf[:, 0] = C[:, 0]
+    assert np.array_equal(n(S.pack_keys(t(Cf)))[:5000], co.pack_keys(C))      # floor, also for negatives
+    out = torch.empty((5000, 4), dtype=torch.int32, device=dev())
+    L.call("pcc_keys_unpack", L.ptr(keys), 5000, L.ptr(out), L.stream())
+    assert np.array_equal(n(out), C)
+
+
+@pytest.mark.parametrize("nkeys", [1, 63, 2048, 2049, 100_000, 1_000_003])
+def test_sort_matches_numpy_stable(nkeys):
+    S, L = _S()
+    rng = np.random.default_rng(nkeys)
+    C = np.concatenate([rng.integers(0, 2, (nkeys, 1)), rng.integers(-5, 700, (nkeys, 3))], axis=1)
+    keys = co.pack_keys(C)
+    b = S.Bounds(1, (-5, -5, -5), (699, 699, 699))
+    k_in = t(keys)
+    k_out = torch.empty_like(k_in)
+    perm = torch.empty(nkeys, dtype=torch.int32, device=dev())
+    ws = L.workspace(L.load().pcc_sort_ws_bytes(nkeys), dev())
+    L.call("pcc_sort_keys", L.ptr(k_in), nkeys, b.bit_mask(), L.ptr(k_out), L.ptr(perm), L.ptr(ws), ws.numel(), L.stream())
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(n(k_out), keys[order])
+    assert np.array_equal(n(perm), order.astype(np.int32))
+
+
+def test_sparse_tensor_dedup_first_wins_and_user_order():
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    C = np.array([[0, 5, 5, 5], [0, 1, 2, 3], [0, 5, 5, 5], [0, -1, 0, 7], [0, 1, 2, 3]], dtype=np.int32)
+    F = np.arange(5, dtype=np.float32)[:, None]
+    x = ME.SparseTensor(coordinates=t(C), features=t(F))
+    assert n(x.C).tolist() == [[0, 5, 5, 5], [0, 1, 2, 3], [0, -1, 0, 7]]       # original order, first kept (A.1)
+    assert n(x.F)[:, 0].tolist() == [0.0, 1.0, 3.0]
+    keys = n(x._cset.keys)[:x._cset.n]
+    assert np.array_equal(keys, np.unique(co.pack_keys(C)))
+    assert n(x._canonical_features())[:, 0].tolist() == [3.0, 1.0, 0.0]           # canonical = (b,x,y,z) ascending
+    cq, fq = ME.utils.sparse_quantize(coordinates=t(C), features=t(F), quantization_size=1.0)
+    oc, of = co.sparse_quantize(C, F)
+    assert np.array_equal(n(cq), oc) and np.array_equal(n(fq), of)
+    # O(1) re-wrap of an existing coordinate tensor keeps the coordinate set
+    y = ME.SparseTensor(coordinates=x.C, features=x.F * 2, tensor_stride=x.tensor_stride, device=x.device)
+    assert y._cset is x._cset
+
+
+def test_empty_inputs():
+    S, L = _S()
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    x = ME.SparseTensor(coordinates=torch.zeros((0, 4), dtype=torch.int32, device=dev()),
+                        features=torch.zeros((0, 4), device=dev()))
+    assert x._cset.n == 0 and x.C.shape == (0, 4)
+    assert x._cset.stride(2).n == 0
+    assert x._cset.expand(2, 1).n == 0
+
+
+@pytest.mark.parametrize("seed,size,p,ts", [(0, 40, 0.1, 1), (1, 24, 0.3, 2), (2, 64, 0.02, 4)])
+def test_stride_matches_oracle(seed, size, p, ts):
+    S, L = _S()
+    keys = cloud_keys(seed, size, p, ts, batch=2)
+    C = co.unpack_keys(keys)
+    C[:, 1:] -= 3 * ts                                 # some negative coordinates
+    keys = np.unique(co.pack_keys(C))
+    C = co.unpack_keys(keys)
+    cs = S.CoordSet(t(keys), len(keys), ts, S.Bounds(1, C[:, 1:].min(0), C[:, 1:].max(0)))
+    for m in (2 * ts, 4 * ts):
+        got = cs.stride(m)
+        want = co.stride_keys(keys, m)
+        assert got.n == len(want)
+        assert np.array_equal(n(got.keys)[:got.n], want)
+        cs2 = got.stride(2 * m)                         # chained (down_conv twice, model/model.py:228-229)
+        assert np.array_equal(n(cs2.keys)[:cs2.n], co.stride_keys(want, 2 * m))
+
+
+@pytest.mark.parametrize("ks,ts_in", [(5, 2), (2, 2), (2, 32), (5, 8), (3, 2)])
+def test_expand_matches_oracle(ks, ts_in):
+    S, L = _S()
+    keys = cloud_keys(7, 20, 0.08, ts_in, batch=2)       # includes coordinates at 0 -> negative outputs for k5
+    C = co.unpack_keys(keys)
+    cs = S.CoordSet(t(keys), len(keys), ts_in, S.Bounds(1, C[:, 1:].min(0), C[:, 1:].max(0)))
+    got = cs.expand(ks, ts_in // 2)
+    want = co.expand_keys(keys, ks, ts_in // 2)
+    assert got.n == len(want)
+    assert np.array_equal(n(got.keys)[:got.n], want)
+    assert got.ts == ts_in // 2

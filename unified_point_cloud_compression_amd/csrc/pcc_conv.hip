@@ -1,0 +1,531 @@
+// Sparse convolution forward for gfx950: output-stationary implicit GEMM on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), deterministic (no atomics, fixed summation order).
+//
+// A workgroup owns BM consecutive positions of one map segment and BN output channels.  The
+// reduction dimension is the flattened (active kernel offset, input channel) axis, consumed in
+// chunks of 32: the BM gathered feature-row pieces and the BN weight rows of a chunk are staged
+// through LDS as [row][32+4] tiles (16-byte pad: conflict-free ds_read_b128 / ds_write_b128), and
+// every wave multiplies its 32x32 tiles with 4 MFMAs per pair of 16-byte fragment reads.
+// Kernel offsets for which no position of the tile has a neighbour are skipped (wave ballots over
+// the neighbour table), so sparse tiles do not pay for empty offsets.
+//
+// The same kernel body computes the fused GDN / IGDN (model/blocks.py:38-57): A = |x|, W = gamma^T,
+// epilogue x / (acc + beta) or x * (acc + beta).
+//
+// Thin outputs (Cout <= 4: occupancy logits, colours, model/transforms.py:141-160) are gather-bound;
+// they use a VALU kernel with lanes spread over the input channels of a row.
+#include <vector>
+
+#include "pcc_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int LDS_LD = 36;   // floats per LDS tile row: 32 + 4 pad
+static constexpr int MAXK = 128;    // kernel offsets per segment (K <= 125)
+
+enum { MODE_CONV = 0, MODE_GDN = 1, MODE_IGDN = 2 };
+
+struct ConvArgs {
+  const float* feat;      // [n_in, cin]
+  const float* wp;        // packed weights [K*ppo][cout_pad][CB]
+  const float* bias;      // [cout] or null (GDN: beta_eff)
+  const int* hdr;         // map header (null: identity, one segment of n_out positions)
+  const int* nbr;
+  const int* rows;
+  float* out;             // [n_out, cout]
+  long long n_out;
+  int cin, cout, cout_pad;
+  int cb_log2;            // log2(CB), CB = min(cin, 32)
+  int ppo;                // pieces per offset = cin / CB
+  int act;
+  float slope;
+};
+
+__host__ __device__ inline int bn_for(int cout) { return cout >= 128 ? 128 : (cout > 32 ? 64 : 32); }
+
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+  __shared__ unsigned char act_flag[MAXK];
+  __shared__ unsigned char act_list[MAXK];   // segment-local offset slot
+  __shared__ unsigned char act_kid[MAXK];    // kernel offset id (weight index)
+  __shared__ int s_nact;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+  // ---- locate (segment, tile) --------------------------------------------------------------
+  int pos0, npos, k_count, koff_begin;
+  long long seg_pos_count;
+  const int* seg_nbr = nullptr;
+  bool identity = (a.hdr == nullptr);
+  if (identity) {
+    const long long p0 = (long long)blockIdx.x * BM;
+    if (p0 >= a.n_out) return;
+    pos0 = (int)p0;
+    npos = (int)min((long long)BM, a.n_out - p0);
+    k_count = 1; koff_begin = 0; seg_pos_count = a.n_out;
+  } else {
+    const int nseg = a.hdr[HDR_NSEG];
+    int tile = blockIdx.x, s = 0;
+    bool found = false;
+    int pb = 0, pc = 0;
+    for (; s < nseg; ++s) {
+      const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+      pb = sg[SEG_POS_BEGIN]; pc = sg[SEG_POS_COUNT];
+      const int tiles = (pc + BM - 1) / BM;
+      if (tile < tiles) { found = true; break; }
+      tile -= tiles;
+    }
+    if (!found) return;   // grid is an upper bound on the tile count
+    const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+    k_count = sg[SEG_K_COUNT];
+    koff_begin = sg[SEG_KOFF_BEGIN];
+    const long long nb = ((long long)(unsigned)sg[SEG_NBR_LO]) | ((long long)sg[SEG_NBR_HI] << 32);
+    seg_nbr = a.nbr + nb;
+    seg_pos_count = pc;
+    const int local0 = tile * BM;
+    pos0 = pb + local0;
+    npos = min(BM, pc - local0);
+    seg_nbr += local0;     // seg_nbr[j * seg_pos_count + r] = input row of tile row r for slot j
+  }
+
+  // ---- active offsets of this tile ---------------------------------------------------------
+  if (identity) {
+    if (tid == 0) { act_list[0] = 0; act_kid[0] = 0; s_nact = 1; }
+  } else {
+    for (int j = w; j < k_count; j += 4) {
+      bool any = false;
+      for (int r = lane; r < npos; r += 64) any |= (seg_nbr[(long long)j * seg_pos_count + r] >= 0);
+      const unsigned long long m = __ballot(any);
+      if (lane == 0) act_flag[j] = m ? 1 : 0;
+    }
+    __syncthreads();
+    if (w == 0) {
+      int n = 0;
+      for (int j0 = 0; j0 < k_count; j0 += 64) {
+        const int j = j0 + lane;
+        const bool f = (j < k_count) && act_flag[j];
+        const unsigned long long m = __ballot(f);
+        if (f) {
+          const int p = n + __popcll(m & ((1ull << lane) - 1ull));
+          act_list[p] = (unsigned char)j;
+          act_kid[p] = (unsigned char)a.hdr[HDR_KOFFS + koff_begin + j];
+        }
+        n += __popcll(m);
+      }
+      if (lane == 0) s_nact = n;
+    }
+  }
+  __syncthreads();
+  const int nact = s_nact;
+
+  const int CB = 1 << a.cb_log2;
+  const int ppc_log2 = 5 - a.cb_log2;                 // pieces per 32-wide chunk
+  const int npieces = nact * a.ppo;
+  const int nchunks = (npieces + (1 << ppc_log2) - 1) >> ppc_log2;
+
+  // staging role of this thread: 16-byte part `part` of tile rows r0 + 32*i
+  const int part = tid & 7;
+  const int r0 = tid >> 3;
+  const int kk0 = part * 4;
+  const int piece_in_chunk = kk0 >> a.cb_log2;
+  const int within = kk0 & (CB - 1);
+  constexpr int AI = BM / 32, BI = BN / 32;
+  const int colblock = blockIdx.y * BN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm = w / WN, wn = w % WN;
+  const int half = lane >> 5, r31 = lane & 31;
+
+  int cached_a = -1;
+  int in_row[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) in_row[i] = -1;
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int piece = (c << ppc_log2) + piece_in_chunk;
+    const int ai = piece / a.ppo;           // active-offset index of my part
+    const int cbi = piece - ai * a.ppo;     // channel block within the offset
+    const bool pvalid = ai < nact;
+    if (ai != cached_a) {
+      cached_a = ai;
+      const int slot = pvalid ? act_list[ai] : 0;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int r = r0 + 32 * i;
+        int v = -1;
+        if (pvalid && r < npos) v = identity ? (pos0 + r) : seg_nbr[(long long)slot * seg_pos_count + r];
+        in_row[i] = v;
+      }
+    }
+    // global -> registers
+    float4 av[AI], bv[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in_row[i] >= 0)
+        av[i] = *reinterpret_cast<const float4*>(a.feat + (long long)in_row[i] * a.cin + (cbi << a.cb_log2) + within);
+    }
+    {
+      const long long wbase = pvalid ? ((long long)(act_kid[ai] * a.ppo + cbi) * a.cout_pad) : 0;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pvalid) {
+          const int col = colblock + r0 + 32 * i;
+          bv[i] = *reinterpret_cast<const float4*>(a.wp + ((wbase + col) << a.cb_log2) + within);
+        }
+      }
+    }
+    if (MODE != MODE_CONV) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        av[i].x = fabsf(av[i].x); av[i].y = fabsf(av[i].y); av[i].z = fabsf(av[i].z); av[i].w = fabsf(av[i].w);
+      }
+    }
+    __syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDS_LD + kk0]) = av[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDS_LD + kk0]) = bv[i];
+    __syncthreads();
+    // LDS -> fragments -> MFMA
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const float4*>(&As[((wm * TM + i) * 32 + r31) * LDS_LD + g * 8 + half * 4]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const float4*>(&Bs[((wn * TN + j) * 32 + r31) * LDS_LD + g * 8 + half * 4]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: bias, activation (or GDN), store -------------------------------------------
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = colblock + (wn * TN + j) * 32 + r31;
+    if (col >= a.cout) continue;
+    const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (r >= npos) continue;
+        const long long orow = a.rows ? a.rows[pos0 + r] : (pos0 + r);
+        float v = acc[i][j][e] + b;
+        if (MODE == MODE_CONV) {
+          if (a.act == PCC_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == PCC_ACT_LEAKY) v = v >= 0.f ? v : v * a.slope;
+        } else {
+          const float x = a.feat[orow * a.cin + col];
+          v = (MODE == MODE_GDN) ? x / v : x * v;
+        }
+        a.out[orow * a.cout + col] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// thin outputs (cout <= 4) or channel counts the MFMA tiling does not take: VALU, gather-bound.
+// Wt layout [K][cout][cin].  LPR lanes share one output position.
+// ------------------------------------------------------------------------------------------
+struct ThinArgs {
+  const float* feat; const float* wt; const float* bias;
+  const int* hdr; const int* nbr; const int* rows;
+  float* out; long long n_out; int cin, cout, act; float slope; int lpr_log2;
+};
+
+template <int COUT_MAX>
+__global__ void __launch_bounds__(256) k_conv_thin(ThinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << a.lpr_log2;
+  const int rpw = 64 >> a.lpr_log2;                       // rows per wave
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long p = wave * rpw + (lane >> a.lpr_log2);  // position handled by my lane group
+  const int cl = lane & (lpr - 1);
+  const bool valid = p < a.n_out;
+
+  int k_count = 1, koff_begin = 0;
+  long long seg_pos_count = a.n_out, local = p;
+  const int* seg_nbr = nullptr;
+  const bool identity = (a.hdr == nullptr);
+  if (!identity && valid) {
+    const int nseg = a.hdr[HDR_NSEG];
+    int s = 0;
+    for (; s < nseg - 1; ++s) {
+      const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+      if (p < (long long)sg[SEG_POS_BEGIN] + sg[SEG_POS_COUNT]) break;
+    }
+    const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+    k_count = sg[SEG_K_COUNT];
+    koff_begin = sg[SEG_KOFF_BEGIN];
+    seg_pos_count = sg[SEG_POS_COUNT];
+    local = p - sg[SEG_POS_BEGIN];
+    seg_nbr = a.nbr + (((long long)(unsigned)sg[SEG_NBR_LO]) | ((long long)sg[SEG_NBR_HI] << 32));
+  }
+  float acc[COUT_MAX];
+#pragma unroll
+  for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
+  if (valid) {
+    for (int j = 0; j < k_count; ++j) {
+      const long long ir = identity ? p : (long long)seg_nbr[(long long)j * seg_pos_count + local];
+      if (ir < 0) continue;
+      const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + j];
+      const float* f = a.feat + ir * a.cin;
+      const float* wk = a.wt + (long long)kid * a.cout * a.cin;
+      for (int c = cl; c < a.cin; c += lpr) {
+        const float x = f[c];
+#pragma unroll
+        for (int o = 0; o < COUT_MAX; ++o)
+          if (o < a.cout) acc[o] = fmaf(x, wk[o * a.cin + c], acc[o]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < COUT_MAX; ++o)
+    for (int d = lpr >> 1; d >= 1; d >>= 1) acc[o] += __shfl_xor(acc[o], d);
+  if (valid && cl == 0) {
+    const long long orow = a.rows ? a.rows[p] : p;
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) {
+      if (o >= a.cout) break;
+      float v = acc[o] + (a.bias ? a.bias[o] : 0.f);
+      if (a.act == PCC_ACT_RELU) v = fmaxf(v, 0.f);
+      else if (a.act == PCC_ACT_LEAKY) v = v >= 0.f ? v : v * a.slope;
+      a.out[orow * a.cout + o] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dispatch, packing
+// ------------------------------------------------------------------------------------------
+static bool mfma_ok(int cin, int cout) {
+  if (cout <= 4) return false;
+  if (cin == 4 || cin == 8 || cin == 16) return true;
+  return cin >= 32 && cin % 32 == 0;
+}
+static int cb_log2_for(int cin) { return cin >= 32 ? 5 : (cin == 16 ? 4 : (cin == 8 ? 3 : 2)); }
+static int cout_pad_for(int cout) { const int bn = bn_for(cout); return (cout + bn - 1) / bn * bn; }
+
+extern "C" int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout) {
+  if (K <= 0 || cin <= 0 || cout <= 0) return 0;
+  if (mfma_ok(cin, cout)) return (int64_t)K * cin * cout_pad_for(cout);
+  return (int64_t)K * cin * cout;
+}
+
+// W [K][cin][cout] -> MFMA layout [K*ppo][cout_pad][CB] (zero padded columns)
+__global__ void k_pack_mfma(const float* __restrict__ W, int K, int cin, int cout, int cout_pad, int cb_log2,
+                            float* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)K * cin * cout_pad;
+  if (t >= total) return;
+  const int CB = 1 << cb_log2;
+  const int within = (int)(t & (CB - 1));
+  const long long q = t >> cb_log2;
+  const int col = (int)(q % cout_pad);
+  const long long piece = q / cout_pad;
+  const int ppo = cin >> cb_log2;
+  const int kid = (int)(piece / ppo), cbi = (int)(piece % ppo);
+  const int ci = (cbi << cb_log2) + within;
+  out[t] = (col < cout) ? W[((long long)kid * cin + ci) * cout + col] : 0.f;
+}
+
+// W [K][cin][cout] -> thin layout [K][cout][cin]
+__global__ void k_pack_thin(const float* __restrict__ W, int K, int cin, int cout, float* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)K * cin * cout) return;
+  const int c = (int)(t % cin);
+  const int o = (int)((t / cin) % cout);
+  const int k = (int)(t / ((long long)cin * cout));
+  out[t] = W[((long long)k * cin + c) * cout + o];
+}
+
+extern "C" int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
+                                     void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(W && packed && K >= 1 && K <= MAXK && cin >= 1 && cout >= 1, "pcc_conv_pack_weights: bad arguments");
+  const int64_t total = pcc_conv_packed_elems(K, cin, cout);
+  if (mfma_ok(cin, cout))
+    k_pack_mfma<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(W, K, cin, cout, cout_pad_for(cout), cb_log2_for(cin), packed);
+  else {
+    PCC_REQUIRE(cout <= 4, "pcc_conv: unsupported shape cin=%d cout=%d (MFMA path needs cin in {4,8,16} or a multiple of 32)", cin, cout);
+    k_pack_thin<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(W, K, cin, cout, packed);
+  }
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// ---- per-launch event timing (bench.py roofline) ------------------------------------------------
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_ev_pool;
+static size_t g_ev_used = 0;
+static int64_t g_launches = 0;
+
+extern "C" int pcc_prof_enable(int32_t on) {
+  g_prof_on = on != 0;
+  g_ev_used = 0;
+  g_launches = 0;
+  return PCC_OK;
+}
+
+static int prof_event(hipEvent_t* ev, hipStream_t s) {
+  if (g_ev_used == g_ev_pool.size()) {
+    hipEvent_t e;
+    PCC_CHECK_HIP(hipEventCreate(&e));
+    g_ev_pool.push_back(e);
+  }
+  *ev = g_ev_pool[g_ev_used++];
+  PCC_CHECK_HIP(hipEventRecord(*ev, s));
+  return PCC_OK;
+}
+
+extern "C" int pcc_prof_collect(double* h_conv_ms, int64_t* h_conv_launches) {
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < g_ev_used; i += 2) {
+    PCC_CHECK_HIP(hipEventSynchronize(g_ev_pool[i + 1]));
+    float t = 0.f;
+    PCC_CHECK_HIP(hipEventElapsedTime(&t, g_ev_pool[i], g_ev_pool[i + 1]));
+    ms += t;
+  }
+  if (h_conv_ms) *h_conv_ms = ms;
+  if (h_conv_launches) *h_conv_launches = g_launches;
+  g_ev_used = 0;
+  g_launches = 0;
+  return PCC_OK;
+}
+
+template <int MODE>
+static int launch_mfma(const ConvArgs& a, int tiles_bound_extra, hipStream_t s) {
+  const int bn = bn_for(a.cout);
+  const unsigned gy = (unsigned)(a.cout_pad / bn);
+  auto tiles = [&](int bm) { return (unsigned)(pcc_cdiv(a.n_out, bm) + tiles_bound_extra); };
+  if (bn == 128) k_conv_mfma<2, 2, 2, 2, MODE><<<dim3(tiles(128), gy), 256, 0, s>>>(a);
+  else if (bn == 64) k_conv_mfma<2, 2, 2, 1, MODE><<<dim3(tiles(128), gy), 256, 0, s>>>(a);
+  else k_conv_mfma<4, 1, 1, 1, MODE><<<dim3(tiles(128), gy), 256, 0, s>>>(a);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                            const float* bias, int32_t K, int32_t cout, const int32_t* hdr, const int32_t* nbr,
+                            const int32_t* rows, int64_t n_out, float* out, int32_t act, float slope,
+                            void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out <= 0) return PCC_OK;
+  PCC_REQUIRE(feat_in && packed_w && out && n_in > 0, "pcc_conv_fwd: NULL array");
+  PCC_REQUIRE(K >= 1 && K <= MAXK, "pcc_conv_fwd: K=%d unsupported", K);
+  PCC_REQUIRE(hdr ? (nbr != nullptr) : (K == 1 && n_in == n_out), "pcc_conv_fwd: map missing (only K=1 may omit it)");
+  PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd: bad activation");
+  PCC_REQUIRE(n_in < (1ll << 31) && n_out < (1ll << 31), "pcc_conv_fwd: too many rows");
+  hipEvent_t e0, e1;
+  if (g_prof_on) PCC_TRY(prof_event(&e0, s));
+  if (mfma_ok(cin, cout)) {
+    ConvArgs a;
+    a.feat = feat_in; a.wp = packed_w; a.bias = bias; a.hdr = hdr; a.nbr = nbr; a.rows = rows; a.out = out;
+    a.n_out = n_out; a.cin = cin; a.cout = cout; a.cout_pad = cout_pad_for(cout);
+    a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = act; a.slope = slope;
+    PCC_TRY(launch_mfma<MODE_CONV>(a, rows ? PCC_MAP_MAX_SEG : 0, s));
+  } else {
+    PCC_REQUIRE(cout <= 4, "pcc_conv_fwd: unsupported shape cin=%d cout=%d", cin, cout);
+    ThinArgs t;
+    t.feat = feat_in; t.wt = packed_w; t.bias = bias; t.hdr = hdr; t.nbr = nbr; t.rows = rows; t.out = out;
+    t.n_out = n_out; t.cin = cin; t.cout = cout; t.act = act; t.slope = slope;
+    int l = 0;
+    while ((1 << l) < cin && l < 6) ++l;
+    t.lpr_log2 = l;
+    const int64_t rpw = 64 >> l;
+    const int64_t waves = pcc_cdiv(n_out, rpw);
+    k_conv_thin<4><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(t);
+    PCC_LAUNCH_CHECK();
+  }
+  if (g_prof_on) {
+    PCC_TRY(prof_event(&e1, s));
+    ++g_launches;
+  }
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// GDN
+// ------------------------------------------------------------------------------------------
+__global__ void k_gdn_pack(const float* __restrict__ beta_raw, const float* __restrict__ gamma_raw, int c,
+                           float beta_bound, float gamma_bound, float pedestal, int cout_pad, int cb_log2,
+                           float* __restrict__ packed, float* __restrict__ beta_eff) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < c) {
+    const float b = fmaxf(beta_raw[t], beta_bound);
+    beta_eff[t] = b * b - pedestal;
+  }
+  const long long total = (long long)c * cout_pad;
+  if (t >= total) return;
+  // conv weight W[ci][co] = gamma[co][ci]; packed layout [ppo][cout_pad][CB]
+  const int CB = 1 << cb_log2;
+  const int within = (int)(t & (CB - 1));
+  const long long q = t >> cb_log2;
+  const int col = (int)(q % cout_pad);
+  const int cbi = (int)(q / cout_pad);
+  const int ci = (cbi << cb_log2) + within;
+  float v = 0.f;
+  if (col < c) {
+    const float g = fmaxf(gamma_raw[(long long)col * c + ci], gamma_bound);
+    v = g * g - pedestal;
+  }
+  packed[t] = v;
+}
+
+extern "C" int pcc_gdn_pack(const float* beta_raw, const float* gamma_raw, int32_t c, float beta_min, float* packed,
+                            float* beta_eff, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(beta_raw && gamma_raw && packed && beta_eff, "pcc_gdn_pack: NULL array");
+  PCC_REQUIRE(mfma_ok(c, c), "pcc_gdn: channel count %d unsupported (needs 8, 16 or a multiple of 32)", c);
+  const double pedestal = 1.0 / 68719476736.0;   // 2^-36
+  const float beta_bound = (float)sqrt((double)beta_min + pedestal);
+  const float gamma_bound = (float)sqrt(pedestal);
+  const int64_t total = (int64_t)c * cout_pad_for(c);
+  k_gdn_pack<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(beta_raw, gamma_raw, c, beta_bound, gamma_bound,
+                                                           (float)pedestal, cout_pad_for(c), cb_log2_for(c), packed,
+                                                           beta_eff);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* packed, const float* beta_eff,
+                           int32_t inverse, float* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(x && packed && beta_eff && out && x != out, "pcc_gdn_fwd: bad arguments");
+  PCC_REQUIRE(mfma_ok(c, c), "pcc_gdn: channel count %d unsupported", c);
+  ConvArgs a;
+  a.feat = x; a.wp = packed; a.bias = beta_eff; a.hdr = nullptr; a.nbr = nullptr; a.rows = nullptr; a.out = out;
+  a.n_out = n; a.cin = c; a.cout = c; a.cout_pad = cout_pad_for(c);
+  a.cb_log2 = cb_log2_for(c); a.ppo = c >> a.cb_log2; a.act = 0; a.slope = 0.f;
+  if (inverse) return launch_mfma<MODE_IGDN>(a, 0, s);
+  return launch_mfma<MODE_GDN>(a, 0, s);
+}

@@ -1,0 +1,140 @@
+// Hyperprior likelihood path: fused Gaussian-conditional kernel (scale bound, table index search,
+// quantisation, likelihood) and the factorised prior on the hyper latent.  Element-wise, HBM-bound.
+#include "pcc_common.h"
+
+static constexpr float SCALE_BOUND = 0.11f;
+static constexpr float LIK_BOUND = 1e-9f;
+
+__device__ inline float std_cum(float x) {           // 0.5 * erfc(-x / sqrt(2))
+  return 0.5f * erfcf(-0.70710678118654752440f * x);
+}
+
+__device__ inline int table_index(float s, const float* __restrict__ tab, int nt) {
+  // idx = (nt-1) - #{t < nt-1 : s <= tab[t]}   (GaussianConditional.build_indexes)
+  int idx = nt - 1;
+  for (int t = 0; t < nt - 1; ++t) idx -= (s <= tab[t]) ? 1 : 0;
+  return idx;
+}
+
+template <bool ENCODE>
+__global__ void __launch_bounds__(256) k_gauss(const float* __restrict__ y, const int* __restrict__ sym_in,
+                                               const float* __restrict__ params, const int64_t* __restrict__ keys,
+                                               const float* __restrict__ gain, long long n, int c,
+                                               const float* __restrict__ table, int nt, int* __restrict__ sym,
+                                               int* __restrict__ idx, float* __restrict__ lik,
+                                               float* __restrict__ y_hat) {
+  __shared__ float tab[256];
+  if (threadIdx.x < nt) tab[threadIdx.x] = table[threadIdx.x];
+  __syncthreads();
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * c) return;
+  const long long r = t / c;
+  const int ch = (int)(t - r * c);
+  const float scale = params[r * 2 * c + ch];
+  const float mean = params[r * 2 * c + c + ch];
+  float g = 1.f;
+  if (gain) g = gain[(keys[r] >> 48) * c + ch];
+  const float s = fmaxf(scale * g, SCALE_BOUND);
+  if (idx) idx[t] = table_index(s, tab, nt);
+  if (ENCODE) {
+    const float q = rintf(y[t] * g - mean * g);
+    if (sym) sym[t] = (int)q;
+    if (lik) {
+      const float a = fabsf(q);
+      const float up = std_cum((0.5f - a) / s);
+      const float lo = std_cum((-0.5f - a) / s);
+      lik[t] = fmaxf(up - lo, LIK_BOUND);
+    }
+  } else {
+    y_hat[t] = (float)sym_in[t] + mean * g;
+  }
+}
+
+extern "C" int pcc_gauss_encode(const float* y, const float* params, const int64_t* keys, const float* gain,
+                                int64_t n, int32_t c, const float* table, int32_t n_table, int32_t* sym, int32_t* idx,
+                                float* lik, void* stream) {
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(y && params && table && c >= 1 && n_table >= 2 && n_table <= 256, "pcc_gauss_encode: bad arguments");
+  PCC_REQUIRE(!gain || keys, "pcc_gauss_encode: gain needs keys");
+  k_gauss<true><<<(unsigned)pcc_cdiv(n * c, 256), 256, 0, (hipStream_t)stream>>>(y, nullptr, params, keys, gain, n, c,
+                                                                                 table, n_table, sym, idx, lik, nullptr);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_gauss_decode(const int32_t* sym, const float* params, const int64_t* keys, const float* gain,
+                                int64_t n, int32_t c, const float* table, int32_t n_table, float* y_hat, int32_t* idx,
+                                void* stream) {
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(sym && params && table && y_hat && c >= 1 && n_table >= 2 && n_table <= 256,
+              "pcc_gauss_decode: bad arguments");
+  PCC_REQUIRE(!gain || keys, "pcc_gauss_decode: gain needs keys");
+  k_gauss<false><<<(unsigned)pcc_cdiv(n * c, 256), 256, 0, (hipStream_t)stream>>>(nullptr, sym, params, keys, gain, n,
+                                                                                  c, table, n_table, nullptr, idx,
+                                                                                  nullptr, y_hat);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// factorised prior, filters (3,3,3,3): packed [c][58]
+// ------------------------------------------------------------------------------------------
+__device__ inline float eb_logits(const float* __restrict__ p, float x) {
+  const float* m0 = p;        const float* M1 = p + 3;  const float* M2 = p + 12; const float* M3 = p + 21;
+  const float* m4 = p + 30;   const float* b = p + 33;  const float* f = p + 46;
+  float h[3], g[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { h[i] = m0[i] * x + b[i]; h[i] += f[i] * tanhf(h[i]); }
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const float* M = (l == 0) ? M1 : (l == 1 ? M2 : M3);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = M[o * 3 + 0] * h[0];
+      v += M[o * 3 + 1] * h[1];
+      v += M[o * 3 + 2] * h[2];
+      v += b[3 + 3 * l + o];
+      g[o] = v + f[3 + 3 * l + o] * tanhf(v);
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) h[o] = g[o];
+  }
+  float v = m4[0] * h[0];
+  v += m4[1] * h[1];
+  v += m4[2] * h[2];
+  return v + b[12];
+}
+
+__device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) k_eb_encode(const float* __restrict__ z, long long n, int c,
+                                                   const float* __restrict__ packed, const float* __restrict__ med,
+                                                   int* __restrict__ sym, float* __restrict__ z_hat,
+                                                   float* __restrict__ lik) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * c) return;
+  const int ch = (int)(t % c);
+  const float m = med[ch];
+  const float q = rintf(z[t] - m);
+  const float zh = q + m;
+  if (sym) sym[t] = (int)q;
+  if (z_hat) z_hat[t] = zh;
+  if (lik) {
+    const float* p = packed + (long long)ch * 58;
+    const float lo = eb_logits(p, zh - 0.5f);
+    const float up = eb_logits(p, zh + 0.5f);
+    const float sum = lo + up;
+    const float sg = (sum > 0.f) ? -1.f : ((sum < 0.f) ? 1.f : 0.f);
+    lik[t] = fmaxf(fabsf(sigmoidf_(sg * up) - sigmoidf_(sg * lo)), LIK_BOUND);
+  }
+}
+
+extern "C" int pcc_eb_encode(const float* z, int64_t n, int32_t c, const float* eb_packed, const float* medians,
+                             int32_t* sym, float* z_hat, float* lik, void* stream) {
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(z && medians && c >= 1 && (!lik || eb_packed), "pcc_eb_encode: bad arguments");
+  k_eb_encode<<<(unsigned)pcc_cdiv(n * c, 256), 256, 0, (hipStream_t)stream>>>(z, n, c, eb_packed, medians, sym, z_hat,
+                                                                             lik);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}

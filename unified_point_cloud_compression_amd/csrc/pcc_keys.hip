@@ -1,0 +1,489 @@
+// Coordinate keys: pack/unpack, exclusive scan, LSD radix sort, adjacent unique, stride and
+// generative expansion of canonical coordinate sets.  All HBM-bound integer work:
+// 16-byte coalesced accesses, wave ballots for ranking, no atomics on global memory.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "pcc_common.h"
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void pcc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* pcc_last_error(void) { return g_err; }
+extern "C" int pcc_version(void) { return 100; }
+
+extern "C" int pcc_device_info(int* h_cu_count, char* h_arch, int h_arch_len) {
+  int dev = 0;
+  PCC_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  PCC_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+  if (h_cu_count) *h_cu_count = p.multiProcessorCount;
+  if (h_arch && h_arch_len > 0) {
+    strncpy(h_arch, p.gcnArchName, h_arch_len - 1);
+    h_arch[h_arch_len - 1] = 0;
+  }
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pack / unpack
+// ------------------------------------------------------------------------------------------
+__device__ inline int64_t pack4(int b, int x, int y, int z) {
+  return ((int64_t)b << 48) | ((int64_t)(x + PCC_BIAS) << 32) | ((int64_t)(y + PCC_BIAS) << 16) |
+         (int64_t)(z + PCC_BIAS);
+}
+
+__global__ void k_pack_i32(const int4* __restrict__ c, int64_t n, int64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 v = c[i];
+  keys[i] = pack4(v.x, v.y, v.z, v.w);
+}
+
+__global__ void k_pack_f32(const float4* __restrict__ c, int64_t n, int64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = c[i];
+  keys[i] = pack4((int)floorf(v.x), (int)floorf(v.y), (int)floorf(v.z), (int)floorf(v.w));
+}
+
+__global__ void k_unpack(const int64_t* __restrict__ keys, int64_t n, int4* __restrict__ c) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t k = keys[i];
+  int4 v;
+  v.x = (int)(k >> 48);
+  v.y = (int)((k >> 32) & 0xFFFF) - (int)PCC_BIAS;
+  v.z = (int)((k >> 16) & 0xFFFF) - (int)PCC_BIAS;
+  v.w = (int)(k & 0xFFFF) - (int)PCC_BIAS;
+  c[i] = v;
+}
+
+static inline dim3 grid1(int64_t n, int bs = 256) { return dim3((unsigned)pcc_cdiv(n, bs)); }
+
+extern "C" int pcc_keys_pack_i32(const int32_t* coords, int64_t n, int64_t* keys, void* stream) {
+  if (n == 0) return PCC_OK;
+  PCC_REQUIRE(coords && keys && n > 0, "pcc_keys_pack_i32: bad arguments");
+  k_pack_i32<<<grid1(n), 256, 0, (hipStream_t)stream>>>((const int4*)coords, n, keys);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_keys_pack_f32(const float* coords, int64_t n, int64_t* keys, void* stream) {
+  if (n == 0) return PCC_OK;
+  PCC_REQUIRE(coords && keys && n > 0, "pcc_keys_pack_f32: bad arguments");
+  k_pack_f32<<<grid1(n), 256, 0, (hipStream_t)stream>>>((const float4*)coords, n, keys);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_keys_unpack(const int64_t* keys, int64_t n, int32_t* coords, void* stream) {
+  if (n == 0) return PCC_OK;
+  PCC_REQUIRE(coords && keys && n > 0, "pcc_keys_unpack: bad arguments");
+  k_unpack<<<grid1(n), 256, 0, (hipStream_t)stream>>>(keys, n, (int4*)coords);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan (int32), 256 threads x 8 items per block, recursive over block sums
+// ------------------------------------------------------------------------------------------
+static constexpr int SCAN_T = 256;
+static constexpr int SCAN_I = 8;
+static constexpr int SCAN_B = SCAN_T * SCAN_I;  // 2048
+
+// block-wide exclusive scan of one value per thread; returns exclusive prefix, total in *total
+__device__ inline int block_excl_scan(int v, int* total) {
+  __shared__ int wsum[SCAN_T / PCC_WAVE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_T / PCC_WAVE; ++i) {
+    const int s = wsum[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_reduce(const int* __restrict__ in, int64_t n,
+                                                        int* __restrict__ sums) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_B + (int64_t)threadIdx.x * SCAN_I;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_I; ++i)
+    if (base + i < n) s += in[base + i];
+  int tot;
+  block_excl_scan(s, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_apply(const int* __restrict__ in, int64_t n,
+                                                       const int* __restrict__ offs,
+                                                       int* __restrict__ out) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_B + (int64_t)threadIdx.x * SCAN_I;
+  int v[SCAN_I];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_I; ++i) {
+    v[i] = (base + i < n) ? in[base + i] : 0;
+    s += v[i];
+  }
+  int tot;
+  int run = block_excl_scan(s, &tot) + (offs ? offs[blockIdx.x] : 0);
+#pragma unroll
+  for (int i = 0; i < SCAN_I; ++i) {
+    if (base + i < n) out[base + i] = run;
+    run += v[i];
+  }
+}
+
+size_t pcc_scan_ws_bytes(int64_t n) {
+  size_t tot = 0;
+  int64_t m = n;
+  while (m > SCAN_B) {
+    m = pcc_cdiv(m, SCAN_B);
+    tot += pcc_align_up((size_t)m * sizeof(int));
+  }
+  return tot + 256;
+}
+
+int pcc_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, size_t ws_bytes,
+                           hipStream_t s) {
+  if (n <= 0) return PCC_OK;
+  if (ws_bytes < pcc_scan_ws_bytes(n)) {
+    pcc_set_error("scan: workspace too small");
+    return PCC_EWS;
+  }
+  const int64_t nb = pcc_cdiv(n, SCAN_B);
+  if (nb == 1) {
+    k_scan_apply<<<1, SCAN_T, 0, s>>>(in, n, nullptr, out);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+  }
+  int* sums = (int*)ws;
+  const size_t used = pcc_align_up((size_t)nb * sizeof(int));
+  k_scan_reduce<<<(unsigned)nb, SCAN_T, 0, s>>>(in, n, sums);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(sums, sums, nb, (char*)ws + used, ws_bytes - used, s));
+  k_scan_apply<<<(unsigned)nb, SCAN_T, 0, s>>>(in, n, sums, out);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LSD radix sort, 8-bit digits, 2048 keys per block, stable.
+// ------------------------------------------------------------------------------------------
+static constexpr int RS_T = 256;
+static constexpr int RS_I = 8;
+static constexpr int RS_B = RS_T * RS_I;
+
+__global__ void __launch_bounds__(RS_T) k_rs_hist(const uint64_t* __restrict__ keys, int64_t n, int shift,
+                                                  int nblocks, int* __restrict__ hist) {
+  __shared__ int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_B;
+#pragma unroll
+  for (int r = 0; r < RS_I; ++r) {
+    const int64_t e = base + r * RS_T + threadIdx.x;
+    if (e < n) atomicAdd(&h[(int)((keys[e] >> shift) & 0xFF)], 1);
+  }
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+template <bool PAYLOAD>
+__global__ void __launch_bounds__(RS_T) k_rs_scatter(const uint64_t* __restrict__ keys,
+                                                     const int* __restrict__ pay_in, int64_t n, int shift,
+                                                     int nblocks, const int* __restrict__ offs,
+                                                     uint64_t* __restrict__ keys_out,
+                                                     int* __restrict__ pay_out) {
+  constexpr int NW = RS_T / PCC_WAVE;           // 4 waves
+  constexpr int NWR = NW * RS_I;                // 32 wave-rounds, in element order
+  __shared__ unsigned short wcount[NWR][256];   // 16 KB
+  __shared__ int gbase[256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < NWR * 256 / 2; i += RS_T) ((unsigned*)wcount)[i] = 0u;
+  gbase[tid] = offs[(int64_t)tid * nblocks + blockIdx.x];
+  __syncthreads();
+
+  const int64_t base = (int64_t)blockIdx.x * RS_B;
+  uint64_t key[RS_I];
+  int rank[RS_I];
+#pragma unroll
+  for (int r = 0; r < RS_I; ++r) {
+    const int64_t e = base + r * RS_T + tid;
+    const bool valid = e < n;
+    key[r] = valid ? keys[e] : 0;
+    const int d = (int)((key[r] >> shift) & 0xFF);
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1;
+      const unsigned long long bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    rank[r] = __popcll(peers & lt);
+    if (valid && rank[r] == 0) wcount[r * NW + w][d] = (unsigned short)__popcll(peers);
+  }
+  __syncthreads();
+  {  // per digit: exclusive prefix over the 32 wave-rounds
+    int run = 0;
+#pragma unroll 4
+    for (int i = 0; i < NWR; ++i) {
+      const int c = wcount[i][tid];
+      wcount[i][tid] = (unsigned short)run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_I; ++r) {
+    const int64_t e = base + r * RS_T + tid;
+    if (e < n) {
+      const int d = (int)((key[r] >> shift) & 0xFF);
+      const int64_t pos = (int64_t)gbase[d] + wcount[r * NW + w][d] + rank[r];
+      keys_out[pos] = key[r];
+      if (PAYLOAD) pay_out[pos] = pay_in ? pay_in[e] : (int)e;
+    }
+  }
+}
+
+__global__ void k_copy_keys_iota(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out,
+                                 int* __restrict__ perm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (out != in) out[i] = in[i];
+  if (perm) perm[i] = (int)i;
+}
+
+extern "C" size_t pcc_sort_ws_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  const int64_t nb = pcc_cdiv(n, RS_B);
+  return pcc_align_up((size_t)n * 8) + pcc_align_up((size_t)n * 4) + pcc_align_up((size_t)nb * 256 * 4) +
+         pcc_scan_ws_bytes(nb * 256) + 256;
+}
+
+extern "C" int pcc_sort_keys(const int64_t* keys_in, int64_t n, uint64_t bit_mask, int64_t* keys_out,
+                             int32_t* perm_out, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(keys_in && keys_out && keys_in != keys_out, "pcc_sort_keys: bad arguments");
+  PCC_REQUIRE(n < (1ll << 31), "pcc_sort_keys: n too large");
+  if (ws_bytes < pcc_sort_ws_bytes(n)) {
+    pcc_set_error("pcc_sort_keys: workspace too small");
+    return PCC_EWS;
+  }
+  const int64_t nb = pcc_cdiv(n, RS_B);
+  char* p = (char*)ws;
+  uint64_t* tmp_k = (uint64_t*)p;  p += pcc_align_up((size_t)n * 8);
+  int* tmp_p = (int*)p;            p += pcc_align_up((size_t)n * 4);
+  int* hist = (int*)p;             p += pcc_align_up((size_t)nb * 256 * 4);
+  void* scan_ws = p;
+  const size_t scan_bytes = ws_bytes - (size_t)(p - (char*)ws);
+
+  int shifts[8], np = 0;
+  for (int d = 0; d < 8; ++d)
+    if ((bit_mask >> (8 * d)) & 0xFF) shifts[np++] = 8 * d;
+  if (np == 0) {
+    k_copy_keys_iota<<<grid1(n), 256, 0, s>>>(keys_in, n, keys_out, perm_out);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+  }
+  const uint64_t* src_k = (const uint64_t*)keys_in;
+  const int* src_p = nullptr;
+  for (int i = 0; i < np; ++i) {
+    // last pass must land in keys_out / perm_out
+    const bool to_out = ((np - 1 - i) % 2) == 0;
+    uint64_t* dst_k = to_out ? (uint64_t*)keys_out : tmp_k;
+    int* dst_p = perm_out ? (to_out ? perm_out : tmp_p) : nullptr;
+    k_rs_hist<<<(unsigned)nb, RS_T, 0, s>>>(src_k, n, shifts[i], (int)nb, hist);
+    PCC_LAUNCH_CHECK();
+    PCC_TRY(pcc_scan_exclusive_i32(hist, hist, nb * 256, scan_ws, scan_bytes, s));
+    if (perm_out)
+      k_rs_scatter<true><<<(unsigned)nb, RS_T, 0, s>>>(src_k, src_p, n, shifts[i], (int)nb, hist, dst_k, dst_p);
+    else
+      k_rs_scatter<false><<<(unsigned)nb, RS_T, 0, s>>>(src_k, nullptr, n, shifts[i], (int)nb, hist, dst_k, nullptr);
+    PCC_LAUNCH_CHECK();
+    src_k = dst_k;
+    src_p = dst_p;
+  }
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// adjacent unique on sorted keys
+// ------------------------------------------------------------------------------------------
+__global__ void k_uniq_flags(const int64_t* __restrict__ k, int64_t n, int* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (i == 0 || k[i] != k[i - 1]) ? 1 : 0;
+}
+
+__global__ void k_uniq_scatter(const int64_t* __restrict__ k, int64_t n, const int* __restrict__ pos,
+                               int64_t* __restrict__ uniq, int* __restrict__ first,
+                               int64_t* __restrict__ d_count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool f = (i == 0 || k[i] != k[i - 1]);
+  if (f) {
+    uniq[pos[i]] = k[i];
+    if (first) first[pos[i]] = (int)i;
+  }
+  if (i == n - 1) *d_count = (int64_t)pos[i] + (f ? 1 : 0);
+}
+
+extern "C" size_t pcc_unique_ws_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return pcc_align_up((size_t)n * 4) + pcc_scan_ws_bytes(n) + 256;
+}
+
+extern "C" int pcc_unique_sorted(const int64_t* sorted_keys, int64_t n, int64_t* uniq, int32_t* first,
+                                 int64_t* d_count, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(d_count, "pcc_unique_sorted: d_count is NULL");
+  if (n <= 0) {
+    PCC_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int64_t), s));
+    return PCC_OK;
+  }
+  PCC_REQUIRE(sorted_keys && uniq && sorted_keys != uniq, "pcc_unique_sorted: bad arguments");
+  if (ws_bytes < pcc_unique_ws_bytes(n)) {
+    pcc_set_error("pcc_unique_sorted: workspace too small");
+    return PCC_EWS;
+  }
+  int* pos = (int*)ws;
+  char* p = (char*)ws + pcc_align_up((size_t)n * 4);
+  k_uniq_flags<<<grid1(n), 256, 0, s>>>(sorted_keys, n, pos);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(pos, pos, n, p, ws_bytes - (size_t)(p - (char*)ws), s));
+  k_uniq_scatter<<<grid1(n), 256, 0, s>>>(sorted_keys, n, pos, uniq, first, d_count);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+__global__ void k_is_canonical(const int64_t* __restrict__ k, int64_t n, int* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 || i >= n) return;
+  if (k[i] <= k[i - 1]) *flag = 0;   // benign race: every writer stores 0
+}
+
+extern "C" int pcc_keys_is_canonical(const int64_t* keys, int64_t n, int32_t* d_flag, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(d_flag, "pcc_keys_is_canonical: d_flag is NULL");
+  PCC_CHECK_HIP(hipMemsetAsync(d_flag, 1, sizeof(int), s));   // non-zero = canonical
+  if (n <= 1) return PCC_OK;
+  k_is_canonical<<<grid1(n), 256, 0, s>>>(keys, n, d_flag);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stride and generative expansion
+// ------------------------------------------------------------------------------------------
+__global__ void k_mask_keys(const int64_t* __restrict__ in, int64_t n, int64_t mask, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] & mask;
+}
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" size_t pcc_stride_ws_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return 2 * pcc_align_up((size_t)n * 8) + pcc_sort_ws_bytes(n) + pcc_unique_ws_bytes(n) + 256;
+}
+
+extern "C" int pcc_coords_stride(const int64_t* keys, int64_t n, int32_t new_stride, uint64_t bit_mask,
+                                 int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(d_count, "pcc_coords_stride: d_count is NULL");
+  PCC_REQUIRE(is_pow2(new_stride) && new_stride <= (1 << 14), "pcc_coords_stride: tensor stride %d is not a power of two",
+              new_stride);
+  if (n <= 0) {
+    PCC_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int64_t), s));
+    return PCC_OK;
+  }
+  if (ws_bytes < pcc_stride_ws_bytes(n)) {
+    pcc_set_error("pcc_coords_stride: workspace too small");
+    return PCC_EWS;
+  }
+  // floor(c/m)*m on a biased field == clearing its low bits (2^15 is a multiple of m)
+  const int64_t fm = 0xFFFF & ~(int64_t)(new_stride - 1);
+  const int64_t mask = (int64_t)((0xFFFFull << 48) | ((uint64_t)fm << 32) | ((uint64_t)fm << 16) | (uint64_t)fm);
+  char* p = (char*)ws;
+  int64_t* masked = (int64_t*)p;  p += pcc_align_up((size_t)n * 8);
+  int64_t* sorted = (int64_t*)p;  p += pcc_align_up((size_t)n * 8);
+  void* sort_ws = p;              p += pcc_sort_ws_bytes(n);
+  void* uniq_ws = p;
+  k_mask_keys<<<grid1(n), 256, 0, s>>>(keys, n, mask, masked);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_sort_keys(masked, n, bit_mask & (uint64_t)mask, sorted, nullptr, sort_ws, pcc_sort_ws_bytes(n), s));
+  PCC_TRY(pcc_unique_sorted(sorted, n, out_keys, nullptr, d_count, uniq_ws, pcc_unique_ws_bytes(n), s));
+  return PCC_OK;
+}
+
+__global__ void k_expand(const int64_t* __restrict__ in, int64_t n, int K, int ks, int step,
+                         int64_t* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * K) return;
+  const int64_t i = t / K;
+  const int k = (int)(t - i * K);
+  out[t] = in[i] + pcc_delta_of(k, ks, step);
+}
+
+extern "C" size_t pcc_expand_ws_bytes(int64_t n, int32_t kernel_size) {
+  if (n <= 0) return 256;
+  const int64_t m = n * kernel_size * kernel_size * kernel_size;
+  return 2 * pcc_align_up((size_t)m * 8) + pcc_sort_ws_bytes(m) + pcc_unique_ws_bytes(m) + 256;
+}
+
+extern "C" int pcc_coords_expand(const int64_t* keys, int64_t n, int32_t kernel_size, int32_t ts_out,
+                                 uint64_t bit_mask, int64_t* out_keys, int64_t* d_count, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(d_count, "pcc_coords_expand: d_count is NULL");
+  PCC_REQUIRE(kernel_size >= 1 && kernel_size <= 5 && ts_out >= 1, "pcc_coords_expand: unsupported kernel_size %d", kernel_size);
+  if (n <= 0) {
+    PCC_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int64_t), s));
+    return PCC_OK;
+  }
+  const int K = kernel_size * kernel_size * kernel_size;
+  const int64_t m = n * K;
+  PCC_REQUIRE(m < (1ll << 31), "pcc_coords_expand: too many candidates");
+  if (ws_bytes < pcc_expand_ws_bytes(n, kernel_size)) {
+    pcc_set_error("pcc_coords_expand: workspace too small");
+    return PCC_EWS;
+  }
+  char* p = (char*)ws;
+  int64_t* cand = (int64_t*)p;    p += pcc_align_up((size_t)m * 8);
+  int64_t* sorted = (int64_t*)p;  p += pcc_align_up((size_t)m * 8);
+  void* sort_ws = p;              p += pcc_sort_ws_bytes(m);
+  void* uniq_ws = p;
+  k_expand<<<grid1(m), 256, 0, s>>>(keys, n, K, kernel_size, ts_out, cand);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_sort_keys(cand, m, bit_mask, sorted, nullptr, sort_ws, pcc_sort_ws_bytes(m), s));
+  PCC_TRY(pcc_unique_sorted(sorted, m, out_keys, nullptr, d_count, uniq_ws, pcc_unique_ws_bytes(m), s));
+  return PCC_OK;
+}

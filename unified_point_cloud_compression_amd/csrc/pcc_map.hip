@@ -1,0 +1,293 @@
+// Kernel-map build over canonical (sorted) coordinate keys.
+//
+// conv map:        one segment, nbr[k][o] = row of (out_key[o] + off_k*step) in in_keys.
+// transposed map:  output rows are grouped (stably) by their residue class modulo the up-sampling
+//                  stride; a class lists only the kernel offsets congruent to its residue, so no
+//                  parity-impossible (in,out,k) candidate is ever stored or multiplied.
+// Queries of consecutive rows for one offset are monotone, so the binary searches of a wave walk
+// the same few cache lines of the sorted key array (L2-resident, coalesced).
+#include <string.h>
+
+#include "pcc_common.h"
+
+struct SegPlan {           // host-built, passed by value to k_write_hdr
+  int nseg;
+  int K;
+  int listed;              // 1: koffs[] lists the offsets of each segment
+  int k_count[PCC_MAP_MAX_SEG];
+  int koff_begin[PCC_MAP_MAX_SEG];
+  unsigned char koffs[192];
+};
+
+// class_begin: nullptr -> single segment covering [0, n_out)
+__global__ void k_write_hdr(SegPlan plan, const int* __restrict__ class_begin, int class_stride,
+                            int64_t n_out, int* __restrict__ hdr) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  hdr[HDR_NSEG] = plan.nseg;
+  hdr[HDR_K] = plan.K;
+  hdr[HDR_FLAGS] = plan.listed;
+  int64_t nbr_begin = 0;
+  for (int s = 0; s < plan.nseg; ++s) {
+    int pb = 0, pc = (int)n_out;
+    if (class_begin) {
+      pb = class_begin[s * class_stride];
+      const int pe = (s + 1 < plan.nseg) ? class_begin[(s + 1) * class_stride] : (int)n_out;
+      pc = pe - pb;
+    }
+    int* seg = hdr + HDR_SEG0 + s * SEG_WORDS;
+    seg[SEG_POS_BEGIN] = pb;
+    seg[SEG_POS_COUNT] = pc;
+    seg[SEG_K_COUNT] = plan.k_count[s];
+    seg[SEG_KOFF_BEGIN] = plan.koff_begin[s];
+    seg[SEG_NBR_LO] = (int)(nbr_begin & 0xFFFFFFFFll);
+    seg[SEG_NBR_HI] = (int)(nbr_begin >> 32);
+    nbr_begin += (int64_t)pc * plan.k_count[s];
+  }
+  for (int i = 0; i < plan.K && i < 192; ++i) hdr[HDR_KOFFS + i] = plan.listed ? plan.koffs[i] : i;
+}
+
+// pair counting without global atomics: one partial per block, summed by k_sum_counts
+__device__ inline void count_pairs(bool hit, int* __restrict__ block_counts) {
+  if (!block_counts) return;   // kernel-uniform
+  __shared__ int wc[4];
+  const unsigned long long m = __ballot(hit);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    block_counts[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+__global__ void __launch_bounds__(1024) k_sum_counts(const int* __restrict__ c, int64_t n,
+                                                     int64_t* __restrict__ total) {
+  __shared__ long long ws[16];
+  long long s = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += c[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long t = 0;
+    for (int i = 0; i < 16; ++i) t += ws[i];
+    *total = t;
+  }
+}
+
+// conv: thread per (k, o), o fastest
+__global__ void __launch_bounds__(256) k_map_conv(const int64_t* __restrict__ in_keys, int n_in,
+                                                  const int64_t* __restrict__ out_keys, int64_t n_out, int ks,
+                                                  int step, int* __restrict__ nbr,
+                                                  int* __restrict__ d_pairs) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  int idx = -1;
+  if (o < n_out) {
+    idx = pcc_find(in_keys, n_in, out_keys[o] + pcc_delta_of(k, ks, step));
+    nbr[(int64_t)k * n_out + o] = idx;
+  }
+  count_pairs(idx >= 0, d_pairs);
+}
+
+// transposed: class id per output row (as a sortable 64-bit key)
+__global__ void k_classify(const int64_t* __restrict__ out_keys, int64_t n_out, int log2_step, int stride,
+                           uint64_t* __restrict__ cls) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  const int64_t k = out_keys[o];
+  const int m = stride - 1;
+  const int rx = (int)((k >> 32) & 0xFFFF) >> log2_step & m;
+  const int ry = (int)((k >> 16) & 0xFFFF) >> log2_step & m;
+  const int rz = (int)(k & 0xFFFF) >> log2_step & m;
+  cls[o] = (uint64_t)(rx + stride * (ry + stride * rz));
+}
+
+// class begin positions from the class-sorted id array (ids ascending): begin[c] = first p with id>=c
+__global__ void k_class_begin(const uint64_t* __restrict__ sorted_cls, int64_t n, int nclass,
+                              int* __restrict__ begin) {
+  const int c = threadIdx.x;
+  if (c >= nclass) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted_cls[mid] < (uint64_t)c) lo = mid + 1; else hi = mid;
+  }
+  begin[c] = (int)lo;
+}
+
+// transposed: thread per (slot j, position p), p fastest; in = out - off*step
+__global__ void __launch_bounds__(256) k_map_transposed(const int64_t* __restrict__ in_keys, int n_in,
+                                                        const int64_t* __restrict__ out_keys, int64_t n_out,
+                                                        int ks, int step, const int* __restrict__ hdr,
+                                                        const int* __restrict__ rows, int* __restrict__ nbr,
+                                                        int* __restrict__ d_pairs) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  bool hit = false;
+  if (p < n_out) {
+    const int nseg = hdr[HDR_NSEG];
+    int s = 0;
+    for (; s < nseg - 1; ++s) {
+      const int* sg = hdr + HDR_SEG0 + s * SEG_WORDS;
+      if (p < (int64_t)sg[SEG_POS_BEGIN] + sg[SEG_POS_COUNT]) break;
+    }
+    const int* sg = hdr + HDR_SEG0 + s * SEG_WORDS;
+    if (j < sg[SEG_K_COUNT]) {
+      const int kid = hdr[HDR_KOFFS + sg[SEG_KOFF_BEGIN] + j];
+      const int o = rows[p];
+      const int idx = pcc_find(in_keys, n_in, out_keys[o] - pcc_delta_of(kid, ks, step));
+      const int64_t nb = ((int64_t)(unsigned)sg[SEG_NBR_LO]) | ((int64_t)sg[SEG_NBR_HI] << 32);
+      nbr[nb + (int64_t)j * sg[SEG_POS_COUNT] + (p - sg[SEG_POS_BEGIN])] = idx;
+      hit = idx >= 0;
+    }
+  }
+  count_pairs(hit, d_pairs);
+}
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static int max_class_k(int ks, int stride) {
+  // offsets per axis congruent to a residue: max over residues
+  int best = 0;
+  for (int r = 0; r < stride; ++r) {
+    int c = 0;
+    for (int i = 0; i < ks; ++i) {
+      const int off = (ks & 1) ? i - (ks - 1) / 2 : i;
+      if (((off % stride) + stride) % stride == r) ++c;
+    }
+    if (c > best) best = c;
+  }
+  return best * best * best;
+}
+
+extern "C" int64_t pcc_map_nbr_elems(int64_t n_out, int32_t kernel_size, int32_t stride, int32_t transposed) {
+  const int64_t K = (int64_t)kernel_size * kernel_size * kernel_size;
+  if (!transposed) return n_out * K;
+  return n_out * max_class_k(kernel_size, stride);
+}
+
+extern "C" size_t pcc_map_ws_bytes(int64_t n_out) {
+  if (n_out <= 0) return 256;
+  // class ids (2x) + class sort + one pair-count partial per build block (K <= 125 grid rows)
+  return 2 * pcc_align_up((size_t)n_out * 8) + pcc_sort_ws_bytes(n_out) +
+         pcc_align_up((size_t)pcc_cdiv(n_out, 256) * 128 * 4) + 1024;
+}
+
+extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys,
+                                    int64_t n_out, int32_t kernel_size, int32_t step, int32_t stride,
+                                    int32_t transposed, int32_t* hdr, int32_t* nbr, int32_t* rows,
+                                    int64_t* d_pairs, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(hdr, "pcc_kernel_map_build: hdr is NULL");
+  PCC_REQUIRE(kernel_size >= 1 && kernel_size <= 5, "pcc_kernel_map_build: kernel_size %d unsupported", kernel_size);
+  PCC_REQUIRE(step >= 1 && (step & (step - 1)) == 0, "pcc_kernel_map_build: step %d is not a power of two", step);
+  PCC_REQUIRE(n_in < (1ll << 31) && n_out < (1ll << 31), "pcc_kernel_map_build: too many rows");
+  const int K = kernel_size * kernel_size * kernel_size;
+  if (d_pairs) PCC_CHECK_HIP(hipMemsetAsync(d_pairs, 0, sizeof(int64_t), s));
+  if (n_out > 0 && ws_bytes < pcc_map_ws_bytes(n_out)) {
+    pcc_set_error("pcc_kernel_map_build: workspace too small");
+    return PCC_EWS;
+  }
+  PCC_REQUIRE(n_out == 0 || ws, "pcc_kernel_map_build: ws is NULL");
+  // pair-count partials live at the front of the workspace
+  int* block_counts = d_pairs ? (int*)ws : nullptr;
+  const size_t bc_bytes = pcc_align_up((size_t)pcc_cdiv(n_out > 0 ? n_out : 1, 256) * 128 * 4);
+  SegPlan plan;
+  memset(&plan, 0, sizeof(plan));
+  plan.K = K;
+  if (!transposed) {
+    plan.nseg = 1;
+    plan.listed = 0;
+    plan.k_count[0] = K;
+    plan.koff_begin[0] = 0;
+    k_write_hdr<<<1, 1, 0, s>>>(plan, nullptr, 0, n_out, hdr);
+    PCC_LAUNCH_CHECK();
+    if (n_out == 0) return PCC_OK;
+    PCC_REQUIRE(in_keys && out_keys && nbr, "pcc_kernel_map_build: NULL array");
+    dim3 grid((unsigned)pcc_cdiv(n_out, 256), (unsigned)K);
+    k_map_conv<<<grid, 256, 0, s>>>(in_keys, (int)n_in, out_keys, n_out, kernel_size, step, nbr, block_counts);
+    PCC_LAUNCH_CHECK();
+    if (d_pairs) {
+      k_sum_counts<<<1, 1024, 0, s>>>(block_counts, (int64_t)grid.x * grid.y, d_pairs);
+      PCC_LAUNCH_CHECK();
+    }
+    return PCC_OK;
+  }
+  // ---- transposed ------------------------------------------------------------------------------
+  PCC_REQUIRE(stride == 1 || stride == 2, "pcc_kernel_map_build: transposed stride %d unsupported", stride);
+  const int nclass = stride * stride * stride;
+  plan.nseg = nclass;
+  plan.listed = 1;
+  int fill = 0;
+  for (int c = 0; c < nclass; ++c) {
+    const int rx = c % stride, ry = (c / stride) % stride, rz = c / (stride * stride);
+    plan.koff_begin[c] = fill;
+    for (int kid = 0; kid < K; ++kid) {
+      int dx, dy, dz;
+      pcc_offset_of(kid, kernel_size, dx, dy, dz);
+      auto md = [&](int v) { return ((v % stride) + stride) % stride; };
+      if (md(dx) == rx && md(dy) == ry && md(dz) == rz) plan.koffs[fill++] = (unsigned char)kid;
+    }
+    plan.k_count[c] = fill - plan.koff_begin[c];
+  }
+  if (n_out == 0) {
+    k_write_hdr<<<1, 1, 0, s>>>(plan, nullptr, 0, 0, hdr);   // all segments empty
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+  }
+  PCC_REQUIRE(in_keys && out_keys && nbr && rows, "pcc_kernel_map_build: NULL array (transposed needs rows)");
+  char* p = (char*)ws + bc_bytes;
+  uint64_t* cls = (uint64_t*)p;         p += pcc_align_up((size_t)n_out * 8);
+  uint64_t* cls_sorted = (uint64_t*)p;  p += pcc_align_up((size_t)n_out * 8);
+  int* class_begin = (int*)p;           p += 1024;
+  void* sort_ws = p;
+  dim3 g1((unsigned)pcc_cdiv(n_out, 256));
+  k_classify<<<g1, 256, 0, s>>>(out_keys, n_out, ilog2(step), stride, cls);
+  PCC_LAUNCH_CHECK();
+  // stable counting sort by class == one radix pass; payload = output row of each position
+  PCC_TRY(pcc_sort_keys((const int64_t*)cls, n_out, 0xFFull, (int64_t*)cls_sorted, rows, sort_ws,
+                        ws_bytes - (size_t)(p - (char*)ws), s));
+  k_class_begin<<<1, 64, 0, s>>>(cls_sorted, n_out, nclass, class_begin);
+  PCC_LAUNCH_CHECK();
+  k_write_hdr<<<1, 1, 0, s>>>(plan, class_begin, 1, n_out, hdr);
+  PCC_LAUNCH_CHECK();
+  dim3 grid((unsigned)pcc_cdiv(n_out, 256), (unsigned)max_class_k(kernel_size, stride));
+  k_map_transposed<<<grid, 256, 0, s>>>(in_keys, (int)n_in, out_keys, n_out, kernel_size, step, hdr, rows, nbr,
+                                        block_counts);
+  PCC_LAUNCH_CHECK();
+  if (d_pairs) {
+    k_sum_counts<<<1, 1024, 0, s>>>(block_counts, (int64_t)grid.x * grid.y, d_pairs);
+    PCC_LAUNCH_CHECK();
+  }
+  return PCC_OK;
+}
+
+// dense [K][n_out] view (tests / inspection)
+__global__ void k_map_dense(const int* __restrict__ hdr, const int* __restrict__ nbr, const int* __restrict__ rows,
+                            int64_t n_out, int* __restrict__ dense) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (p >= n_out) return;
+  const int nseg = hdr[HDR_NSEG];
+  int s = 0;
+  for (; s < nseg - 1; ++s) {
+    const int* sg = hdr + HDR_SEG0 + s * SEG_WORDS;
+    if (p < (int64_t)sg[SEG_POS_BEGIN] + sg[SEG_POS_COUNT]) break;
+  }
+  const int* sg = hdr + HDR_SEG0 + s * SEG_WORDS;
+  if (j >= sg[SEG_K_COUNT]) return;
+  const int kid = hdr[HDR_KOFFS + sg[SEG_KOFF_BEGIN] + j];
+  const int64_t nb = ((int64_t)(unsigned)sg[SEG_NBR_LO]) | ((int64_t)sg[SEG_NBR_HI] << 32);
+  const int o = rows ? rows[p] : (int)p;
+  dense[(int64_t)kid * n_out + o] = nbr[nb + (int64_t)j * sg[SEG_POS_COUNT] + (p - sg[SEG_POS_BEGIN])];
+}
+
+extern "C" int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows, int64_t n_out,
+                                int32_t K, int32_t* dense, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out <= 0) return PCC_OK;
+  PCC_REQUIRE(hdr && nbr && dense && K >= 1 && K <= 192, "pcc_map_to_dense: bad arguments");
+  PCC_CHECK_HIP(hipMemsetAsync(dense, 0xFF, (size_t)n_out * K * sizeof(int), s));
+  dim3 grid((unsigned)pcc_cdiv(n_out, 256), (unsigned)K);
+  k_map_dense<<<grid, 256, 0, s>>>(hdr, nbr, rows, n_out, dense);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}

@@ -1,0 +1,129 @@
+"""ctypes binding of libpcc_hip.so (the C ABI declared in include/pcc_hip.h).
+
+PyTorch-ROCm supplies device memory (`tensor.data_ptr()`) and the HIP stream; every kernel on the
+hot path lives in the shared library.  There is NO CPU fallback: if the library is missing or a
+call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcc_hip.so")
+
+MAP_HDR_INTS = 256
+MAP_MAX_SEG = 8
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+_p = C.c_void_p
+_i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pcc_hip.h one to one
+SIGNATURES = {
+    "pcc_version": (C.c_int, []),
+    "pcc_last_error": (C.c_char_p, []),
+    "pcc_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "pcc_keys_pack_i32": (C.c_int, [_p, _i64, _p, _p]),
+    "pcc_keys_pack_f32": (C.c_int, [_p, _i64, _p, _p]),
+    "pcc_keys_unpack": (C.c_int, [_p, _i64, _p, _p]),
+    "pcc_sort_ws_bytes": (_sz, [_i64]),
+    "pcc_sort_keys": (C.c_int, [_p, _i64, _u64, _p, _p, _p, _sz, _p]),
+    "pcc_unique_ws_bytes": (_sz, [_i64]),
+    "pcc_unique_sorted": (C.c_int, [_p, _i64, _p, _p, _p, _p, _sz, _p]),
+    "pcc_keys_is_canonical": (C.c_int, [_p, _i64, _p, _p]),
+    "pcc_stride_ws_bytes": (_sz, [_i64]),
+    "pcc_coords_stride": (C.c_int, [_p, _i64, _i32, _u64, _p, _p, _p, _sz, _p]),
+    "pcc_expand_ws_bytes": (_sz, [_i64, _i32]),
+    "pcc_coords_expand": (C.c_int, [_p, _i64, _i32, _i32, _u64, _p, _p, _p, _sz, _p]),
+    "pcc_map_nbr_elems": (_i64, [_i64, _i32, _i32, _i32]),
+    "pcc_map_ws_bytes": (_sz, [_i64]),
+    "pcc_kernel_map_build": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    "pcc_map_to_dense": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
+    "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
+    "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "pcc_conv_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _f32, _p]),
+    "pcc_gdn_pack": (C.c_int, [_p, _p, _i32, _f32, _p, _p, _p]),
+    "pcc_gdn_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p]),
+    "pcc_topk_ws_bytes": (_sz, [_i64]),
+    "pcc_topk_mask": (C.c_int, [_p, _i64, C.POINTER(_i64), C.POINTER(_i64), _i32, _p, _p, _sz, _p]),
+    "pcc_prune_ws_bytes": (_sz, [_i64]),
+    "pcc_prune_rows": (C.c_int, [_p, _i64, _p, _p, _i32, _p, _p, _p, _p, _sz, _p]),
+    "pcc_lookup_gather": (C.c_int, [_p, _i64, _p, _i32, _p, _i64, _p, _p]),
+    "pcc_lookup_rows": (C.c_int, [_p, _i64, _p, _i64, _p, _p]),
+    "pcc_gauss_encode": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i32, _p, _p, _p, _p]),
+    "pcc_gauss_decode": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i32, _p, _p, _p]),
+    "pcc_eb_encode": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "pcc_prof_enable": (C.c_int, [_i32]),
+    "pcc_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64)]),
+}
+
+_lib = None
+
+
+class PccError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpcc_hip.so and declare every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PccError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C unified_point_cloud_compression_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().pcc_last_error()
+        raise PccError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous and on a GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PccError("libpcc_hip operates on GPU tensors only (no CPU fallback); got a CPU tensor")
+    if not t.is_contiguous():
+        raise PccError("non-contiguous tensor handed to libpcc_hip")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """One growing scratch buffer per device; calls are stream-ordered so it is shared."""
+    key = torch.device(device).index or 0
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _ws[key] = buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+    return buf
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)
+
+
+def device_info():
+    lib = load()
+    cu = C.c_int(0)
+    arch = C.create_string_buffer(64)
+    check(lib.pcc_device_info(C.byref(cu), arch, 64), "pcc_device_info")
+    return cu.value, arch.value.decode()

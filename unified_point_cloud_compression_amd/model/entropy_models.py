@@ -1,0 +1,177 @@
+"""Mean-scale hyperprior: counterpart of the reference's `model/entropy_models.py`.
+
+Same module names (`h_a`, `h_s`, `scale_nn`, `rescale_nn`, `quant_nn`, `entropy_bottleneck`,
+`gaussian_conditional`) and the same arithmetic as `MeanScaleHyperprior.compress/decompress/forward`
+(`model/entropy_models.py:236-490`), on [N,C] rows:
+
+  * every coordinate set is stored in canonical (b,x,y,z) order and the convolutions are deterministic
+    (fixed summation order, no atomics), so the reference's `Sorted*` wrappers and `sort_tensor` /
+    `sort_points` calls (`model/entropy_models.py:28-126,364-365,432-433`) are identities here;
+  * LeakyReLU is fused into the producing convolution's epilogue;
+  * scale bound, gain, table-index search, quantisation and likelihood are one kernel (`pcc_gauss_*`).
+
+The entropy-coder boundary carries integer symbols this round (rANS byte coding = SURVEY 8f row 1).
+"""
+import torch
+import torch.nn as nn
+
+from .. import MinkowskiEngine as ME
+from .. import lib as L
+from .. import sparse as S
+from ..MinkowskiEngine.sparse_tensor import SparseTensor
+from ..compressai.entropy_models import EntropyBottleneck, GaussianConditional
+from ..compressai.models.base import CompressionModel
+from ..compressai.ops import LowerBound
+
+
+class SortedMinkowskiConvolution(ME.MinkowskiConvolution):
+    """Kept for state-dict / API parity; canonical storage makes the sort a no-op."""
+
+
+class SortedMinkowskiGenerativeConvolutionTranspose(ME.MinkowskiGenerativeConvolutionTranspose):
+    pass
+
+
+class SortedMinkowskiLeakyReLU(ME.MinkowskiLeakyReLU):
+    pass
+
+
+def _mlp(sizes, last=None):
+    layers = []
+    for i in range(len(sizes) - 1):
+        layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+        if i < len(sizes) - 2:
+            layers.append(nn.ReLU())
+    if last is not None:
+        layers.append(last)
+    return nn.Sequential(*layers)
+
+
+class MeanScaleHyperprior(CompressionModel):
+    def __init__(self, config):
+        super().__init__()
+        Cb, Ch = config["C_bottleneck"], config["C_hyper_bottleneck"]
+        self.inverse_rescaling = config["inverse_rescaling"]
+        self.quantization_mode = config["quantization_mode"]
+        self.entropy_bottleneck_vbr = config["entropy_bottleneck_vbr"]
+        self.adaptive_BN = config["adaptive_BN"] if "adaptive_BN" in config else True
+        self.eps = 0.0001
+        self.quantization_offset = config["quantization_offset"]
+        if self.entropy_bottleneck_vbr:
+            raise L.PccError("entropy_bottleneck_vbr is training-only in the reference (`model/entropy_models.py:275`) "
+                             "and not built")
+        self.gaussian_conditional = GaussianConditional(None)
+        self.entropy_bottleneck = EntropyBottleneck(Ch)
+        conv, gen = ME.MinkowskiConvolution, SortedMinkowskiGenerativeConvolutionTranspose
+        self.h_a = nn.Sequential(
+            conv(in_channels=Cb, out_channels=Ch, kernel_size=3, dimension=3),
+            ME.MinkowskiLeakyReLU(inplace=False),
+            conv(in_channels=Ch, out_channels=Ch, kernel_size=3, stride=2, dimension=3),
+            ME.MinkowskiLeakyReLU(inplace=False),
+            conv(in_channels=Ch, out_channels=Ch, kernel_size=3, stride=2, dimension=3),
+        )
+        self.h_s = nn.Sequential(
+            gen(in_channels=Ch, out_channels=Ch, kernel_size=2, stride=2, bias=True, dimension=3),
+            SortedMinkowskiLeakyReLU(inplace=False),
+            gen(in_channels=Ch, out_channels=Cb * 3 // 2, kernel_size=2, stride=2, bias=True, dimension=3),
+            SortedMinkowskiLeakyReLU(inplace=False),
+            SortedMinkowskiConvolution(in_channels=Cb * 3 // 2, out_channels=Cb * 2, kernel_size=3, stride=1,
+                                       dimension=3, bias=True),
+        )
+        self.scale_nn = _mlp([2, 8, Cb // 4, Cb], nn.Softplus())
+        self.rescale_nn = _mlp([2, 8, Cb // 4, Cb], nn.Softplus())
+        self.quant_nn = _mlp([2, 10, 10, 1])
+
+    # ---- fused sub-networks (same arithmetic as the Sequentials above) -------------------------------
+    @staticmethod
+    def _conv_act(layer, x, act):
+        cs = x._cset
+        if isinstance(layer, ME.MinkowskiGenerativeConvolutionTranspose):
+            out_set = cs.expand(layer.kernel_size, cs.ts // layer.stride)
+            kmap = cs.kernel_map(out_set, layer.kernel_size, transposed=True, up_stride=layer.stride)
+        else:
+            out_set = cs if layer.stride == 1 else cs.stride(cs.ts * layer.stride)
+            kmap = cs.kernel_map(out_set, layer.kernel_size)
+        f = layer._apply_conv(x, out_set, kmap, act=act, slope=0.01)
+        return SparseTensor._from_canonical(out_set, f)
+
+    def hyper_analysis(self, y):
+        x = self._conv_act(self.h_a[0], y, L.ACT_LEAKY)
+        x = self._conv_act(self.h_a[2], x, L.ACT_LEAKY)
+        return self._conv_act(self.h_a[4], x, L.ACT_NONE)
+
+    def hyper_synthesis(self, z_hat):
+        x = self._conv_act(self.h_s[0], z_hat, L.ACT_LEAKY)
+        x = self._conv_act(self.h_s[2], x, L.ACT_LEAKY)
+        return self._conv_act(self.h_s[4], x, L.ACT_NONE)
+
+    def get_offsets(self, stddev, scale):
+        """`quant_nn` on (scale, stddev) pairs per element (`model/entropy_models.py:218-233`)."""
+        return self.quant_nn(torch.stack([scale, stddev], dim=-1)).squeeze(-1)
+
+    def _gains(self, q, y_cset, n_ch):
+        """(scale rows [nb,C] | None, rescale rows [nb,C] | None) indexed by batch id
+        (`model/entropy_models.py:386-393,451-465`)."""
+        if not self.adaptive_BN:
+            return None, None
+        scale = self.scale_nn(q) + self.eps
+        rescale = 1.0 / scale if self.inverse_rescaling else 1.0 / self.rescale_nn(q)
+        return scale.to(torch.float32).contiguous(), rescale.to(torch.float32).contiguous()
+
+    def _gaussian_params(self, z_hat, y_cset):
+        g = self.hyper_synthesis(z_hat)
+        return S.lookup_gather(g._cset, g._canonical_features(), y_cset.keys, y_cset.n)   # [Ny, 2C]
+
+    # ---- reference API ---------------------------------------------------------------------------------
+    def compress(self, y, q):
+        """Returns (points, symbols, shape): `points` = [y.C, z.C]; `symbols` = [y_symbols [Ny,C] int32,
+        z_symbols [Nz,Ch] int32] standing where the reference returns rANS strings
+        (`model/entropy_models.py:344-406`)."""
+        z = self.hyper_analysis(y)
+        z_sym, z_hat_f, _ = self.entropy_bottleneck.encode_rows(z._canonical_features(), want_likelihood=False)
+        z_hat = SparseTensor._from_canonical(z._cset, z_hat_f)
+        params = self._gaussian_params(z_hat, y._cset)
+        scale, _ = self._gains(q, y._cset, y.F.shape[1])
+        y_sym, _, _ = self.gaussian_conditional.encode_rows(y._canonical_features(), params, y._cset.keys, scale,
+                                                            want_likelihood=False)
+        return [y.C, z.C], [y_sym, z_sym], [z._cset.n]
+
+    def likelihoods(self, y, q):
+        """Eval-mode likelihoods of y and z (what `forward` feeds the rate loss, `loss.py:63-81`)."""
+        z = self.hyper_analysis(y)
+        _, z_hat_f, z_lik = self.entropy_bottleneck.encode_rows(z._canonical_features())
+        params = self._gaussian_params(SparseTensor._from_canonical(z._cset, z_hat_f), y._cset)
+        scale, _ = self._gains(q, y._cset, y.F.shape[1])
+        _, _, y_lik = self.gaussian_conditional.encode_rows(y._canonical_features(), params, y._cset.keys, scale)
+        return y_lik, z_lik
+
+    def decompress(self, points, symbols, shape, q):
+        """points = [y coords | y SparseTensor, z coords]; symbols = [y_symbols, z_symbols]
+        (`model/entropy_models.py:409-490`).  Returns y_hat as a stride-8 SparseTensor."""
+        assert isinstance(symbols, list) and len(symbols) == 2
+        assert isinstance(points, list) and len(points) == 2
+        y_sym, z_sym = symbols
+        y_cset, z_cset = points
+        med = self.entropy_bottleneck.quantiles[:, 0, 1].detach().to(torch.float32)
+        z_hat = SparseTensor._from_canonical(z_cset, z_sym.to(torch.float32) + med[None, :])
+        params = self._gaussian_params(z_hat, y_cset)
+        scale, rescale = self._gains(q, y_cset, y_sym.shape[1])
+        if self.quantization_offset:
+            c = y_sym.shape[1]
+            scales_hat, means_hat = params[:, :c], params[:, c:]
+            b = (y_cset.keys[:y_cset.n] >> 48)
+            g = scale[b] if scale is not None else torch.ones_like(scales_hat)
+            rg = rescale[b] if rescale is not None else torch.ones_like(scales_hat)
+            qv = y_sym.to(torch.float32)
+            q_abs, signs = qv.abs(), torch.sign(qv)
+            stdev = self.gaussian_conditional.lower_bound_scale(scales_hat * g)
+            off = -self.get_offsets(stdev, g)
+            off[q_abs < 0.0001] = 0
+            y_hat = signs * (q_abs + off) * rg + means_hat
+        else:
+            y_hat, _ = self.gaussian_conditional.decode_rows(y_sym, params, y_cset.keys, scale)
+        return SparseTensor._from_canonical(y_cset, y_hat)
+
+    def forward(self, y, q):
+        raise L.PccError("MeanScaleHyperprior.forward (training proxy quantisation + backward) is BASELINE config 4, "
+                         "not built in this round; use likelihoods() for eval-mode rate")

@@ -1,0 +1,101 @@
+"""`UnifiedModel`: counterpart of the reference's `model/model.py:15-250` (compress / decompress / update).
+
+Same call signatures and return structure as the reference when `path is None`:
+  compress(pointcloud[N,6], q[1,2], block_size) -> (bitstreams, block_shapes, block_k, block_coordinates,
+  block_q_vals), one entry per block; decompress(coordinates=, strings=, shape=, k=, q_vals=) -> [N,6].
+`bitstreams[i]` holds [y_symbols, z_symbols] (int32 device tensors) where the reference holds rANS strings
+(entropy coder = SURVEY 8f row 1); the file container / G-PCC coordinate coder (`path=`) are out of scope.
+"""
+import torch
+
+from .. import lib as L
+from .. import sparse as S
+from ..MinkowskiEngine.sparse_tensor import SparseTensor
+from ..compressai.models.base import CompressionModel
+from .entropy_models import MeanScaleHyperprior
+from .transforms import AnalysisTransform, SparseSynthesisTransform
+
+
+class UnifiedModel(CompressionModel):
+    def __init__(self, config):
+        super().__init__()
+        self.g_a = AnalysisTransform(config["g_a"])
+        self.g_s = SparseSynthesisTransform(config["g_s"])
+        self.entropy_model = MeanScaleHyperprior(config["entropy_model"])
+
+    def update(self):
+        self.entropy_model.update(force=True)
+
+    def aux_loss(self):
+        return self.entropy_model.aux_loss()
+
+    def forward(self, x, q, Lambda):
+        raise L.PccError("UnifiedModel.forward (training step, BASELINE config 4) is not built in this round")
+
+    @staticmethod
+    def partition(pointcloud, block_size):
+        """Block partition (`model/model.py:121-127`): blocks ordered by (ix, iy, iz), points keep input order."""
+        xyz = pointcloud[:, :3]
+        mn = xyz.amin(dim=0)
+        bi = ((xyz - mn) / block_size).floor().to(torch.int64)
+        code = bi[:, 0] * 10 ** 6 + bi[:, 1] * 10 ** 3 + bi[:, 2]
+        if int(code.max().item()) == 0:
+            return None, [pointcloud.shape[0]]
+        order = torch.argsort(code, stable=True)
+        _, counts = torch.unique_consecutive(code[order], return_counts=True)
+        return order, counts.tolist()
+
+    @staticmethod
+    def block_input(x_block):
+        """floor -> int32, de-duplicate (first wins), features [1, r, g, b] (`model/model.py:141-161`)."""
+        n = x_block.shape[0]
+        coords = torch.cat([torch.zeros((n, 1), device=x_block.device, dtype=x_block.dtype), x_block[:, :3]], dim=1)
+        feats = torch.cat([torch.ones((n, 1), device=x_block.device, dtype=torch.float32),
+                           x_block[:, 3:6].to(torch.float32)], dim=1)
+        return SparseTensor(coordinates=coords, features=feats, device=x_block.device)
+
+    @torch.no_grad()
+    def compress(self, pointcloud, q, path=None, block_size=1024, scaling_factor=1.0):
+        if path:
+            raise L.PccError("file container + G-PCC coordinate coder (`model/model.py:253-486`) are out of scope (8f)")
+        if not pointcloud.is_cuda:
+            raise L.PccError("compress expects the point cloud on the GPU (`utils.py:436-441` moves it there)")
+        if scaling_factor != 1.0:
+            pointcloud = pointcloud.clone()
+            pointcloud[:, :3] = torch.round(pointcloud[:, :3] / scaling_factor).int()
+        order, counts = self.partition(pointcloud, block_size)
+        xs = pointcloud if order is None else pointcloud[order]
+        bitstreams, block_shapes, block_coordinates, block_q_vals, block_k = [], [], [], [], []
+        start = 0
+        for count in counts:
+            x = self.block_input(xs[start:start + count])
+            y, k = self.g_a(x)
+            _, symbols, shape = self.entropy_model.compress(y, q)
+            block_q_vals.append(q)
+            block_coordinates.append(y.C)
+            block_shapes.append(shape)
+            block_k.append(k)
+            bitstreams.append(symbols)
+            start += count
+        return bitstreams, block_shapes, block_k, block_coordinates, block_q_vals
+
+    @torch.no_grad()
+    def decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None, q_vals=None, trace=None):
+        if path:
+            raise L.PccError("file container + G-PCC coordinate coder (`model/model.py:253-486`) are out of scope (8f)")
+        feats, coords = [], []
+        for i, (block_symbols, block_shape, block_coords, block_k) in enumerate(zip(strings, shape, coordinates, k)):
+            y_cset = getattr(block_coords, "_pcc_cset", None)
+            if y_cset is None or y_cset.ts != 8:
+                y_cset = SparseTensor(coordinates=block_coords, features=torch.ones((block_coords.shape[0], 1)),
+                                      tensor_stride=8, device=self.g_s.down_conv.kernel.device)._cset
+            # z coordinates: two k3-s2 `down_conv`s in the reference (`model/model.py:227-229`) = coordinate-only stride
+            z_cset = y_cset.stride(16).stride(32)
+            y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i])
+            x_hat = self.g_s(y_hat, k=block_k, trace=trace)
+            feats.append(x_hat.F)
+            coords.append(x_hat.C)
+        f = torch.cat(feats, dim=0)
+        c = torch.cat(coords, dim=0)
+        f = torch.clamp(torch.round(f * 255), 0.0, 255.0) / 255
+        return torch.cat([c[:, 1:4].to(f.dtype), f], dim=1)

@@ -1,0 +1,156 @@
+"""Analysis / synthesis transforms g_a, g_s: counterpart of the reference's `model/transforms.py`.
+
+Module structure, attribute names and Sequential indices equal the reference's (`model/transforms.py:32-44,
+126-166`) so its `state_dict` keys load.  The forward passes produce the same tensors but
+  * fuse ReLU into the first occupancy-head convolution's epilogue,
+  * select the top-k rows with a radix select on the device and compact directly, instead of
+    torch.topk + int64 flattening + torch.isin + MinkowskiPruning (`model/transforms.py:228-282`),
+  * obtain z / training target coordinates with the coordinate-only stride operator.
+"""
+import torch
+import torch.nn as nn
+
+from .. import MinkowskiEngine as ME
+from .. import lib as L
+from .. import sparse as S
+from ..MinkowskiEngine.sparse_tensor import SparseTensor
+from .blocks import MinkowskiGDN
+
+
+def batch_segments(cset):
+    """Row ranges per batch index of a canonical set: ([begin_0, ..., end], batch ids)."""
+    bmax = cset.bounds.bmax
+    if bmax == 0:
+        return [0, cset.n], [0]
+    q = torch.arange(0, bmax + 2, device=cset.device, dtype=torch.int64) << 48
+    pos = torch.searchsorted(cset.keys[:cset.n], q).tolist()
+    return pos, list(range(bmax + 1))
+
+
+def count_per_batch(x):
+    """`AnalysisTransform.count_per_batch` (`model/transforms.py:47-64`): rows per occupied batch index."""
+    seg, _ = batch_segments(x._cset)
+    return [seg[i + 1] - seg[i] for i in range(len(seg) - 1) if seg[i + 1] > seg[i]]
+
+
+class AnalysisTransform(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        C_in, N1, N2, N3, N4 = (config[k] for k in ("C_in", "N1", "N2", "N3", "N4"))
+        self.down_conv_1 = nn.Sequential(
+            ME.MinkowskiConvolution(in_channels=C_in, out_channels=N1, kernel_size=5, stride=2, bias=True, dimension=3),
+            MinkowskiGDN(N1),
+        )
+        self.down_conv_2 = nn.Sequential(
+            ME.MinkowskiConvolution(in_channels=N1, out_channels=N2, kernel_size=5, stride=2, bias=True, dimension=3),
+            MinkowskiGDN(N2),
+        )
+        self.down_conv_3 = nn.Sequential(
+            ME.MinkowskiConvolution(in_channels=N2, out_channels=N3, kernel_size=5, stride=2, bias=True, dimension=3),
+            MinkowskiGDN(N3),
+            ME.MinkowskiConvolution(in_channels=N3, out_channels=N4, kernel_size=5, stride=1, bias=True, dimension=3),
+        )
+
+    count_per_batch = staticmethod(count_per_batch)
+
+    def forward(self, x):
+        """x -> (y, k) with k = rows per batch at strides [4, 2, 1] (`model/transforms.py:68-97`)."""
+        k = [count_per_batch(x)]
+        x = self.down_conv_1(x)
+        k.append(count_per_batch(x))
+        x = self.down_conv_2(x)
+        k.append(count_per_batch(x))
+        x = self.down_conv_3(x)
+        k.reverse()
+        return x, k
+
+
+class SparseSynthesisTransform(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        C_out, N1, N2, N3, N4 = (config[k] for k in ("C_out", "N1", "N2", "N3", "N4"))
+        conv, gen = ME.MinkowskiConvolution, ME.MinkowskiGenerativeConvolutionTranspose
+        self.up_1 = nn.Sequential(
+            conv(in_channels=N4, out_channels=N3, kernel_size=5, stride=1, bias=True, dimension=3),
+            MinkowskiGDN(N3, inverse=True),
+            gen(in_channels=N3, out_channels=N2, kernel_size=5, stride=2, bias=True, dimension=3),
+        )
+        self.up_2 = nn.Sequential(
+            MinkowskiGDN(N2, inverse=True),
+            gen(in_channels=N2, out_channels=N1, kernel_size=5, stride=2, bias=True, dimension=3),
+        )
+        self.up_3 = nn.Sequential(
+            MinkowskiGDN(N1, inverse=True),
+            gen(in_channels=N1, out_channels=N1 // 4, kernel_size=5, stride=2, bias=True, dimension=3),
+        )
+        self.color_conv = nn.Sequential(
+            conv(in_channels=N1 // 4, out_channels=C_out, kernel_size=1, stride=1, bias=True, dimension=3),
+        )
+        self.predict_1 = nn.Sequential(
+            conv(in_channels=N2, out_channels=N2 // 2, kernel_size=3, stride=1, bias=True, dimension=3),
+            ME.MinkowskiReLU(inplace=False),
+            conv(in_channels=N2 // 2, out_channels=1, kernel_size=3, stride=1, bias=True, dimension=3),
+        )
+        self.predict_2 = nn.Sequential(
+            conv(in_channels=N1, out_channels=N1 // 2, kernel_size=3, stride=1, bias=True, dimension=3),
+            ME.MinkowskiReLU(inplace=False),
+            conv(in_channels=N1 // 2, out_channels=1, kernel_size=3, stride=1, bias=True, dimension=3),
+        )
+        self.predict_3 = nn.Sequential(
+            conv(in_channels=N1 // 4, out_channels=N4 // 8, kernel_size=3, stride=1, bias=True, dimension=3),
+            ME.MinkowskiReLU(inplace=False),
+            conv(in_channels=N4 // 8, out_channels=1, kernel_size=3, stride=1, bias=True, dimension=3),
+        )
+        self.prune = ME.MinkowskiPruning()
+        self.down_conv = conv(in_channels=1, out_channels=1, kernel_size=3, stride=2, dimension=3)
+
+    # ---- fused building blocks ---------------------------------------------------------------------
+    @staticmethod
+    def _predict(head, x):
+        """conv k3 -> ReLU (fused into the epilogue) -> conv k3 -> 1 logit per row; both convs share one map."""
+        c0, c2 = head[0], head[2]
+        cs = x._cset
+        kmap = cs.kernel_map(cs, 3)
+        h = c0._apply_conv(x, cs, kmap, act=L.ACT_RELU)
+        ht = SparseTensor._from_canonical(cs, h)
+        logit = c2._apply_conv(ht, cs, kmap)
+        return SparseTensor._from_canonical(cs, logit)
+
+    @staticmethod
+    def _topk_prediction(prediction, k):
+        """Mask of the k[b] largest logits per batch b; ties -> lowest canonical row (SURVEY A.7;
+        reference `model/transforms.py:228-254`)."""
+        seg, bids = batch_segments(prediction._cset)
+        ks = [int(k[b]) if (seg[i + 1] > seg[i]) else 0 for i, b in enumerate(bids)]
+        return S.topk_mask(prediction._canonical_features(), seg, ks), sum(
+            min(kk, seg[i + 1] - seg[i]) for i, kk in enumerate(ks))
+
+    @staticmethod
+    def _prune_tensor(x, mask, n_keep):
+        cs = x._cset
+        keys, feats, n = S.prune(cs.keys, cs.n, x._canonical_features(), mask, n_keep)
+        return SparseTensor._from_canonical(S.CoordSet(keys, n, cs.ts, cs.bounds), feats)
+
+    def forward(self, y, coords=None, k=None, trace=None):
+        """y (stride 8) -> x (stride 1) features at the k-selected voxels (`model/transforms.py:170-225`)."""
+        x = self.up_1(y)
+        predictions = []
+        for lvl, (up, head) in enumerate(((None, self.predict_1), (self.up_2, self.predict_2),
+                                          (self.up_3, self.predict_3))):
+            if up is not None:
+                x = up(x)
+            pred = self._predict(head, x)
+            mask, n_keep = self._topk_prediction(pred, k[lvl])
+            if trace is not None:
+                trace[f"keys_{lvl}"], trace[f"feats_{lvl}"] = x._cset.keys[:x._cset.n], x.F
+                trace[f"logit_{lvl}"], trace[f"mask_{lvl}"] = pred.F, mask
+            predictions.append(pred)
+            x = self._prune_tensor(x, mask, n_keep)
+        x = self.color_conv(x)
+        if coords is None:
+            return x
+        with torch.no_grad():   # training targets: coordinates of the ground truth at strides 2 and 4
+            cs1 = coords._cset.stride(coords._cset.ts * 2)
+            cs2 = cs1.stride(cs1.ts * 2)
+            ones = lambda c: SparseTensor._from_canonical(c, torch.ones((c.n, 1), device=c.device))
+        return x, [ones(cs2), ones(cs1), coords], predictions

@@ -1,0 +1,306 @@
+"""Coordinate sets, kernel maps and the functional operator layer over libpcc_hip.
+
+Everything here runs on the GPU through the C ABI (include/pcc_hip.h).  A `CoordSet` is a canonical
+(strictly ascending) packed-key array plus host-side bookkeeping; derived sets (stride, generative
+expansion) and kernel maps are cached on the set they derive from, which replaces MinkowskiEngine's
+coordinate manager.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+BIAS = 1 << 15
+
+
+def _field_mask(lo, hi):
+    a, b = lo + BIAS, hi + BIAS
+    return (1 << (a ^ b).bit_length()) - 1
+
+
+class Bounds:
+    """Conservative host-side coordinate bounds of a set; they select which radix digits can differ."""
+
+    def __init__(self, bmax, lo, hi):
+        self.bmax, self.lo, self.hi = int(bmax), tuple(int(v) for v in lo), tuple(int(v) for v in hi)
+        if min(self.lo) < -BIAS + 64 or max(self.hi) >= BIAS - 64 or self.bmax >= (1 << 15):
+            raise L.PccError(f"coordinates out of the 16-bit key range: lo={self.lo} hi={self.hi} batch={self.bmax}")
+
+    def bit_mask(self):
+        m = ((1 << self.bmax.bit_length()) - 1) << 48
+        for i, sh in enumerate((32, 16, 0)):
+            m |= _field_mask(self.lo[i], self.hi[i]) << sh
+        return m & 0xFFFFFFFFFFFFFFFF
+
+    def strided(self, m):
+        return Bounds(self.bmax, [(v // m) * m for v in self.lo], [(v // m) * m for v in self.hi])
+
+    def expanded(self, ksize, step):
+        lo_off = -((ksize - 1) // 2) if ksize % 2 else 0
+        hi_off = (ksize - 1) // 2 if ksize % 2 else ksize - 1
+        return Bounds(self.bmax, [v + lo_off * step for v in self.lo], [v + hi_off * step for v in self.hi])
+
+
+class KernelMap:
+    """Device-resident kernel map: header, neighbour table, optional position->row list."""
+
+    def pairs(self):
+        """Number of (in,out) pairs P (FLOP = 2*P*Cin*Cout); reads one device int64."""
+        if self._pairs is None:
+            self._pairs = int(self.d_pairs.item()) if self.d_pairs is not None else -1
+        return self._pairs
+
+    def dense(self):
+        """[K, n_out] int32 table with -1 holes (tests)."""
+        out = torch.empty((self.K, self.n_out), dtype=torch.int32, device=self.hdr.device)
+        if self.n_out:
+            L.call("pcc_map_to_dense", L.ptr(self.hdr), L.ptr(self.nbr), L.ptr(self.rows), self.n_out, self.K,
+                   L.ptr(out), L.stream())
+        return out
+
+
+COUNT_PAIRS = False   # bench.py switches this on for its FLOP accounting pass
+
+
+class CoordSet:
+    """Canonical coordinate set at one tensor stride."""
+
+    def __init__(self, keys, n, tensor_stride, bounds):
+        self.keys = keys                    # int64 [>=n] device, ascending
+        self.n = int(n)
+        self.ts = int(tensor_stride)
+        self.bounds = bounds
+        self._C = None
+        self._derived = {}
+        self._maps = {}
+
+    @property
+    def device(self):
+        return self.keys.device
+
+    def coords(self):
+        """int32 [n,4] (b,x,y,z) view, cached; tagged so SparseTensor(coordinates=x.C) re-wraps in O(1)."""
+        if self._C is None:
+            c = torch.empty((self.n, 4), dtype=torch.int32, device=self.device)
+            if self.n:
+                L.call("pcc_keys_unpack", L.ptr(self.keys), self.n, L.ptr(c), L.stream())
+            c._pcc_cset = self
+            c._pcc_perm = None
+            self._C = c
+        return self._C
+
+    # ---- derived sets ------------------------------------------------------------------------
+    def stride(self, new_stride):
+        """Output set of a strided conv (a2-i): unique(floor(c/m)*m)."""
+        key = ("stride", new_stride)
+        if key not in self._derived:
+            dev = self.device
+            out = torch.empty(max(self.n, 1), dtype=torch.int64, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            nb = L.load().pcc_stride_ws_bytes(self.n)
+            ws = L.workspace(nb, dev)
+            L.call("pcc_coords_stride", L.ptr(self.keys), self.n, new_stride, self.bounds.bit_mask(), L.ptr(out),
+                   L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+            n = int(cnt.item())
+            self._derived[key] = CoordSet(out[:n].clone() if n < self.n // 2 else out, n, new_stride,
+                                          self.bounds.strided(new_stride))
+        return self._derived[key]
+
+    def expand(self, ksize, ts_out):
+        """Output set of a generative transposed conv (a3-i): unique{c + off_k*ts_out}."""
+        key = ("expand", ksize, ts_out)
+        if key not in self._derived:
+            dev = self.device
+            K = ksize ** 3
+            ob = self.bounds.expanded(ksize, ts_out)
+            cap = max(self.n * K, 1)
+            out = torch.empty(cap, dtype=torch.int64, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            nb = L.load().pcc_expand_ws_bytes(self.n, ksize)
+            ws = L.workspace(nb, dev)
+            L.call("pcc_coords_expand", L.ptr(self.keys), self.n, ksize, ts_out, ob.bit_mask(), L.ptr(out),
+                   L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+            n = int(cnt.item())
+            self._derived[key] = CoordSet(out[:n].clone(), n, ts_out, ob)
+        return self._derived[key]
+
+    # ---- kernel maps ---------------------------------------------------------------------------
+    def kernel_map(self, out_set, ksize, transposed=False, up_stride=1):
+        """Map from this (input) set to `out_set` (a2-ii / a3), cached per (out set, kernel, kind)."""
+        key = (id(out_set), ksize, bool(transposed), up_stride)
+        m = self._maps.get(key)
+        if m is not None:
+            return m
+        dev = self.device
+        lib = L.load()
+        K = ksize ** 3
+        m = KernelMap()
+        m.n_in, m.n_out, m.K, m.ksize, m.transposed = self.n, out_set.n, K, ksize, bool(transposed)
+        m._pairs = None
+        m.hdr = torch.empty(L.MAP_HDR_INTS, dtype=torch.int32, device=dev)
+        nelem = lib.pcc_map_nbr_elems(out_set.n, ksize, up_stride, 1 if transposed else 0)
+        m.nbr = torch.empty(max(nelem, 1), dtype=torch.int32, device=dev)
+        m.rows = torch.empty(max(out_set.n, 1), dtype=torch.int32, device=dev) if transposed else None
+        m.d_pairs = torch.zeros(1, dtype=torch.int64, device=dev) if COUNT_PAIRS else None
+        step = out_set.ts if transposed else self.ts
+        ws = L.workspace(lib.pcc_map_ws_bytes(out_set.n), dev)
+        L.call("pcc_kernel_map_build", L.ptr(self.keys), self.n, L.ptr(out_set.keys), out_set.n, ksize, step,
+               up_stride, 1 if transposed else 0, L.ptr(m.hdr), L.ptr(m.nbr), L.ptr(m.rows), L.ptr(m.d_pairs),
+               L.ptr(ws), ws.numel(), L.stream())
+        self._maps[key] = m
+        # keep the output set alive as long as the map is cached (id() is the cache key)
+        self._derived.setdefault(("map_out", id(out_set)), out_set)
+        return m
+
+
+def _canon_check(keys, n):
+    flag = torch.empty(1, dtype=torch.int32, device=keys.device)
+    L.call("pcc_keys_is_canonical", L.ptr(keys), n, L.ptr(flag), L.stream())
+    return bool(flag.item())
+
+
+def pack_keys(coords):
+    """[n,4] int / float tensor on the GPU -> int64 keys (floor for floats), a1."""
+    n = coords.shape[0]
+    keys = torch.empty(max(n, 1), dtype=torch.int64, device=coords.device)
+    if n == 0:
+        return keys
+    if coords.dtype.is_floating_point:
+        c = coords.to(torch.float32).contiguous()
+        L.call("pcc_keys_pack_f32", L.ptr(c), n, L.ptr(keys), L.stream())
+    else:
+        c = coords.to(torch.int32).contiguous()
+        L.call("pcc_keys_pack_i32", L.ptr(c), n, L.ptr(keys), L.stream())
+    return keys
+
+
+def bounds_of(coords):
+    if coords.shape[0] == 0:
+        return Bounds(0, (0, 0, 0), (0, 0, 0))
+    c = coords.floor() if coords.dtype.is_floating_point else coords
+    mn = c.amin(dim=0).tolist()
+    mx = c.amax(dim=0).tolist()
+    if mn[0] < 0:
+        raise L.PccError("negative batch index")
+    return Bounds(int(mx[0]), [int(v) for v in mn[1:]], [int(v) for v in mx[1:]])
+
+
+def coordset_from_coords(coords, tensor_stride):
+    """Canonicalise user coordinates.  Returns (CoordSet, perm, keep):
+    perm  None when the rows already are in canonical order, else int64 [n] with
+          canonical position -> row of the (de-duplicated) user-order tensor;
+    keep  None, or int64 indices of the user rows that survive de-duplication (first wins, A.1)."""
+    n = coords.shape[0]
+    keys = pack_keys(coords)
+    b = bounds_of(coords)
+    if n <= 1 or _canon_check(keys, n):
+        return CoordSet(keys, n, tensor_stride, b), None, None
+    dev = coords.device
+    lib = L.load()
+    skeys = torch.empty(n, dtype=torch.int64, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = L.workspace(lib.pcc_sort_ws_bytes(n), dev)
+    L.call("pcc_sort_keys", L.ptr(keys), n, b.bit_mask(), L.ptr(skeys), L.ptr(perm), L.ptr(ws), ws.numel(), L.stream())
+    ukeys = torch.empty(n, dtype=torch.int64, device=dev)
+    first = torch.empty(n, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = L.workspace(lib.pcc_unique_ws_bytes(n), dev)
+    L.call("pcc_unique_sorted", L.ptr(skeys), n, L.ptr(ukeys), L.ptr(first), L.ptr(cnt), L.ptr(ws), ws.numel(),
+           L.stream())
+    nu = int(cnt.item())
+    # stable sort => first[] points at the smallest user row of each run
+    first_user = perm.long()[first[:nu].long()]
+    cs = CoordSet(ukeys[:nu].clone() if nu < n else ukeys, nu, tensor_stride, b)
+    if nu == n:
+        return cs, first_user, None
+    keep, inv = torch.sort(first_user)            # surviving user rows, original order
+    rank = torch.empty_like(inv)
+    rank[inv] = torch.arange(nu, device=dev)
+    return cs, rank, keep
+
+
+# ------------------------------------------------------------------------------------------------
+# functional operators on canonical-order features
+# ------------------------------------------------------------------------------------------------
+class PackedConv:
+    """Packed copy of a conv weight, refreshed when the parameter changes."""
+
+    def __init__(self):
+        self.tag = None
+        self.packed = None
+
+    def get(self, kernel):
+        w = kernel.detach()
+        tag = (w.data_ptr(), kernel._version, tuple(w.shape), str(w.device))
+        if tag != self.tag:
+            w3 = w if w.dim() == 3 else w.unsqueeze(0)
+            w3 = w3.to(torch.float32).contiguous()
+            K, cin, cout = w3.shape
+            n = L.load().pcc_conv_packed_elems(K, cin, cout)
+            self.packed = torch.empty(n, dtype=torch.float32, device=w.device)
+            L.call("pcc_conv_pack_weights", L.ptr(w3), K, cin, cout, L.ptr(self.packed), L.stream())
+            self.tag = tag
+        return self.packed
+
+
+def conv_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NONE, slope=0.01):
+    """out[o] = act(bias + sum_k feats[nbr_k(o)] @ W[k])  -- a2-iii / a3."""
+    feats = feats.contiguous()
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    if n_out == 0:
+        return out
+    b = bias.detach().reshape(-1).contiguous() if bias is not None else None
+    L.call("pcc_conv_fwd", L.ptr(feats), feats.shape[0], cin, L.ptr(packed_w), L.ptr(b), K, cout,
+           L.ptr(kmap.hdr) if kmap is not None else None, L.ptr(kmap.nbr) if kmap is not None else None,
+           L.ptr(kmap.rows) if kmap is not None else None, n_out, L.ptr(out), act, float(slope), L.stream())
+    return out
+
+
+def topk_mask(logits, seg_begin, ks):
+    """Per-batch top-k mask over rows in canonical order (a4)."""
+    n = logits.shape[0]
+    mask = torch.empty(max(n, 1), dtype=torch.uint8, device=logits.device)
+    if n == 0:
+        return mask[:0].bool()
+    nb = len(ks)
+    sb = (C.c_int64 * (nb + 1))(*seg_begin)
+    kk = (C.c_int64 * nb)(*[int(k) for k in ks])
+    ws = L.workspace(L.load().pcc_topk_ws_bytes(n), logits.device)
+    if logits.dim() == 2:     # column 0 of an [n,c] logit tensor (`prediction.F[:, 0]`, model/transforms.py:246)
+        if logits.stride(1) != 1 and logits.shape[1] != 1:
+            logits = logits.contiguous()
+        stride = logits.stride(0)
+    else:
+        logits, stride = logits.contiguous(), 1
+    if not logits.is_cuda:
+        raise L.PccError("topk_mask: GPU tensor required")
+    L.call("pcc_topk_mask", logits.data_ptr(), stride, sb, kk, nb, L.ptr(mask), L.ptr(ws), ws.numel(), L.stream())
+    return mask[:n].view(torch.bool)
+
+
+def prune(keys, n, feats, mask, n_keep=None):
+    """Stable row compaction (a4).  n_keep known (top-k) avoids the device->host count read."""
+    dev = keys.device
+    m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+    m = m.contiguous()
+    c = feats.shape[1] if feats is not None else 0
+    keys_out = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    feat_out = torch.empty((max(n, 1), c), dtype=torch.float32, device=dev) if feats is not None else None
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = L.workspace(L.load().pcc_prune_ws_bytes(n), dev)
+    f = feats.contiguous() if feats is not None else None
+    L.call("pcc_prune_rows", L.ptr(m), n, L.ptr(keys), L.ptr(f), c, L.ptr(keys_out), L.ptr(feat_out), L.ptr(cnt),
+           L.ptr(ws), ws.numel(), L.stream())
+    k = int(cnt.item()) if n_keep is None else int(n_keep)
+    return keys_out[:k], (feat_out[:k] if feat_out is not None else None), k
+
+
+def lookup_gather(cset, feats, query_keys, nq):
+    """features_at_coordinates for on-grid queries (a6)."""
+    feats = feats.contiguous()
+    out = torch.empty((nq, feats.shape[1]), dtype=torch.float32, device=feats.device)
+    if nq:
+        L.call("pcc_lookup_gather", L.ptr(cset.keys), cset.n, L.ptr(feats), feats.shape[1], L.ptr(query_keys), nq,
+               L.ptr(out), L.stream())
+    return out

@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: points/sec encode+decode of one vox10 frame per GPU (BASELINE.json config 2).
+
+A step = UnifiedModel.compress + UnifiedModel.decompress of one synthetic longdress-like 10-bit frame
+(~0.79 M voxels, one block, R2 architecture `configs/CVPR_inverse_scaling_fixed_R2.yaml`, q = [[0.5, 0.5]]), input
+resident in HBM, timed like `utils.py:454-465` (sync, wall clock, sync).  Each rank codes its own frame (weak
+scaling, no data-path collective); rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
+BITS = 10
+
+R2_CONFIG = {
+    "entropy_model": dict(C_bottleneck=128, C_hyper_bottleneck=192, quantization_mode="ste", inverse_rescaling=False,
+                          quantization_offset=False, entropy_bottleneck_vbr=False, adaptive_BN=False),
+    "g_a": dict(C_in=4, N1=128, N2=128, N3=128, N4=128),
+    "g_s": dict(C_out=3, N1=128, N2=128, N3=128, N4=128),
+}
+
+
+def build_model(device, seed=0, gain=3.0):
+    from unified_point_cloud_compression_amd.model import UnifiedModel
+    from unified_point_cloud_compression_amd.MinkowskiEngine.modules import _ConvBase
+    torch.manual_seed(seed)
+    model = UnifiedModel(R2_CONFIG)
+    with torch.no_grad():   # no trained weights ship (README.md:122): seeded random init, scaled so latents are not all zero
+        for m in model.modules():
+            if isinstance(m, _ConvBase):
+                m.kernel.mul_(gain)
+    model = model.to(device).eval()
+    model.update()
+    return model
+
+
+def step(model, pc, q):
+    out = model.compress(pc, q, block_size=1024)
+    rec = model.decompress(coordinates=out[3], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
+    return out, rec
+
+
+def mfma_shape(cin, cout):
+    return cout > 4 and (cin in (4, 8, 16) or (cin >= 32 and cin % 32 == 0))
+
+
+def account_flops(model, pc, q):
+    """One un-timed step with pair counting on: algorithmic FLOPs (2*P*Cin*Cout) of the MFMA conv launches."""
+    from unified_point_cloud_compression_amd import sparse as S
+    calls = []
+    orig = S.conv_forward
+
+    def spy(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=0, slope=0.01):
+        calls.append((kmap, K, cin, cout, n_out))
+        return orig(feats, packed_w, bias, K, cin, cout, kmap, n_out, act, slope)
+
+    S.COUNT_PAIRS, S.conv_forward = True, spy
+    try:
+        step(model, pc, q)
+        torch.cuda.synchronize()
+    finally:
+        S.COUNT_PAIRS, S.conv_forward = False, orig
+    flops, launches, pairs_total = 0.0, 0, 0
+    for kmap, K, cin, cout, n_out in calls:
+        if not mfma_shape(cin, cout):
+            continue
+        p = kmap.pairs() if kmap is not None else n_out
+        flops += 2.0 * p * cin * cout
+        pairs_total += p
+        launches += 1
+    return flops, launches, pairs_total
+
+
+def cpu_baseline(bits=8, threads=None):
+    """The oracle (numpy restatement, 'port') timed on this host's cores on a bounded sample of the same workload:
+    the same synthetic surface at 2^bits resolution, same R2 architecture, encode + decode."""
+    from oracle import codec
+    from unified_point_cloud_compression_amd import synth
+    threads = threads or os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    pc = synth.surface_cloud(0, bits)
+    P = codec.random_params(codec.R2_CONFIG, 0, gain=3.0)
+    q = np.array([[0.5, 0.5]], dtype=np.float32)
+    t0 = time.time()
+    blocks = codec.compress(P, codec.R2_CONFIG, pc, q, threads=threads)
+    codec.decompress(P, codec.R2_CONFIG, blocks, threads=threads)
+    dt = time.time() - t0
+    return {"value": pc.shape[0] / dt, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (numpy restatement; MinkowskiEngine unavailable) encode+decode of the same synthetic surface "
+                      f"at vox{bits} ({pc.shape[0]} points), R2 architecture, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bits", type=int, default=BITS)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from unified_point_cloud_compression_amd import lib, synth, frames
+    lib.load()
+    cu, arch = lib.device_info()
+    model = build_model(device)
+    pc_np = synth.surface_cloud(seed=rank, bits=args.bits)
+    pc = torch.from_numpy(pc_np).to(device)
+    q = torch.tensor([[0.5, 0.5]], device=device)
+    n_points = pc.shape[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    for _ in range(args.warmup):
+        step(model, pc, q)
+    torch.cuda.synchronize()
+    flops_step, launches_step, pairs_step = account_flops(model, pc, q) if rank == 0 else (0.0, 0, 0)
+
+    lib.call("pcc_prof_enable", 1 if rank == 0 else 0)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    t_enc = 0.0
+    for _ in range(args.steps):
+        te = time.time()
+        out = model.compress(pc, q, block_size=1024)
+        torch.cuda.synchronize()
+        t_enc += time.time() - te
+        rec = model.decompress(coordinates=out[3], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.time() - t0
+    import ctypes as C
+    conv_ms, conv_launches = C.c_double(0), C.c_int64(0)
+    if rank == 0:
+        lib.check(lib.load().pcc_prof_collect(C.byref(conv_ms), C.byref(conv_launches)), "pcc_prof_collect")
+    lib.call("pcc_prof_enable", 0)
+
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt_max = float(tt.item())
+    recs = frames.gather_records([(rank, n_points, t_enc / args.steps, (dt - t_enc) / args.steps, 0.0, rec.shape[0])],
+                                 device)
+    total_points = sum(r[1] for r in recs)
+
+    if rank == 0:
+        ms_step = dt_max / args.steps * 1e3
+        # conv launches: only MFMA-shaped ones are event-timed inside the library
+        ach = (flops_step * args.steps / (conv_ms.value * 1e-3) / 1e12) if conv_ms.value > 0 else None
+        line = {
+            "metric": "points/sec encode+decode, longdress vox10, 1 GPU; bpp & D1-PSNR parity",
+            "value": total_points * args.steps / dt_max,
+            "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: one synthetic longdress-like vox{args.bits} frame per GPU "
+                                   f"({n_points} points on rank 0), R2 architecture, random-init weights, q=[[0.5,0.5]], "
+                                   f"1 block; entropy-coder boundary carries integer symbols (rANS = SURVEY 8f next)",
+                       "frames_per_step": world, "encode_ms": recs[0][2] * 1e3, "decode_ms": recs[0][3] * 1e3,
+                       "device": arch, "cus": cu},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None, "traffic": None,
+                         "kernel": "k_conv_mfma (pcc_conv_fwd)", "flop_per_step": flops_step,
+                         "pairs_per_step": pairs_step, "launches_per_step": launches_step,
+                         "avg_launch_ms": (conv_ms.value / conv_launches.value) if conv_launches.value else None,
+                         "conv_ms_per_step": conv_ms.value / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -445,7 +445,8 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
   PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd: bad activation");
   PCC_REQUIRE(n_in < (1ll << 31) && n_out < (1ll << 31), "pcc_conv_fwd: too many rows");
   hipEvent_t e0, e1;
-  if (g_prof_on) PCC_TRY(prof_event(&e0, s));
+  const bool timed = g_prof_on && mfma_ok(cin, cout);   // the roofline kernel: MFMA launches only
+  if (timed) PCC_TRY(prof_event(&e0, s));
   if (mfma_ok(cin, cout)) {
     ConvArgs a;
     a.feat = feat_in; a.wp = packed_w; a.bias = bias; a.hdr = hdr; a.nbr = nbr; a.rows = rows; a.out = out;
@@ -465,7 +466,7 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
     k_conv_thin<4><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(t);
     PCC_LAUNCH_CHECK();
   }
-  if (g_prof_on) {
+  if (timed) {
     PCC_TRY(prof_event(&e1, s));
     ++g_launches;
   }

@@ -74,6 +74,40 @@ __device__ inline int pcc_find(const int64_t* __restrict__ keys, int n, int64_t 
   return (lo < n && keys[lo] == q) ? lo : -1;
 }
 
+// Wave-cooperative search: the 64 queries of a wave are usually close together (consecutive sorted rows shifted by
+// one offset), so the wave first brackets [lower_bound(min q), upper_bound(max q)) with wave-uniform probes (scalar
+// loads through the constant cache), then every lane searches only inside that short bracket.  Correct for any
+// query distribution; all 64 lanes must call it (inactive lanes pass a key of an active one).
+__device__ inline int64_t pcc_wave_uniform(int64_t v) {
+  const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xFFFFFFFFll));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((int64_t)hi << 32) | (int64_t)(unsigned)lo;
+}
+
+__device__ inline int pcc_find_bracketed(const int64_t* __restrict__ keys, int n, int64_t q) {
+  int64_t qmin = q, qmax = q;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int64_t a = __shfl_xor(qmin, d), b = __shfl_xor(qmax, d);
+    qmin = a < qmin ? a : qmin;
+    qmax = b > qmax ? b : qmax;
+  }
+  qmin = pcc_wave_uniform(qmin);
+  qmax = pcc_wave_uniform(qmax);
+  int l = 0, h = n;
+  while (l < h) { const int m = (l + h) >> 1; if (keys[m] < qmin) l = m + 1; else h = m; }
+  int lo = l;
+  h = n;
+  while (l < h) { const int m = (l + h) >> 1; if (keys[m] <= qmax) l = m + 1; else h = m; }
+  int hi = l;
+  const int end = hi;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < q) lo = mid + 1; else hi = mid;
+  }
+  return (lo < end && keys[lo] == q) ? lo : -1;
+}
+
 // internal cross-file entry points
 int pcc_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, size_t ws_bytes,
                            hipStream_t s);

@@ -148,46 +148,63 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
   const int wm = w / WN, wn = w % WN;
   const int half = lane >> 5, r31 = lane & 31;
 
-  int cached_a = -1;
-  int in_row[AI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) in_row[i] = -1;
-
-  for (int c = 0; c < nchunks; ++c) {
+  // ---- software pipeline over the 32-wide chunks -------------------------------------------------
+  //   neighbour rows of chunk c+2  -> registers   (dependent-load chain hidden two chunks ahead)
+  //   global loads  of chunk c+1  -> registers   (in flight while chunk c is multiplied)
+  //   chunk c: registers -> LDS -> fragments -> MFMA
+  auto chunk_ids = [&](int c, int& ai, int& cbi, bool& pvalid) {
     const int piece = (c << ppc_log2) + piece_in_chunk;
-    const int ai = piece / a.ppo;           // active-offset index of my part
-    const int cbi = piece - ai * a.ppo;     // channel block within the offset
-    const bool pvalid = ai < nact;
-    if (ai != cached_a) {
-      cached_a = ai;
-      const int slot = pvalid ? act_list[ai] : 0;
+    ai = piece / a.ppo;            // active-offset index of my 16-byte part
+    cbi = piece - ai * a.ppo;      // channel block within the offset
+    pvalid = ai < nact;
+  };
+  auto load_rows = [&](int ai, bool pvalid, int (&rows)[AI]) {
+    const int slot = pvalid ? act_list[ai] : 0;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        const int r = r0 + 32 * i;
-        int v = -1;
-        if (pvalid && r < npos) v = identity ? (pos0 + r) : seg_nbr[(long long)slot * seg_pos_count + r];
-        in_row[i] = v;
-      }
+    for (int i = 0; i < AI; ++i) {
+      const int r = r0 + 32 * i;
+      int v = -1;
+      if (pvalid && r < npos) v = identity ? (pos0 + r) : seg_nbr[(long long)slot * seg_pos_count + r];
+      rows[i] = v;
     }
-    // global -> registers
-    float4 av[AI], bv[BI];
+  };
+  auto issue = [&](int ai, int cbi, bool pvalid, const int (&rows)[AI], float4 (&av)[AI], float4 (&bv)[BI]) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in_row[i] >= 0)
-        av[i] = *reinterpret_cast<const float4*>(a.feat + (long long)in_row[i] * a.cin + (cbi << a.cb_log2) + within);
+      if (rows[i] >= 0)
+        av[i] = *reinterpret_cast<const float4*>(a.feat + (long long)rows[i] * a.cin + (cbi << a.cb_log2) + within);
     }
-    {
-      const long long wbase = pvalid ? ((long long)(act_kid[ai] * a.ppo + cbi) * a.cout_pad) : 0;
+    const long long wbase = pvalid ? ((long long)(act_kid[ai] * a.ppo + cbi) * a.cout_pad) : 0;
 #pragma unroll
-      for (int i = 0; i < BI; ++i) {
-        bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pvalid) {
-          const int col = colblock + r0 + 32 * i;
-          bv[i] = *reinterpret_cast<const float4*>(a.wp + ((wbase + col) << a.cb_log2) + within);
-        }
+    for (int i = 0; i < BI; ++i) {
+      bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pvalid) {
+        const int col = colblock + r0 + 32 * i;
+        bv[i] = *reinterpret_cast<const float4*>(a.wp + ((wbase + col) << a.cb_log2) + within);
       }
     }
+  };
+
+  int rows_cur[AI], rows_nxt[AI];
+  float4 av[AI], bv[BI];
+  int ai_c, cbi_c, ai_n = -1, cbi_n = 0;
+  bool pv_c, pv_n = false;
+  if (nchunks > 0) {
+    chunk_ids(0, ai_c, cbi_c, pv_c);
+    load_rows(ai_c, pv_c, rows_cur);
+    issue(ai_c, cbi_c, pv_c, rows_cur, av, bv);
+    if (nchunks > 1) {
+      chunk_ids(1, ai_n, cbi_n, pv_n);
+      if (ai_n != ai_c) load_rows(ai_n, pv_n, rows_nxt);
+      else {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) rows_nxt[i] = rows_cur[i];
+      }
+    }
+  }
+
+  for (int c = 0; c < nchunks; ++c) {
     if (MODE != MODE_CONV) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
@@ -202,6 +219,16 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
     for (int i = 0; i < BI; ++i)
       *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDS_LD + kk0]) = bv[i];
     __syncthreads();
+    if (c + 1 < nchunks) {          // next chunk's global loads fly during this chunk's MFMAs
+#pragma unroll
+      for (int i = 0; i < AI; ++i) rows_cur[i] = rows_nxt[i];
+      ai_c = ai_n; cbi_c = cbi_n; pv_c = pv_n;
+      issue(ai_c, cbi_c, pv_c, rows_cur, av, bv);
+      if (c + 2 < nchunks) {
+        chunk_ids(c + 2, ai_n, cbi_n, pv_n);
+        if (ai_n != ai_c) load_rows(ai_n, pv_n, rows_nxt);
+      }
+    }
     // LDS -> fragments -> MFMA
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -261,8 +288,21 @@ struct ThinArgs {
   float* out; long long n_out; int cin, cout, act; float slope; int lpr_log2;
 };
 
-template <int COUT_MAX>
+template <int VEC> struct ThinVec;
+template <> struct ThinVec<4> { typedef float4 T; };
+template <> struct ThinVec<1> { typedef float T; };
+__device__ inline float thin_dot(float4 x, float4 w) { return x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w; }
+__device__ inline float thin_dot(float x, float w) { return x * w; }
+__device__ inline void thin_zero(float4& v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ inline void thin_zero(float& v) { v = 0.f; }
+
+// LPR lanes share one output position, each lane owns VEC consecutive input channels per pass.  Offsets are
+// processed in batches of JB with all neighbour-index loads, then all feature loads, issued back to back
+// (memory-level parallelism instead of a dependent chain per offset).
+template <int COUT_MAX, int VEC>
 __global__ void __launch_bounds__(256) k_conv_thin(ThinArgs a) {
+  typedef typename ThinVec<VEC>::T VT;
+  constexpr int JB = 9;
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << a.lpr_log2;
   const int rpw = 64 >> a.lpr_log2;                       // rows per wave
@@ -270,6 +310,7 @@ __global__ void __launch_bounds__(256) k_conv_thin(ThinArgs a) {
   const long long p = wave * rpw + (lane >> a.lpr_log2);  // position handled by my lane group
   const int cl = lane & (lpr - 1);
   const bool valid = p < a.n_out;
+  const int cvec = a.cin / VEC;                           // vectors per row
 
   int k_count = 1, koff_begin = 0;
   long long seg_pos_count = a.n_out, local = p;
@@ -293,17 +334,31 @@ __global__ void __launch_bounds__(256) k_conv_thin(ThinArgs a) {
 #pragma unroll
   for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
   if (valid) {
-    for (int j = 0; j < k_count; ++j) {
-      const long long ir = identity ? p : (long long)seg_nbr[(long long)j * seg_pos_count + local];
-      if (ir < 0) continue;
-      const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + j];
-      const float* f = a.feat + ir * a.cin;
-      const float* wk = a.wt + (long long)kid * a.cout * a.cin;
-      for (int c = cl; c < a.cin; c += lpr) {
-        const float x = f[c];
+    for (int cv = cl; cv < cvec; cv += lpr) {
+      for (int j0 = 0; j0 < k_count; j0 += JB) {
+        int ir[JB];
 #pragma unroll
-        for (int o = 0; o < COUT_MAX; ++o)
-          if (o < a.cout) acc[o] = fmaf(x, wk[o * a.cin + c], acc[o]);
+        for (int u = 0; u < JB; ++u) {
+          const int j = j0 + u;
+          ir[u] = (j < k_count) ? (identity ? (int)p : seg_nbr[(long long)j * seg_pos_count + local]) : -1;
+        }
+        VT x[JB];
+#pragma unroll
+        for (int u = 0; u < JB; ++u) {
+          thin_zero(x[u]);
+          if (ir[u] >= 0) x[u] = reinterpret_cast<const VT*>(a.feat + (long long)ir[u] * a.cin)[cv];
+        }
+#pragma unroll
+        for (int u = 0; u < JB; ++u) {
+          const int j = j0 + u;
+          if (j < k_count) {
+            const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + j];
+            const float* wk = a.wt + (long long)kid * a.cout * a.cin;
+#pragma unroll
+            for (int o = 0; o < COUT_MAX; ++o)
+              if (o < a.cout) acc[o] += thin_dot(x[u], reinterpret_cast<const VT*>(wk + o * a.cin)[cv]);
+          }
+        }
       }
     }
   }
@@ -458,12 +513,14 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
     ThinArgs t;
     t.feat = feat_in; t.wt = packed_w; t.bias = bias; t.hdr = hdr; t.nbr = nbr; t.rows = rows; t.out = out;
     t.n_out = n_out; t.cin = cin; t.cout = cout; t.act = act; t.slope = slope;
+    const int vec = (cin % 4 == 0) ? 4 : 1;
     int l = 0;
-    while ((1 << l) < cin && l < 6) ++l;
+    while ((1 << l) < cin / vec && l < 6) ++l;
     t.lpr_log2 = l;
     const int64_t rpw = 64 >> l;
     const int64_t waves = pcc_cdiv(n_out, rpw);
-    k_conv_thin<4><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(t);
+    if (vec == 4) k_conv_thin<4, 4><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(t);
+    else k_conv_thin<4, 1><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(t);
     PCC_LAUNCH_CHECK();
   }
   if (timed) {

@@ -80,11 +80,10 @@ __global__ void __launch_bounds__(256) k_map_conv(const int64_t* __restrict__ in
                                                   int* __restrict__ d_pairs) {
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
-  int idx = -1;
-  if (o < n_out) {
-    idx = pcc_find(in_keys, n_in, out_keys[o] + pcc_delta_of(k, ks, step));
-    nbr[(int64_t)k * n_out + o] = idx;
-  }
+  // consecutive output rows give close-by queries for one offset: bracket per wave, then search inside
+  const int64_t oc = o < n_out ? o : n_out - 1;
+  int idx = pcc_find_bracketed(in_keys, n_in, out_keys[oc] + pcc_delta_of(k, ks, step));
+  if (o < n_out) nbr[(int64_t)k * n_out + o] = idx; else idx = -1;
   count_pairs(idx >= 0, d_pairs);
 }
 
@@ -123,22 +122,23 @@ __global__ void __launch_bounds__(256) k_map_transposed(const int64_t* __restric
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
   bool hit = false;
-  if (p < n_out) {
-    const int nseg = hdr[HDR_NSEG];
-    int s = 0;
-    for (; s < nseg - 1; ++s) {
-      const int* sg = hdr + HDR_SEG0 + s * SEG_WORDS;
-      if (p < (int64_t)sg[SEG_POS_BEGIN] + sg[SEG_POS_COUNT]) break;
-    }
+  // every lane runs the search (clamped position) so the wave-cooperative bracket sees 64 valid queries
+  const int64_t pc = p < n_out ? p : n_out - 1;
+  const int nseg = hdr[HDR_NSEG];
+  int s = 0;
+  for (; s < nseg - 1; ++s) {
     const int* sg = hdr + HDR_SEG0 + s * SEG_WORDS;
-    if (j < sg[SEG_K_COUNT]) {
-      const int kid = hdr[HDR_KOFFS + sg[SEG_KOFF_BEGIN] + j];
-      const int o = rows[p];
-      const int idx = pcc_find(in_keys, n_in, out_keys[o] - pcc_delta_of(kid, ks, step));
-      const int64_t nb = ((int64_t)(unsigned)sg[SEG_NBR_LO]) | ((int64_t)sg[SEG_NBR_HI] << 32);
-      nbr[nb + (int64_t)j * sg[SEG_POS_COUNT] + (p - sg[SEG_POS_BEGIN])] = idx;
-      hit = idx >= 0;
-    }
+    if (pc < (int64_t)sg[SEG_POS_BEGIN] + sg[SEG_POS_COUNT]) break;
+  }
+  const int* sg = hdr + HDR_SEG0 + s * SEG_WORDS;
+  const bool live = j < sg[SEG_K_COUNT];
+  const int kid = hdr[HDR_KOFFS + sg[SEG_KOFF_BEGIN] + (live ? j : 0)];
+  const int o = rows[pc];
+  const int idx = pcc_find_bracketed(in_keys, n_in, out_keys[o] - pcc_delta_of(kid, ks, step));
+  if (p < n_out && live) {
+    const int64_t nb = ((int64_t)(unsigned)sg[SEG_NBR_LO]) | ((int64_t)sg[SEG_NBR_HI] << 32);
+    nbr[nb + (int64_t)j * sg[SEG_POS_COUNT] + (p - sg[SEG_POS_BEGIN])] = idx;
+    hit = idx >= 0;
   }
   count_pairs(hit, d_pairs);
 }

@@ -108,7 +108,18 @@ size_t pcc_map_ws_bytes(int64_t n_out);
 int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys, int64_t n_out,
                          int32_t kernel_size, int32_t step, int32_t stride, int32_t transposed,
                          int32_t* hdr, int32_t* nbr, int32_t* rows /*transposed only*/,
-                         int64_t* d_pairs, void* ws, size_t ws_bytes, void* stream);
+                         int64_t* d_pairs, const uint64_t* grid_bits /*nullable*/, const int32_t* grid_rank,
+                         const int32_t* h_grid, void* ws, size_t ws_bytes, void* stream);
+
+/* Grid index of the INPUT set of a map (replaces MinkowskiEngine's coordinate hash map for lookups): an occupancy
+ * bitmap over the set's bounding lattice plus an exclusive popcount prefix per 64-bit word.  Canonical order equals
+ * ascending cell order, so row(cell) = rank[word] + popcount(bits below) -- two coalesced reads per neighbour query.
+ * h_grid (host int32[8]) = {lo_x, lo_y, lo_z, cells_x, cells_y, cells_z, pitch (tensor stride), batches}.
+ * Without a grid the map build falls back to binary search over the sorted keys. */
+int64_t pcc_grid_words(const int32_t* h_grid);
+size_t pcc_grid_ws_bytes(int64_t words);
+int pcc_grid_build(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits /*[words]*/,
+                   int32_t* rank /*[words]*/, void* ws, size_t ws_bytes, void* stream);
 /* dense [K][n_out] view of any map (testing / inspection): -1 where no pair */
 int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows, int64_t n_out,
                      int32_t K, int32_t* dense, void* stream);

@@ -15,9 +15,22 @@ def _cs(keys, ts, batch=1):
     return S.CoordSet(t(keys), len(keys), ts, S.Bounds(batch - 1, C[:, 1:].min(0), C[:, 1:].max(0)))
 
 
+@pytest.fixture(params=[True, False], ids=["grid", "bsearch"])
+def lookup_mode(request):
+    """Both neighbour-lookup structures (bitmap+rank grid index / binary search) must give identical maps."""
+    from unified_point_cloud_compression_amd import sparse as S
+    old = S.USE_GRID
+    S.USE_GRID = request.param
+    yield request.param
+    S.USE_GRID = old
+
+
 @pytest.mark.parametrize("ks,stride,ts", [(3, 1, 1), (5, 1, 8), (5, 2, 1), (3, 2, 8), (5, 2, 4)])
-def test_conv_map_bit_exact(ks, stride, ts):
+def test_conv_map_bit_exact(ks, stride, ts, lookup_mode):
     keys = cloud_keys(ks + stride, 28, 0.12, ts, batch=2)
+    C = co.unpack_keys(keys)
+    C[:, 1:] -= 2 * ts                                   # negative coordinates too
+    keys = np.unique(co.pack_keys(C))
     cs = _cs(keys, ts, 2)
     out = cs if stride == 1 else cs.stride(ts * stride)
     m = cs.kernel_map(out, ks)
@@ -28,7 +41,7 @@ def test_conv_map_bit_exact(ks, stride, ts):
 
 
 @pytest.mark.parametrize("ks,ts_in", [(5, 2), (2, 2), (2, 32), (5, 8)])
-def test_transposed_map_bit_exact(ks, ts_in):
+def test_transposed_map_bit_exact(ks, ts_in, lookup_mode):
     keys = cloud_keys(3, 18, 0.1, ts_in, batch=2)
     cs = _cs(keys, ts_in, 2)
     ts_out = ts_in // 2

@@ -74,38 +74,35 @@ __device__ inline int pcc_find(const int64_t* __restrict__ keys, int n, int64_t 
   return (lo < n && keys[lo] == q) ? lo : -1;
 }
 
-// Wave-cooperative search: the 64 queries of a wave are usually close together (consecutive sorted rows shifted by
-// one offset), so the wave first brackets [lower_bound(min q), upper_bound(max q)) with wave-uniform probes (scalar
-// loads through the constant cache), then every lane searches only inside that short bracket.  Correct for any
-// query distribution; all 64 lanes must call it (inactive lanes pass a key of an active one).
-__device__ inline int64_t pcc_wave_uniform(int64_t v) {
-  const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xFFFFFFFFll));
-  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
-  return ((int64_t)hi << 32) | (int64_t)(unsigned)lo;
+// ---- grid index: occupancy bitmap + rank over the bounding lattice of a canonical set -----------------
+// Canonical order (b,x,y,z ascending) equals ascending linear cell index ((b*nx+cx)*ny+cy)*nz+cz, so the row of
+// an occupied cell is rank[word] + popcount(bits below it): two coalesced reads instead of a 20-step search.
+struct PccGrid {
+  const unsigned long long* bits;   // nullptr: no grid, fall back to binary search
+  const int* rank;                  // exclusive prefix popcount per 64-bit word
+  int lo[3];                        // coordinate of cell 0 per axis
+  int dims[3];                      // cells per axis
+  int ts_log2;                      // lattice pitch = 1 << ts_log2
+  int nbatch;
+};
+
+__device__ inline int pcc_grid_find(const PccGrid& g, int64_t key) {
+  const int b = (int)(key >> 48);
+  const int x = (int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - g.lo[0];
+  const int y = (int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - g.lo[1];
+  const int z = (int)(key & 0xFFFF) - (int)PCC_BIAS - g.lo[2];
+  if ((x | y | z) < 0 || b >= g.nbatch) return -1;
+  const int cx = x >> g.ts_log2, cy = y >> g.ts_log2, cz = z >> g.ts_log2;
+  if (cx >= g.dims[0] || cy >= g.dims[1] || cz >= g.dims[2]) return -1;
+  const long long cell = (((long long)b * g.dims[0] + cx) * g.dims[1] + cy) * g.dims[2] + cz;
+  const unsigned long long w = g.bits[cell >> 6];
+  const int bit = (int)(cell & 63);
+  if (!((w >> bit) & 1ull)) return -1;
+  return g.rank[cell >> 6] + __popcll(w & ((1ull << bit) - 1ull));
 }
 
-__device__ inline int pcc_find_bracketed(const int64_t* __restrict__ keys, int n, int64_t q) {
-  int64_t qmin = q, qmax = q;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const int64_t a = __shfl_xor(qmin, d), b = __shfl_xor(qmax, d);
-    qmin = a < qmin ? a : qmin;
-    qmax = b > qmax ? b : qmax;
-  }
-  qmin = pcc_wave_uniform(qmin);
-  qmax = pcc_wave_uniform(qmax);
-  int l = 0, h = n;
-  while (l < h) { const int m = (l + h) >> 1; if (keys[m] < qmin) l = m + 1; else h = m; }
-  int lo = l;
-  h = n;
-  while (l < h) { const int m = (l + h) >> 1; if (keys[m] <= qmax) l = m + 1; else h = m; }
-  int hi = l;
-  const int end = hi;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (keys[mid] < q) lo = mid + 1; else hi = mid;
-  }
-  return (lo < end && keys[lo] == q) ? lo : -1;
+__device__ inline int pcc_lookup(const PccGrid& g, const int64_t* __restrict__ keys, int n, int64_t q) {
+  return g.bits ? pcc_grid_find(g, q) : pcc_find(keys, n, q);
 }
 
 // internal cross-file entry points

@@ -74,16 +74,17 @@ __global__ void __launch_bounds__(1024) k_sum_counts(const int* __restrict__ c, 
 }
 
 // conv: thread per (k, o), o fastest
-__global__ void __launch_bounds__(256) k_map_conv(const int64_t* __restrict__ in_keys, int n_in,
+__global__ void __launch_bounds__(256) k_map_conv(PccGrid grid, const int64_t* __restrict__ in_keys, int n_in,
                                                   const int64_t* __restrict__ out_keys, int64_t n_out, int ks,
                                                   int step, int* __restrict__ nbr,
                                                   int* __restrict__ d_pairs) {
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
-  // consecutive output rows give close-by queries for one offset: bracket per wave, then search inside
-  const int64_t oc = o < n_out ? o : n_out - 1;
-  int idx = pcc_find_bracketed(in_keys, n_in, out_keys[oc] + pcc_delta_of(k, ks, step));
-  if (o < n_out) nbr[(int64_t)k * n_out + o] = idx; else idx = -1;
+  int idx = -1;
+  if (o < n_out) {
+    idx = pcc_lookup(grid, in_keys, n_in, out_keys[o] + pcc_delta_of(k, ks, step));
+    nbr[(int64_t)k * n_out + o] = idx;
+  }
   count_pairs(idx >= 0, d_pairs);
 }
 
@@ -114,7 +115,7 @@ __global__ void k_class_begin(const uint64_t* __restrict__ sorted_cls, int64_t n
 }
 
 // transposed: thread per (slot j, position p), p fastest; in = out - off*step
-__global__ void __launch_bounds__(256) k_map_transposed(const int64_t* __restrict__ in_keys, int n_in,
+__global__ void __launch_bounds__(256) k_map_transposed(PccGrid grid, const int64_t* __restrict__ in_keys, int n_in,
                                                         const int64_t* __restrict__ out_keys, int64_t n_out,
                                                         int ks, int step, const int* __restrict__ hdr,
                                                         const int* __restrict__ rows, int* __restrict__ nbr,
@@ -122,23 +123,22 @@ __global__ void __launch_bounds__(256) k_map_transposed(const int64_t* __restric
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
   bool hit = false;
-  // every lane runs the search (clamped position) so the wave-cooperative bracket sees 64 valid queries
-  const int64_t pc = p < n_out ? p : n_out - 1;
-  const int nseg = hdr[HDR_NSEG];
-  int s = 0;
-  for (; s < nseg - 1; ++s) {
+  if (p < n_out) {
+    const int nseg = hdr[HDR_NSEG];
+    int s = 0;
+    for (; s < nseg - 1; ++s) {
+      const int* sg = hdr + HDR_SEG0 + s * SEG_WORDS;
+      if (p < (int64_t)sg[SEG_POS_BEGIN] + sg[SEG_POS_COUNT]) break;
+    }
     const int* sg = hdr + HDR_SEG0 + s * SEG_WORDS;
-    if (pc < (int64_t)sg[SEG_POS_BEGIN] + sg[SEG_POS_COUNT]) break;
-  }
-  const int* sg = hdr + HDR_SEG0 + s * SEG_WORDS;
-  const bool live = j < sg[SEG_K_COUNT];
-  const int kid = hdr[HDR_KOFFS + sg[SEG_KOFF_BEGIN] + (live ? j : 0)];
-  const int o = rows[pc];
-  const int idx = pcc_find_bracketed(in_keys, n_in, out_keys[o] - pcc_delta_of(kid, ks, step));
-  if (p < n_out && live) {
-    const int64_t nb = ((int64_t)(unsigned)sg[SEG_NBR_LO]) | ((int64_t)sg[SEG_NBR_HI] << 32);
-    nbr[nb + (int64_t)j * sg[SEG_POS_COUNT] + (p - sg[SEG_POS_BEGIN])] = idx;
-    hit = idx >= 0;
+    if (j < sg[SEG_K_COUNT]) {
+      const int kid = hdr[HDR_KOFFS + sg[SEG_KOFF_BEGIN] + j];
+      const int o = rows[p];
+      const int idx = pcc_lookup(grid, in_keys, n_in, out_keys[o] - pcc_delta_of(kid, ks, step));
+      const int64_t nb = ((int64_t)(unsigned)sg[SEG_NBR_LO]) | ((int64_t)sg[SEG_NBR_HI] << 32);
+      nbr[nb + (int64_t)j * sg[SEG_POS_COUNT] + (p - sg[SEG_POS_BEGIN])] = idx;
+      hit = idx >= 0;
+    }
   }
   count_pairs(hit, d_pairs);
 }
@@ -174,8 +174,21 @@ extern "C" size_t pcc_map_ws_bytes(int64_t n_out) {
 extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys,
                                     int64_t n_out, int32_t kernel_size, int32_t step, int32_t stride,
                                     int32_t transposed, int32_t* hdr, int32_t* nbr, int32_t* rows,
-                                    int64_t* d_pairs, void* ws, size_t ws_bytes, void* stream) {
+                                    int64_t* d_pairs, const uint64_t* grid_bits, const int32_t* grid_rank,
+                                    const int32_t* h_grid, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  PccGrid grid;
+  memset(&grid, 0, sizeof(grid));
+  if (grid_bits) {
+    PCC_REQUIRE(grid_rank && h_grid, "pcc_kernel_map_build: grid needs rank[] and its 8 host parameters");
+    grid.bits = (const unsigned long long*)grid_bits;
+    grid.rank = grid_rank;
+    for (int i = 0; i < 3; ++i) { grid.lo[i] = h_grid[i]; grid.dims[i] = h_grid[3 + i]; }
+    PCC_REQUIRE(h_grid[6] >= 1 && (h_grid[6] & (h_grid[6] - 1)) == 0, "pcc_kernel_map_build: grid pitch must be a power of two");
+    int l = 0; while ((1 << l) < h_grid[6]) ++l;
+    grid.ts_log2 = l;
+    grid.nbatch = h_grid[7];
+  }
   PCC_REQUIRE(hdr, "pcc_kernel_map_build: hdr is NULL");
   PCC_REQUIRE(kernel_size >= 1 && kernel_size <= 5, "pcc_kernel_map_build: kernel_size %d unsupported", kernel_size);
   PCC_REQUIRE(step >= 1 && (step & (step - 1)) == 0, "pcc_kernel_map_build: step %d is not a power of two", step);
@@ -202,11 +215,11 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
     PCC_LAUNCH_CHECK();
     if (n_out == 0) return PCC_OK;
     PCC_REQUIRE(in_keys && out_keys && nbr, "pcc_kernel_map_build: NULL array");
-    dim3 grid((unsigned)pcc_cdiv(n_out, 256), (unsigned)K);
-    k_map_conv<<<grid, 256, 0, s>>>(in_keys, (int)n_in, out_keys, n_out, kernel_size, step, nbr, block_counts);
+    dim3 gdim((unsigned)pcc_cdiv(n_out, 256), (unsigned)K);
+    k_map_conv<<<gdim, 256, 0, s>>>(grid, in_keys, (int)n_in, out_keys, n_out, kernel_size, step, nbr, block_counts);
     PCC_LAUNCH_CHECK();
     if (d_pairs) {
-      k_sum_counts<<<1, 1024, 0, s>>>(block_counts, (int64_t)grid.x * grid.y, d_pairs);
+      k_sum_counts<<<1, 1024, 0, s>>>(block_counts, (int64_t)gdim.x * gdim.y, d_pairs);
       PCC_LAUNCH_CHECK();
     }
     return PCC_OK;
@@ -249,14 +262,77 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
   PCC_LAUNCH_CHECK();
   k_write_hdr<<<1, 1, 0, s>>>(plan, class_begin, 1, n_out, hdr);
   PCC_LAUNCH_CHECK();
-  dim3 grid((unsigned)pcc_cdiv(n_out, 256), (unsigned)max_class_k(kernel_size, stride));
-  k_map_transposed<<<grid, 256, 0, s>>>(in_keys, (int)n_in, out_keys, n_out, kernel_size, step, hdr, rows, nbr,
+  dim3 gdim((unsigned)pcc_cdiv(n_out, 256), (unsigned)max_class_k(kernel_size, stride));
+  k_map_transposed<<<gdim, 256, 0, s>>>(grid, in_keys, (int)n_in, out_keys, n_out, kernel_size, step, hdr, rows, nbr,
                                         block_counts);
   PCC_LAUNCH_CHECK();
   if (d_pairs) {
-    k_sum_counts<<<1, 1024, 0, s>>>(block_counts, (int64_t)grid.x * grid.y, d_pairs);
+    k_sum_counts<<<1, 1024, 0, s>>>(block_counts, (int64_t)gdim.x * gdim.y, d_pairs);
     PCC_LAUNCH_CHECK();
   }
+  return PCC_OK;
+}
+
+// ---- grid index build ---------------------------------------------------------------------------------
+__device__ inline long long grid_cell(const int64_t key, const int lo0, const int lo1, const int lo2, const int d0,
+                                      const int d1, const int d2, const int tsl) {
+  const int b = (int)(key >> 48);
+  const int cx = ((int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - lo0) >> tsl;
+  const int cy = ((int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - lo1) >> tsl;
+  const int cz = ((int)(key & 0xFFFF) - (int)PCC_BIAS - lo2) >> tsl;
+  return (((long long)b * d0 + cx) * d1 + cy) * d2 + cz;
+}
+
+// keys are sorted => cells ascending: the first row of each word ORs the bits of its (<= 64) followers; no atomics
+__global__ void k_grid_bits(const int64_t* __restrict__ keys, int64_t n, int lo0, int lo1, int lo2, int d0, int d1,
+                            int d2, int tsl, unsigned long long* __restrict__ bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long c = grid_cell(keys[i], lo0, lo1, lo2, d0, d1, d2, tsl);
+  const long long w = c >> 6;
+  if (i > 0 && (grid_cell(keys[i - 1], lo0, lo1, lo2, d0, d1, d2, tsl) >> 6) == w) return;
+  unsigned long long acc = 1ull << (c & 63);
+  for (int64_t t = i + 1; t < n && t < i + 64; ++t) {
+    const long long c2 = grid_cell(keys[t], lo0, lo1, lo2, d0, d1, d2, tsl);
+    if ((c2 >> 6) != w) break;
+    acc |= 1ull << (c2 & 63);
+  }
+  bits[w] = acc;
+}
+
+__global__ void k_grid_popc(const unsigned long long* __restrict__ bits, int64_t words, int* __restrict__ cnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words) cnt[i] = __popcll(bits[i]);
+}
+
+extern "C" int64_t pcc_grid_words(const int32_t* h_grid) {
+  const long long cells = (long long)h_grid[7] * h_grid[3] * h_grid[4] * h_grid[5];
+  return (cells + 63) / 64;
+}
+
+extern "C" size_t pcc_grid_ws_bytes(int64_t words) { return pcc_scan_ws_bytes(words) + 256; }
+
+extern "C" int pcc_grid_build(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits, int32_t* rank,
+                              void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(h_grid && bits && rank, "pcc_grid_build: NULL array");
+  const int64_t words = pcc_grid_words(h_grid);
+  PCC_REQUIRE(words >= 1 && words < (1ll << 31), "pcc_grid_build: lattice too large (%lld words)", (long long)words);
+  PCC_REQUIRE(h_grid[6] >= 1 && (h_grid[6] & (h_grid[6] - 1)) == 0, "pcc_grid_build: pitch must be a power of two");
+  if (ws_bytes < pcc_grid_ws_bytes(words)) {
+    pcc_set_error("pcc_grid_build: workspace too small");
+    return PCC_EWS;
+  }
+  PCC_CHECK_HIP(hipMemsetAsync(bits, 0, (size_t)words * 8, s));
+  if (n > 0) {
+    PCC_REQUIRE(keys, "pcc_grid_build: keys is NULL");
+    k_grid_bits<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(keys, n, h_grid[0], h_grid[1], h_grid[2], h_grid[3], h_grid[4],
+                                                          h_grid[5], ilog2(h_grid[6]), (unsigned long long*)bits);
+    PCC_LAUNCH_CHECK();
+  }
+  k_grid_popc<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>((const unsigned long long*)bits, words, rank);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(rank, rank, words, ws, ws_bytes, s));
   return PCC_OK;
 }
 

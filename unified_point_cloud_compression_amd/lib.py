@@ -38,7 +38,11 @@ SIGNATURES = {
     "pcc_coords_expand": (C.c_int, [_p, _i64, _i32, _i32, _u64, _p, _p, _p, _sz, _p]),
     "pcc_map_nbr_elems": (_i64, [_i64, _i32, _i32, _i32]),
     "pcc_map_ws_bytes": (_sz, [_i64]),
-    "pcc_kernel_map_build": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    "pcc_kernel_map_build": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p,
+                                       C.POINTER(_i32), _p, _sz, _p]),
+    "pcc_grid_words": (_i64, [C.POINTER(_i32)]),
+    "pcc_grid_ws_bytes": (_sz, [_i64]),
+    "pcc_grid_build": (C.c_int, [_p, _i64, C.POINTER(_i32), _p, _p, _p, _sz, _p]),
     "pcc_map_to_dense": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),

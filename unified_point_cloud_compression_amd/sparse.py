@@ -61,6 +61,8 @@ class KernelMap:
 
 
 COUNT_PAIRS = False   # bench.py switches this on for its FLOP accounting pass
+USE_GRID = True       # neighbour lookup through the bitmap+rank grid index (False: binary search; tests run both)
+GRID_MAX_BYTES = 8 << 30
 
 
 class CoordSet:
@@ -74,6 +76,7 @@ class CoordSet:
         self._C = None
         self._derived = {}
         self._maps = {}
+        self._grid = None
 
     @property
     def device(self):
@@ -89,6 +92,25 @@ class CoordSet:
             c._pcc_perm = None
             self._C = c
         return self._C
+
+    def grid(self):
+        """Occupancy bitmap + rank over the bounding lattice (the lookup structure of every map whose input is this
+        set).  Returns (bits, rank, h_grid) or None when the lattice would be unreasonably large."""
+        if self._grid is None:
+            b = self.bounds
+            dims = [(b.hi[i] - b.lo[i]) // self.ts + 1 for i in range(3)]
+            h = (C.c_int32 * 8)(b.lo[0], b.lo[1], b.lo[2], dims[0], dims[1], dims[2], self.ts, b.bmax + 1)
+            words = L.load().pcc_grid_words(h)
+            if self.n == 0 or words >= (1 << 31) or words * 12 > GRID_MAX_BYTES:
+                self._grid = False
+            else:
+                bits = torch.empty(words, dtype=torch.int64, device=self.device)
+                rank = torch.empty(words, dtype=torch.int32, device=self.device)
+                ws = L.workspace(L.load().pcc_grid_ws_bytes(words), self.device)
+                L.call("pcc_grid_build", L.ptr(self.keys), self.n, h, L.ptr(bits), L.ptr(rank), L.ptr(ws), ws.numel(),
+                       L.stream())
+                self._grid = (bits, rank, h)
+        return self._grid or None
 
     # ---- derived sets ------------------------------------------------------------------------
     def stride(self, new_stride):
@@ -144,9 +166,11 @@ class CoordSet:
         m.rows = torch.empty(max(out_set.n, 1), dtype=torch.int32, device=dev) if transposed else None
         m.d_pairs = torch.zeros(1, dtype=torch.int64, device=dev) if COUNT_PAIRS else None
         step = out_set.ts if transposed else self.ts
+        g = self.grid() if USE_GRID else None
         ws = L.workspace(lib.pcc_map_ws_bytes(out_set.n), dev)
         L.call("pcc_kernel_map_build", L.ptr(self.keys), self.n, L.ptr(out_set.keys), out_set.n, ksize, step,
                up_stride, 1 if transposed else 0, L.ptr(m.hdr), L.ptr(m.nbr), L.ptr(m.rows), L.ptr(m.d_pairs),
+               L.ptr(g[0]) if g else None, L.ptr(g[1]) if g else None, g[2] if g else None,
                L.ptr(ws), ws.numel(), L.stream())
         self._maps[key] = m
         # keep the output set alive as long as the map is cached (id() is the cache key)

@@ -58,18 +58,22 @@ def account_flops(model, pc, q):
     """One un-timed step with pair counting on: algorithmic FLOPs (2*P*Cin*Cout) of the MFMA conv launches."""
     from unified_point_cloud_compression_amd import sparse as S
     calls = []
-    orig = S.conv_forward
+    orig, orig_t = S.conv_forward, S.convt_forward
 
     def spy(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=0, slope=0.01):
         calls.append((kmap, K, cin, cout, n_out))
         return orig(feats, packed_w, bias, K, cin, cout, kmap, n_out, act, slope)
 
-    S.COUNT_PAIRS, S.conv_forward = True, spy
+    def spy_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=0, slope=0.01):
+        calls.append((kmap, K, cin, cout, n_out))     # pairs = n_in*K: the dense GEMM does exactly the algorithmic FLOPs
+        return orig_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act, slope)
+
+    S.COUNT_PAIRS, S.conv_forward, S.convt_forward = True, spy, spy_t
     try:
         step(model, pc, q)
         torch.cuda.synchronize()
     finally:
-        S.COUNT_PAIRS, S.conv_forward = False, orig
+        S.COUNT_PAIRS, S.conv_forward, S.convt_forward = False, orig, orig_t
     flops, launches, pairs_total = 0.0, 0, 0
     for kmap, K, cin, cout, n_out in calls:
         if not mfma_shape(cin, cout):

@@ -140,6 +140,18 @@ int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* p
                  const int32_t* nbr, const int32_t* rows, int64_t n_out, float* out, int32_t act,
                  float slope, void* stream);
 
+/* a3  generative transposed convolution, input stationary (ME.MinkowskiGenerativeConvolutionTranspose forward:
+ * model/transforms.py:129,133,137; model/entropy_models.py:186,188).  Every (input row, offset) is one pair, so
+ *   T[i][k][:] = feat_in[i] @ W[k]       one dense [n_in,cin] x [cin,K*cout] GEMM on the fp32 MFMA
+ *   out[o]     = act(bias + sum_k T[nbr_k(o)][k][:])   ordered gather-sum through the transposed map
+ * T: caller scratch of n_in*K*cout floats.  hdr/nbr/rows: a transposed map from pcc_kernel_map_build. */
+int64_t pcc_convt_packed_elems(int32_t K, int32_t cin, int32_t cout);
+int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed, void* stream);
+int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                  const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* hdr,
+                  const int32_t* nbr, const int32_t* rows, int64_t n_out, float* T, float* out, int32_t act,
+                  float slope, void* stream);
+
 /* a5  fused GDN / IGDN (GDN1 form), MinkowskiGDN.forward model/blocks.py:26-57:
  *   norm = beta + |x| @ gamma^T ; out = x / norm (inverse=0) or x * norm (inverse=1)
  * beta_raw/gamma_raw are the raw (un-reparametrised) CompressAI parameters; the

@@ -106,11 +106,14 @@ def test_generative_transpose_features(cin, cout, ks):
     W = (rng.standard_normal((K, cin, cout)) / np.sqrt(cin * 4)).astype(np.float32)
     b = rng.standard_normal((1, cout)).astype(np.float32)
     m = cs.kernel_map(out, ks, transposed=True, up_stride=2)
-    got = S.conv_forward(t(f), S.PackedConv().get(torch.nn.Parameter(t(W))), t(b), K, cin, cout, m, out.n)
+    got = S.convt_forward(t(f), S.PackedConv(True).get(torch.nn.Parameter(t(W))), t(b), K, cin, cout, m, out.n)
+    # the output-stationary kernel on the same transposed map must agree as well
+    got2 = S.conv_forward(t(f), S.PackedConv().get(torch.nn.Parameter(t(W))), t(b), K, cin, cout, m, out.n)
     out_keys = co.expand_keys(keys, ks, 1)
     pairs = codec.kernel_map_pairs(keys, out_keys, ks, 1, transposed=True)
     want = codec.conv_pairs(f, W, b, pairs, len(out_keys))
-    assert_close(n(got), want, what="generative transpose")
+    assert_close(n(got), want, what="generative transpose (input stationary)")
+    assert_close(n(got2), want, what="generative transpose (output stationary)")
 
 
 def test_conv_1x1_and_row_tails():

@@ -28,7 +28,19 @@ def spy(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=0, slope=0.01):
     return out
 
 
-S.COUNT_PAIRS, S.conv_forward = True, spy
+orig_t = S.convt_forward
+
+
+def spy_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=0, slope=0.01):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = orig_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act, slope)
+    e1.record()
+    calls.append((kmap, -K, cin, cout, feats.shape[0], n_out, e0, e1))
+    return out
+
+
+S.COUNT_PAIRS, S.conv_forward, S.convt_forward = True, spy, spy_t
 bench.step(model, pc, q)
 torch.cuda.synchronize()
 tot_ms = tot_fl = 0

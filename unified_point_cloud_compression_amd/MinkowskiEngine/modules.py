@@ -51,7 +51,7 @@ class _ConvBase(nn.Module):
         shape = (K, self.in_channels, self.out_channels) if K > 1 else (self.in_channels, self.out_channels)
         self.kernel = nn.Parameter(torch.empty(shape, dtype=torch.float32))
         self.bias = nn.Parameter(torch.empty(1, self.out_channels, dtype=torch.float32)) if bias else None
-        self._packed = S.PackedConv()
+        self._packed = S.PackedConv(transposed=self.TRANSPOSED)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -67,8 +67,9 @@ class _ConvBase(nn.Module):
         if torch.is_grad_enabled() and (x.F.requires_grad or self.kernel.requires_grad and self.training):
             raise L.PccError("libpcc_hip convolution has no backward yet: wrap inference in torch.no_grad() / model.eval()")
         packed = self._packed.get(self.kernel)
-        return S.conv_forward(x._canonical_features(), packed, self.bias, self.kernel_volume, self.in_channels,
-                              self.out_channels, kmap, out_set.n, act, slope)
+        fwd = S.convt_forward if self.TRANSPOSED else S.conv_forward
+        return fwd(x._canonical_features(), packed, self.bias, self.kernel_volume, self.in_channels,
+                   self.out_channels, kmap, out_set.n, act, slope)
 
     def extra_repr(self):
         return (f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, "

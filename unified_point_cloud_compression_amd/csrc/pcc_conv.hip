@@ -295,6 +295,15 @@ __device__ inline float thin_dot(float4 x, float4 w) { return x.x * w.x + x.y * 
 __device__ inline float thin_dot(float x, float w) { return x * w; }
 __device__ inline void thin_zero(float4& v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ inline void thin_zero(float& v) { v = 0.f; }
+__device__ inline void thin_acc(float4& a, const float4 x) { a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
+__device__ inline void thin_acc(float& a, const float x) { a += x; }
+__device__ inline float act1(float v, int act, float slope) {
+  if (act == PCC_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == PCC_ACT_LEAKY) return v >= 0.f ? v : v * slope;
+  return v;
+}
+__device__ inline void thin_act(float4& a, int act, float s) { a.x = act1(a.x, act, s); a.y = act1(a.y, act, s); a.z = act1(a.z, act, s); a.w = act1(a.w, act, s); }
+__device__ inline void thin_act(float& a, int act, float s) { a = act1(a, act, s); }
 
 // LPR lanes share one output position, each lane owns VEC consecutive input channels per pass.  Offsets are
 // processed in batches of JB with all neighbour-index loads, then all feature loads, issued back to back
@@ -527,6 +536,141 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
     PCC_TRY(prof_event(&e1, s));
     ++g_launches;
   }
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Generative transposed convolution, input stationary.
+//   Every (input row i, kernel offset k) is exactly one pair of the map, so the products
+//   T[i][k][:] = feat[i] @ W[k] form ONE dense GEMM  [n_in, cin] x [cin, K*cout]  with no gather and no padding
+//   waste, however sparse the output neighbourhoods are.  The sum over the pairs of an output row is then taken
+//   in fixed order (class offsets ascending) through the transposed map: deterministic, no atomics.
+// ------------------------------------------------------------------------------------------
+__global__ void k_pack_convt(const float* __restrict__ W, int K, int cin, int cout, int ncol, int cout_pad,
+                             int cb_log2, float* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)cin * cout_pad;
+  if (t >= total) return;
+  const int CB = 1 << cb_log2;
+  const int within = (int)(t & (CB - 1));
+  const long long q = t >> cb_log2;
+  const int col = (int)(q % cout_pad);
+  const int cbi = (int)(q / cout_pad);
+  const int ci = (cbi << cb_log2) + within;
+  float v = 0.f;
+  if (col < ncol) {
+    const int k = col / cout, co = col - k * cout;
+    v = W[((long long)k * cin + ci) * cout + co];
+  }
+  out[t] = v;
+}
+
+extern "C" int64_t pcc_convt_packed_elems(int32_t K, int32_t cin, int32_t cout) {
+  if (K <= 0 || cin <= 0 || cout <= 0 || !mfma_ok(cin, K * cout)) return 0;
+  return (int64_t)cin * cout_pad_for(K * cout);
+}
+
+extern "C" int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
+                                      void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(W && packed && K >= 1 && K <= MAXK && cin >= 1 && cout >= 1, "pcc_convt_pack_weights: bad arguments");
+  PCC_REQUIRE(mfma_ok(cin, K * cout), "pcc_convt: unsupported shape cin=%d (needs 4, 8, 16 or a multiple of 32)", cin);
+  const int64_t total = pcc_convt_packed_elems(K, cin, cout);
+  k_pack_convt<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(W, K, cin, cout, K * cout, cout_pad_for(K * cout),
+                                                             cb_log2_for(cin), packed);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+struct GatherArgs {
+  const float* T; const float* bias; const int* hdr; const int* nbr; const int* rows;
+  float* out; long long n_out; int K, cout, act; float slope; int lpr_log2;
+};
+
+// LPR lanes per output position, VEC channels per lane and pass; offsets in batches of independent loads
+template <int VEC>
+__global__ void __launch_bounds__(256) k_convt_gather(GatherArgs a) {
+  typedef typename ThinVec<VEC>::T VT;
+  constexpr int JB = 9;
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << a.lpr_log2;
+  const int rpw = 64 >> a.lpr_log2;
+  const long long p = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> a.lpr_log2);
+  const int cl = lane & (lpr - 1);
+  if (p >= a.n_out) return;
+  const int cvec = a.cout / VEC;
+  const int nseg = a.hdr[HDR_NSEG];
+  int s = 0;
+  for (; s < nseg - 1; ++s) {
+    const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+    if (p < (long long)sg[SEG_POS_BEGIN] + sg[SEG_POS_COUNT]) break;
+  }
+  const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+  const int k_count = sg[SEG_K_COUNT], koff_begin = sg[SEG_KOFF_BEGIN];
+  const long long spc = sg[SEG_POS_COUNT], local = p - sg[SEG_POS_BEGIN];
+  const int* seg_nbr = a.nbr + (((long long)(unsigned)sg[SEG_NBR_LO]) | ((long long)sg[SEG_NBR_HI] << 32));
+  const long long orow = a.rows ? a.rows[p] : p;
+  for (int cv = cl; cv < cvec; cv += lpr) {
+    VT acc;
+    thin_zero(acc);
+    for (int j0 = 0; j0 < k_count; j0 += JB) {
+      int ir[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) ir[u] = (j0 + u < k_count) ? seg_nbr[(long long)(j0 + u) * spc + local] : -1;
+      VT x[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) {
+        thin_zero(x[u]);
+        if (ir[u] >= 0) {
+          const int kid = a.hdr[HDR_KOFFS + koff_begin + j0 + u];
+          x[u] = reinterpret_cast<const VT*>(a.T + ((long long)ir[u] * a.K + kid) * a.cout)[cv];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < JB; ++u) thin_acc(acc, x[u]);     // fixed order: offsets ascending
+    }
+    VT b;
+    thin_zero(b);
+    if (a.bias) b = reinterpret_cast<const VT*>(a.bias)[cv];
+    thin_acc(acc, b);
+    thin_act(acc, a.act, a.slope);
+    reinterpret_cast<VT*>(a.out + orow * a.cout)[cv] = acc;
+  }
+}
+
+extern "C" int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias,
+                             int32_t K, int32_t cout, const int32_t* hdr, const int32_t* nbr, const int32_t* rows,
+                             int64_t n_out, float* T, float* out, int32_t act, float slope, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out <= 0 || n_in <= 0) return PCC_OK;
+  PCC_REQUIRE(feat_in && packed_w && hdr && nbr && rows && T && out, "pcc_convt_fwd: NULL array");
+  PCC_REQUIRE(K >= 1 && K <= MAXK && mfma_ok(cin, K * cout), "pcc_convt_fwd: unsupported shape K=%d cin=%d cout=%d", K, cin, cout);
+  PCC_REQUIRE(act >= 0 && act <= 2, "pcc_convt_fwd: bad activation");
+  PCC_REQUIRE(n_in < (1ll << 31) && n_out < (1ll << 31), "pcc_convt_fwd: too many rows");
+  // 1) dense GEMM  T[n_in, K*cout] = feat[n_in, cin] @ Wflat[cin, K*cout]
+  ConvArgs a;
+  a.feat = feat_in; a.wp = packed_w; a.bias = nullptr; a.hdr = nullptr; a.nbr = nullptr; a.rows = nullptr; a.out = T;
+  a.n_out = n_in; a.cin = cin; a.cout = K * cout; a.cout_pad = cout_pad_for(K * cout);
+  a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
+  hipEvent_t e0, e1;
+  if (g_prof_on) PCC_TRY(prof_event(&e0, s));
+  PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));
+  if (g_prof_on) {
+    PCC_TRY(prof_event(&e1, s));
+    ++g_launches;
+  }
+  // 2) ordered gather-sum through the transposed map
+  GatherArgs g;
+  g.T = T; g.bias = bias; g.hdr = hdr; g.nbr = nbr; g.rows = rows; g.out = out; g.n_out = n_out; g.K = K; g.cout = cout;
+  g.act = act; g.slope = slope;
+  const int vec = (cout % 4 == 0) ? 4 : 1;
+  int l = 0;
+  while ((1 << l) < cout / vec && l < 6) ++l;
+  g.lpr_log2 = l;
+  const int64_t waves = pcc_cdiv(n_out, 64 >> l);
+  if (vec == 4) k_convt_gather<4><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(g);
+  else k_convt_gather<1><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(g);
+  PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
 

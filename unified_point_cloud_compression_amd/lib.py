@@ -47,6 +47,9 @@ SIGNATURES = {
     "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "pcc_conv_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _f32, _p]),
+    "pcc_convt_packed_elems": (_i64, [_i32, _i32, _i32]),
+    "pcc_convt_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "pcc_convt_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _f32, _p]),
     "pcc_gdn_pack": (C.c_int, [_p, _p, _i32, _f32, _p, _p, _p]),
     "pcc_gdn_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p]),
     "pcc_topk_ws_bytes": (_sz, [_i64]),

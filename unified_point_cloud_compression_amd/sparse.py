@@ -248,11 +248,13 @@ def coordset_from_coords(coords, tensor_stride):
 # functional operators on canonical-order features
 # ------------------------------------------------------------------------------------------------
 class PackedConv:
-    """Packed copy of a conv weight, refreshed when the parameter changes."""
+    """Packed copy of a conv weight, refreshed when the parameter changes.  `transposed` selects the flattened
+    [cin, K*cout] layout of the input-stationary generative transposed convolution."""
 
-    def __init__(self):
+    def __init__(self, transposed=False):
         self.tag = None
         self.packed = None
+        self.transposed = transposed
 
     def get(self, kernel):
         w = kernel.detach()
@@ -261,9 +263,12 @@ class PackedConv:
             w3 = w if w.dim() == 3 else w.unsqueeze(0)
             w3 = w3.to(torch.float32).contiguous()
             K, cin, cout = w3.shape
-            n = L.load().pcc_conv_packed_elems(K, cin, cout)
+            pre = "pcc_convt" if self.transposed else "pcc_conv"
+            n = getattr(L.load(), pre + "_packed_elems")(K, cin, cout)
+            if n <= 0:
+                raise L.PccError(f"unsupported convolution shape K={K} cin={cin} cout={cout}")
             self.packed = torch.empty(n, dtype=torch.float32, device=w.device)
-            L.call("pcc_conv_pack_weights", L.ptr(w3), K, cin, cout, L.ptr(self.packed), L.stream())
+            L.call(pre + "_pack_weights", L.ptr(w3), K, cin, cout, L.ptr(self.packed), L.stream())
             self.tag = tag
         return self.packed
 
@@ -278,6 +283,20 @@ def conv_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NON
     L.call("pcc_conv_fwd", L.ptr(feats), feats.shape[0], cin, L.ptr(packed_w), L.ptr(b), K, cout,
            L.ptr(kmap.hdr) if kmap is not None else None, L.ptr(kmap.nbr) if kmap is not None else None,
            L.ptr(kmap.rows) if kmap is not None else None, n_out, L.ptr(out), act, float(slope), L.stream())
+    return out
+
+
+def convt_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NONE, slope=0.01):
+    """Generative transposed conv (a3): dense GEMM into the per-pair buffer T, then ordered gather-sum."""
+    feats = feats.contiguous()
+    n_in = feats.shape[0]
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    if n_out == 0 or n_in == 0:
+        return out
+    T = torch.empty(n_in * K * cout, dtype=torch.float32, device=feats.device)
+    b = bias.detach().reshape(-1).contiguous() if bias is not None else None
+    L.call("pcc_convt_fwd", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(kmap.hdr),
+           L.ptr(kmap.nbr), L.ptr(kmap.rows), n_out, L.ptr(T), L.ptr(out), act, float(slope), L.stream())
     return out
 
 

@@ -135,10 +135,11 @@ int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
 /* W: ME layout [K, cin, cout] row-major (state_dict `kernel`) */
 int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
                           void* stream);
+size_t pcc_conv_ws_bytes(int64_t n_in, int32_t K, int32_t cin, int32_t cout);
 int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                  const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* hdr,
                  const int32_t* nbr, const int32_t* rows, int64_t n_out, float* out, int32_t act,
-                 float slope, void* stream);
+                 float slope, void* ws, size_t ws_bytes, void* stream);
 
 /* a3  generative transposed convolution, input stationary (ME.MinkowskiGenerativeConvolutionTranspose forward:
  * model/transforms.py:129,133,137; model/entropy_models.py:186,188).  Every (input row, offset) is one pair, so

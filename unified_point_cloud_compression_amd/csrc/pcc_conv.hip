@@ -388,6 +388,197 @@ __global__ void __launch_bounds__(256) k_conv_thin(ThinArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Thin outputs, two-pass form (cout <= 4, cin <= 64):  out[o] = b + sum_k  <feat[nbr_k(o)], w_k>
+//   pass 1  t[k*cout+co][i] = <feat[i], w_k[co]>      per input row, features read ONCE, coalesced writes
+//   pass 2  out[o][co]      = b + sum_k t[k*cout+co][nbr_k(o)]   scalar gathers, near-contiguous per offset
+// 16x (cin=16) to 64x (cin=64) fewer gathered bytes than fetching whole neighbour rows per offset.
+// ------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ void __launch_bounds__(256) k_thin_project(const float* __restrict__ feat, long long n_in,
+                                                      const float* __restrict__ wt, int kc, float* __restrict__ t) {
+  extern __shared__ __attribute__((aligned(16))) float w_s[];
+  for (int i = threadIdx.x; i < kc * CIN; i += 256) w_s[i] = wt[i];
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_in) return;
+  float4 x[CIN / 4];
+#pragma unroll
+  for (int c = 0; c < CIN / 4; ++c) x[c] = reinterpret_cast<const float4*>(feat + i * CIN)[c];
+  for (int k = 0; k < kc; ++k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN / 4; ++c) {
+      const float4 w = reinterpret_cast<const float4*>(w_s + k * CIN)[c];   // wave-uniform address: LDS broadcast
+      acc += x[c].x * w.x + x[c].y * w.y + x[c].z * w.z + x[c].w * w.w;
+    }
+    t[(long long)k * n_in + i] = acc;
+  }
+}
+
+struct ThinGatherArgs {
+  const float* t; const float* bias; const int* hdr; const int* nbr; const int* rows;
+  float* out; long long n_in, n_out; int cout, act; float slope;
+};
+
+template <int COUT_MAX>
+__global__ void __launch_bounds__(256) k_thin_gather(ThinGatherArgs a) {
+  constexpr int JB = 9;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n_out) return;
+  int k_count = 1, koff_begin = 0;
+  long long spc = a.n_out, local = p;
+  const int* seg_nbr = nullptr;
+  const bool identity = (a.hdr == nullptr);
+  if (!identity) {
+    const int nseg = a.hdr[HDR_NSEG];
+    int s = 0;
+    for (; s < nseg - 1; ++s) {
+      const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+      if (p < (long long)sg[SEG_POS_BEGIN] + sg[SEG_POS_COUNT]) break;
+    }
+    const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+    k_count = sg[SEG_K_COUNT]; koff_begin = sg[SEG_KOFF_BEGIN]; spc = sg[SEG_POS_COUNT];
+    local = p - sg[SEG_POS_BEGIN];
+    seg_nbr = a.nbr + (((long long)(unsigned)sg[SEG_NBR_LO]) | ((long long)sg[SEG_NBR_HI] << 32));
+  }
+  float acc[COUT_MAX];
+#pragma unroll
+  for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
+  for (int j0 = 0; j0 < k_count; j0 += JB) {
+    int ir[JB];
+#pragma unroll
+    for (int u = 0; u < JB; ++u)
+      ir[u] = (j0 + u < k_count) ? (identity ? (int)p : seg_nbr[(long long)(j0 + u) * spc + local]) : -1;
+    float v[JB][COUT_MAX];
+#pragma unroll
+    for (int u = 0; u < JB; ++u) {
+      const int kid = (ir[u] >= 0 && !identity) ? a.hdr[HDR_KOFFS + koff_begin + j0 + u] : 0;
+#pragma unroll
+      for (int o = 0; o < COUT_MAX; ++o)
+        v[u][o] = (ir[u] >= 0 && o < a.cout) ? a.t[(long long)(kid * a.cout + o) * a.n_in + ir[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < JB; ++u)
+#pragma unroll
+      for (int o = 0; o < COUT_MAX; ++o) acc[o] += v[u][o];
+  }
+  const long long orow = a.rows ? a.rows[p] : p;
+#pragma unroll
+  for (int o = 0; o < COUT_MAX; ++o)
+    if (o < a.cout) a.out[orow * a.cout + o] = act1(acc[o] + (a.bias ? a.bias[o] : 0.f), a.act, a.slope);
+}
+
+// ------------------------------------------------------------------------------------------
+// Narrow outputs with weights that fit LDS (4 < cout <= 16, cin in {16,32,64}): wave-autonomous kernel on
+// v_mfma_f32_16x16x4_f32.  All K weight slices sit in LDS for the whole (persistent) workgroup; each wave owns
+// 32 positions (two 16-row MFMA tiles), reads the neighbour rows straight from global memory into the MFMA A
+// layout (lane = row, 16-byte k-quads) and never meets a workgroup barrier in its main loop.  No padding to a
+// 32-wide column tile, offsets with no neighbour in the wave's 32 rows are skipped by ballot.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Wave16Args {
+  const float* feat; const float* wl; const float* bias; const int* hdr; const int* nbr; const int* rows;
+  float* out; long long n_out; int K, cout, act; float slope;
+};
+
+template <int CIN>
+__global__ void __launch_bounds__(256) k_conv_wave16(Wave16Args a) {
+  constexpr int LD = CIN + 4;
+  constexpr int G = CIN / 16;
+  extern __shared__ __attribute__((aligned(16))) float wl_s[];   // [K][16][LD]
+  for (int i = threadIdx.x; i < a.K * 16 * (CIN / 4); i += 256) {
+    const int row = i / (CIN / 4), c4 = i - row * (CIN / 4);
+    reinterpret_cast<float4*>(wl_s + row * LD)[c4] = reinterpret_cast<const float4*>(a.wl + (long long)row * CIN)[c4];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+  const bool identity = (a.hdr == nullptr);
+  const int nseg = identity ? 1 : a.hdr[HDR_NSEG];
+  long long total_tiles = 0;
+  if (identity) total_tiles = (a.n_out + 31) / 32;
+  else
+    for (int s = 0; s < nseg; ++s) total_tiles += (a.hdr[HDR_SEG0 + s * SEG_WORDS + SEG_POS_COUNT] + 31) / 32;
+
+  for (long long wt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wt < total_tiles; wt += (long long)gridDim.x * 4) {
+    long long pos0, spc;
+    int npos, k_count = 1, koff_begin = 0;
+    const int* seg_nbr = nullptr;
+    if (identity) {
+      pos0 = wt * 32; npos = (int)min(32ll, a.n_out - pos0); spc = a.n_out;
+    } else {
+      long long tile = wt;
+      int s = 0;
+      for (; s < nseg - 1; ++s) {
+        const long long tiles = (a.hdr[HDR_SEG0 + s * SEG_WORDS + SEG_POS_COUNT] + 31) / 32;
+        if (tile < tiles) break;
+        tile -= tiles;
+      }
+      const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+      k_count = sg[SEG_K_COUNT]; koff_begin = sg[SEG_KOFF_BEGIN]; spc = sg[SEG_POS_COUNT];
+      const long long local0 = tile * 32;
+      pos0 = sg[SEG_POS_BEGIN] + local0;
+      npos = (int)min(32ll, spc - local0);
+      seg_nbr = a.nbr + (((long long)(unsigned)sg[SEG_NBR_LO]) | ((long long)sg[SEG_NBR_HI] << 32)) + local0;
+    }
+    const bool vA = r16 < npos, vB = 16 + r16 < npos;
+    f32x4 accA0 = {0.f, 0.f, 0.f, 0.f}, accA1 = accA0, accB0 = accA0, accB1 = accA0;
+    auto fetch = [&](int j, int& iA, int& iB) {
+      iA = -1; iB = -1;
+      if (j < k_count) {
+        if (vA) iA = identity ? (int)(pos0 + r16) : seg_nbr[(long long)j * spc + r16];
+        if (vB) iB = identity ? (int)(pos0 + 16 + r16) : seg_nbr[(long long)j * spc + 16 + r16];
+      }
+    };
+    int iA, iB, nA, nB;
+    fetch(0, iA, iB);
+    for (int j = 0; j < k_count; ++j) {
+      fetch(j + 1, nA, nB);                                   // next offset's rows: hides the index-load latency
+      if (__ballot(iA >= 0 || iB >= 0)) {
+        const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + j];
+        float4 xa[G], xb[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          xa[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+          xb[g] = xa[g];
+          if (iA >= 0) xa[g] = *reinterpret_cast<const float4*>(a.feat + (long long)iA * CIN + 16 * g + 4 * q);
+          if (iB >= 0) xb[g] = *reinterpret_cast<const float4*>(a.feat + (long long)iB * CIN + 16 * g + 4 * q);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 w = *reinterpret_cast<const float4*>(wl_s + (kid * 16 + r16) * LD + 16 * g + 4 * q);
+          accA0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].x, w.x, accA0, 0, 0, 0);
+          accB0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[g].x, w.x, accB0, 0, 0, 0);
+          accA1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].y, w.y, accA1, 0, 0, 0);
+          accB1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[g].y, w.y, accB1, 0, 0, 0);
+          accA0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].z, w.z, accA0, 0, 0, 0);
+          accB0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[g].z, w.z, accB0, 0, 0, 0);
+          accA1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].w, w.w, accA1, 0, 0, 0);
+          accB1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[g].w, w.w, accB1, 0, 0, 0);
+        }
+      }
+      iA = nA; iB = nB;
+    }
+    // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+    if (r16 < a.cout) {
+      const float b = a.bias ? a.bias[r16] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int rA = 4 * q + e, rB = 16 + 4 * q + e;
+        if (rA < npos) {
+          const long long orow = a.rows ? a.rows[pos0 + rA] : pos0 + rA;
+          a.out[orow * a.cout + r16] = act1(accA0[e] + accA1[e] + b, a.act, a.slope);
+        }
+        if (rB < npos) {
+          const long long orow = a.rows ? a.rows[pos0 + rB] : pos0 + rB;
+          a.out[orow * a.cout + r16] = act1(accB0[e] + accB1[e] + b, a.act, a.slope);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // dispatch, packing
 // ------------------------------------------------------------------------------------------
 static bool mfma_ok(int cin, int cout) {
@@ -398,10 +589,32 @@ static bool mfma_ok(int cin, int cout) {
 static int cb_log2_for(int cin) { return cin >= 32 ? 5 : (cin == 16 ? 4 : (cin == 8 ? 3 : 2)); }
 static int cout_pad_for(int cout) { const int bn = bn_for(cout); return (cout + bn - 1) / bn * bn; }
 
+enum { KIND_NONE = -1, KIND_MFMA = 0, KIND_WAVE16 = 1, KIND_THIN_T = 2, KIND_THIN = 3 };
+static int conv_kind(int K, int cin, int cout) {
+  if (cout <= 4) {
+    const bool pow2 = cin == 4 || cin == 8 || cin == 16 || cin == 32 || cin == 64;
+    if (pow2 && (int64_t)K * cout * cin * 4 <= 48 * 1024) return KIND_THIN_T;
+    return KIND_THIN;
+  }
+  if (cout <= 16 && (cin == 16 || cin == 32 || cin == 64) && (int64_t)K * 16 * (cin + 4) * 4 <= 64 * 1024)
+    return KIND_WAVE16;
+  return mfma_ok(cin, cout) ? KIND_MFMA : KIND_NONE;
+}
+
 extern "C" int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout) {
   if (K <= 0 || cin <= 0 || cout <= 0) return 0;
-  if (mfma_ok(cin, cout)) return (int64_t)K * cin * cout_pad_for(cout);
-  return (int64_t)K * cin * cout;
+  switch (conv_kind(K, cin, cout)) {
+    case KIND_MFMA: return (int64_t)K * cin * cout_pad_for(cout);
+    case KIND_WAVE16: return (int64_t)K * 16 * cin;
+    case KIND_THIN_T: case KIND_THIN: return (int64_t)K * cin * cout;
+    default: return 0;
+  }
+}
+
+// scratch floats pcc_conv_fwd needs (two-pass thin form: the projection buffer t[K*cout][n_in])
+extern "C" size_t pcc_conv_ws_bytes(int64_t n_in, int32_t K, int32_t cin, int32_t cout) {
+  if (conv_kind(K, cin, cout) == KIND_THIN_T) return (size_t)K * cout * (size_t)n_in * sizeof(float) + 256;
+  return 256;
 }
 
 // W [K][cin][cout] -> MFMA layout [K*ppo][cout_pad][CB] (zero padded columns)
@@ -421,6 +634,16 @@ __global__ void k_pack_mfma(const float* __restrict__ W, int K, int cin, int cou
   out[t] = (col < cout) ? W[((long long)kid * cin + ci) * cout + col] : 0.f;
 }
 
+// W [K][cin][cout] -> wave16 layout [K][16][cin] (column-major per offset, zero padded to 16 columns)
+__global__ void k_pack_wave16(const float* __restrict__ W, int K, int cin, int cout, float* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)K * 16 * cin) return;
+  const int c = (int)(t % cin);
+  const int o = (int)((t / cin) % 16);
+  const int k = (int)(t / ((long long)cin * 16));
+  out[t] = o < cout ? W[((long long)k * cin + c) * cout + o] : 0.f;
+}
+
 // W [K][cin][cout] -> thin layout [K][cout][cin]
 __global__ void k_pack_thin(const float* __restrict__ W, int K, int cin, int cout, float* __restrict__ out) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -436,11 +659,14 @@ extern "C" int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(W && packed && K >= 1 && K <= MAXK && cin >= 1 && cout >= 1, "pcc_conv_pack_weights: bad arguments");
   const int64_t total = pcc_conv_packed_elems(K, cin, cout);
-  if (mfma_ok(cin, cout))
-    k_pack_mfma<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(W, K, cin, cout, cout_pad_for(cout), cb_log2_for(cin), packed);
-  else {
-    PCC_REQUIRE(cout <= 4, "pcc_conv: unsupported shape cin=%d cout=%d (MFMA path needs cin in {4,8,16} or a multiple of 32)", cin, cout);
-    k_pack_thin<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(W, K, cin, cout, packed);
+  const unsigned g = (unsigned)pcc_cdiv(total > 0 ? total : 1, 256);
+  switch (conv_kind(K, cin, cout)) {
+    case KIND_MFMA: k_pack_mfma<<<g, 256, 0, s>>>(W, K, cin, cout, cout_pad_for(cout), cb_log2_for(cin), packed); break;
+    case KIND_WAVE16: k_pack_wave16<<<g, 256, 0, s>>>(W, K, cin, cout, packed); break;
+    case KIND_THIN_T: case KIND_THIN: k_pack_thin<<<g, 256, 0, s>>>(W, K, cin, cout, packed); break;
+    default:
+      pcc_set_error("pcc_conv: unsupported shape cin=%d cout=%d (MFMA path needs cin in {4,8,16} or a multiple of 32)", cin, cout);
+      return PCC_EINVAL;
   }
   PCC_LAUNCH_CHECK();
   return PCC_OK;
@@ -497,10 +723,33 @@ static int launch_mfma(const ConvArgs& a, int tiles_bound_extra, hipStream_t s) 
   return PCC_OK;
 }
 
+template <int CIN>
+static int launch_wave16(const Wave16Args& a, hipStream_t s) {
+  const size_t lds = (size_t)a.K * 16 * (CIN + 4) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_wave16<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_set = true;
+  }
+  const long long tiles = pcc_cdiv(a.n_out, 32) + (a.rows ? PCC_MAP_MAX_SEG : 0);
+  const long long want = pcc_cdiv(tiles, 4);
+  const unsigned grid = (unsigned)(want < 512 ? want : 512);     // persistent: 2 workgroups per CU re-use the LDS weights
+  k_conv_wave16<CIN><<<grid, 256, lds, s>>>(a);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+template <int CIN>
+static int launch_project(const float* feat, int64_t n_in, const float* wt, int kc, float* t, hipStream_t s) {
+  k_thin_project<CIN><<<(unsigned)pcc_cdiv(n_in, 256), 256, (size_t)kc * CIN * sizeof(float), s>>>(feat, n_in, wt, kc, t);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
 extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                             const float* bias, int32_t K, int32_t cout, const int32_t* hdr, const int32_t* nbr,
                             const int32_t* rows, int64_t n_out, float* out, int32_t act, float slope,
-                            void* stream) {
+                            void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0) return PCC_OK;
   PCC_REQUIRE(feat_in && packed_w && out && n_in > 0, "pcc_conv_fwd: NULL array");
@@ -508,17 +757,44 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
   PCC_REQUIRE(hdr ? (nbr != nullptr) : (K == 1 && n_in == n_out), "pcc_conv_fwd: map missing (only K=1 may omit it)");
   PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd: bad activation");
   PCC_REQUIRE(n_in < (1ll << 31) && n_out < (1ll << 31), "pcc_conv_fwd: too many rows");
+  const int kind = conv_kind(K, cin, cout);
+  PCC_REQUIRE(kind != KIND_NONE, "pcc_conv_fwd: unsupported shape cin=%d cout=%d", cin, cout);
   hipEvent_t e0, e1;
-  const bool timed = g_prof_on && mfma_ok(cin, cout);   // the roofline kernel: MFMA launches only
+  const bool timed = g_prof_on && (kind == KIND_MFMA || kind == KIND_WAVE16);   // the roofline kernels: MFMA launches
   if (timed) PCC_TRY(prof_event(&e0, s));
-  if (mfma_ok(cin, cout)) {
+  if (kind == KIND_MFMA) {
     ConvArgs a;
     a.feat = feat_in; a.wp = packed_w; a.bias = bias; a.hdr = hdr; a.nbr = nbr; a.rows = rows; a.out = out;
     a.n_out = n_out; a.cin = cin; a.cout = cout; a.cout_pad = cout_pad_for(cout);
     a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = act; a.slope = slope;
     PCC_TRY(launch_mfma<MODE_CONV>(a, rows ? PCC_MAP_MAX_SEG : 0, s));
+  } else if (kind == KIND_WAVE16) {
+    Wave16Args a;
+    a.feat = feat_in; a.wl = packed_w; a.bias = bias; a.hdr = hdr; a.nbr = nbr; a.rows = rows; a.out = out;
+    a.n_out = n_out; a.K = K; a.cout = cout; a.act = act; a.slope = slope;
+    if (cin == 16) PCC_TRY(launch_wave16<16>(a, s));
+    else if (cin == 32) PCC_TRY(launch_wave16<32>(a, s));
+    else PCC_TRY(launch_wave16<64>(a, s));
+  } else if (kind == KIND_THIN_T) {
+    if (!ws || ws_bytes < pcc_conv_ws_bytes(n_in, K, cin, cout)) {
+      pcc_set_error("pcc_conv_fwd: workspace too small (need pcc_conv_ws_bytes)");
+      return PCC_EWS;
+    }
+    float* t = (float*)ws;
+    const int kc = K * cout;
+    switch (cin) {
+      case 4: PCC_TRY(launch_project<4>(feat_in, n_in, packed_w, kc, t, s)); break;
+      case 8: PCC_TRY(launch_project<8>(feat_in, n_in, packed_w, kc, t, s)); break;
+      case 16: PCC_TRY(launch_project<16>(feat_in, n_in, packed_w, kc, t, s)); break;
+      case 32: PCC_TRY(launch_project<32>(feat_in, n_in, packed_w, kc, t, s)); break;
+      default: PCC_TRY(launch_project<64>(feat_in, n_in, packed_w, kc, t, s)); break;
+    }
+    ThinGatherArgs g;
+    g.t = t; g.bias = bias; g.hdr = hdr; g.nbr = nbr; g.rows = rows; g.out = out; g.n_in = n_in; g.n_out = n_out;
+    g.cout = cout; g.act = act; g.slope = slope;
+    k_thin_gather<4><<<(unsigned)pcc_cdiv(n_out, 256), 256, 0, s>>>(g);
+    PCC_LAUNCH_CHECK();
   } else {
-    PCC_REQUIRE(cout <= 4, "pcc_conv_fwd: unsupported shape cin=%d cout=%d", cin, cout);
     ThinArgs t;
     t.feat = feat_in; t.wt = packed_w; t.bias = bias; t.hdr = hdr; t.nbr = nbr; t.rows = rows; t.out = out;
     t.n_out = n_out; t.cin = cin; t.cout = cout; t.act = act; t.slope = slope;

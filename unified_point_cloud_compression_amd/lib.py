@@ -46,7 +46,8 @@ SIGNATURES = {
     "pcc_map_to_dense": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
-    "pcc_conv_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _f32, _p]),
+    "pcc_conv_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "pcc_conv_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _f32, _p, _sz, _p]),
     "pcc_convt_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_convt_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "pcc_convt_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _f32, _p]),

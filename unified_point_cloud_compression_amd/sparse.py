@@ -280,9 +280,11 @@ def conv_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NON
     if n_out == 0:
         return out
     b = bias.detach().reshape(-1).contiguous() if bias is not None else None
+    ws = L.workspace(L.load().pcc_conv_ws_bytes(feats.shape[0], K, cin, cout), feats.device)
     L.call("pcc_conv_fwd", L.ptr(feats), feats.shape[0], cin, L.ptr(packed_w), L.ptr(b), K, cout,
            L.ptr(kmap.hdr) if kmap is not None else None, L.ptr(kmap.nbr) if kmap is not None else None,
-           L.ptr(kmap.rows) if kmap is not None else None, n_out, L.ptr(out), act, float(slope), L.stream())
+           L.ptr(kmap.rows) if kmap is not None else None, n_out, L.ptr(out), act, float(slope), L.ptr(ws),
+           ws.numel(), L.stream())
     return out
 
 

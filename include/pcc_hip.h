@@ -156,8 +156,9 @@ int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* 
 /* a5  fused GDN / IGDN (GDN1 form), MinkowskiGDN.forward model/blocks.py:26-57:
  *   norm = beta + |x| @ gamma^T ; out = x / norm (inverse=0) or x * norm (inverse=1)
  * beta_raw/gamma_raw are the raw (un-reparametrised) CompressAI parameters; the
- * NonNegativeParametrizer is applied by pcc_gdn_pack. packed: pcc_conv_packed_elems(1,c,c)
- * floats, beta_eff: c floats. */
+ * NonNegativeParametrizer is applied by pcc_gdn_pack. packed: pcc_gdn_packed_elems(c) floats
+ * (0 = unsupported channel count), beta_eff: c floats. */
+int64_t pcc_gdn_packed_elems(int32_t c);
 int pcc_gdn_pack(const float* beta_raw, const float* gamma_raw, int32_t c, float beta_min,
                  float* packed, float* beta_eff, void* stream);
 int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* packed, const float* beta_eff,

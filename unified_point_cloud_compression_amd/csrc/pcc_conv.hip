@@ -978,6 +978,8 @@ __global__ void k_gdn_pack(const float* __restrict__ beta_raw, const float* __re
   packed[t] = v;
 }
 
+extern "C" int64_t pcc_gdn_packed_elems(int32_t c) { return mfma_ok(c, c) ? (int64_t)c * cout_pad_for(c) : 0; }
+
 extern "C" int pcc_gdn_pack(const float* beta_raw, const float* gamma_raw, int32_t c, float beta_min, float* packed,
                             float* beta_eff, void* stream) {
   hipStream_t s = (hipStream_t)stream;

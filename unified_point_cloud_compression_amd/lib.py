@@ -51,6 +51,7 @@ SIGNATURES = {
     "pcc_convt_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_convt_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "pcc_convt_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _f32, _p]),
+    "pcc_gdn_packed_elems": (_i64, [_i32]),
     "pcc_gdn_pack": (C.c_int, [_p, _p, _i32, _f32, _p, _p, _p]),
     "pcc_gdn_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p]),
     "pcc_topk_ws_bytes": (_sz, [_i64]),

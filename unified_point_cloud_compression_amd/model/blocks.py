@@ -23,7 +23,9 @@ class MinkowskiGDN(GDN):
         if tag != self._tag:
             c = self.in_channels
             dev = self.gamma.device
-            n = L.load().pcc_conv_packed_elems(1, c, c)
+            n = L.load().pcc_gdn_packed_elems(c)
+            if n <= 0:
+                raise L.PccError(f"pcc_gdn: channel count {c} unsupported (needs 4, 8, 16 or a multiple of 32)")
             self._packed = torch.empty(n, dtype=torch.float32, device=dev)
             self._beta_eff = torch.empty(c, dtype=torch.float32, device=dev)
             L.call("pcc_gdn_pack", L.ptr(self.beta.detach().contiguous()), L.ptr(self.gamma.detach().contiguous()), c,

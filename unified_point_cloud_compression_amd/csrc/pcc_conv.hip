@@ -483,11 +483,12 @@ struct Wave16Args {
 };
 
 template <int CIN>
-__global__ void __launch_bounds__(256) k_conv_wave16(Wave16Args a) {
+__global__ void __launch_bounds__(512) k_conv_wave16(Wave16Args a) {
   constexpr int LD = CIN + 4;
   constexpr int G = CIN / 16;
+  constexpr int NW = 8;                                            // waves per workgroup
   extern __shared__ __attribute__((aligned(16))) float wl_s[];   // [K][16][LD]
-  for (int i = threadIdx.x; i < a.K * 16 * (CIN / 4); i += 256) {
+  for (int i = threadIdx.x; i < a.K * 16 * (CIN / 4); i += 512) {
     const int row = i / (CIN / 4), c4 = i - row * (CIN / 4);
     reinterpret_cast<float4*>(wl_s + row * LD)[c4] = reinterpret_cast<const float4*>(a.wl + (long long)row * CIN)[c4];
   }
@@ -500,7 +501,7 @@ __global__ void __launch_bounds__(256) k_conv_wave16(Wave16Args a) {
   else
     for (int s = 0; s < nseg; ++s) total_tiles += (a.hdr[HDR_SEG0 + s * SEG_WORDS + SEG_POS_COUNT] + 31) / 32;
 
-  for (long long wt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wt < total_tiles; wt += (long long)gridDim.x * 4) {
+  for (long long wt = (long long)blockIdx.x * NW + (threadIdx.x >> 6); wt < total_tiles; wt += (long long)gridDim.x * NW) {
     long long pos0, spc;
     int npos, k_count = 1, koff_begin = 0;
     const int* seg_nbr = nullptr;
@@ -530,20 +531,26 @@ __global__ void __launch_bounds__(256) k_conv_wave16(Wave16Args a) {
         if (vB) iB = identity ? (int)(pos0 + 16 + r16) : seg_nbr[(long long)j * spc + 16 + r16];
       }
     };
-    int iA, iB, nA, nB;
-    fetch(0, iA, iB);
-    for (int j = 0; j < k_count; ++j) {
-      fetch(j + 1, nA, nB);                                   // next offset's rows: hides the index-load latency
-      if (__ballot(iA >= 0 || iB >= 0)) {
-        const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + j];
-        float4 xa[G], xb[G];
+    auto gather = [&](int iA, int iB, float4 (&xa)[G], float4 (&xb)[G]) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          xa[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-          xb[g] = xa[g];
-          if (iA >= 0) xa[g] = *reinterpret_cast<const float4*>(a.feat + (long long)iA * CIN + 16 * g + 4 * q);
-          if (iB >= 0) xb[g] = *reinterpret_cast<const float4*>(a.feat + (long long)iB * CIN + 16 * g + 4 * q);
-        }
+      for (int g = 0; g < G; ++g) {
+        xa[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xb[g] = xa[g];
+        if (iA >= 0) xa[g] = *reinterpret_cast<const float4*>(a.feat + (long long)iA * CIN + 16 * g + 4 * q);
+        if (iB >= 0) xb[g] = *reinterpret_cast<const float4*>(a.feat + (long long)iB * CIN + 16 * g + 4 * q);
+      }
+    };
+    // three-stage pipeline per wave: indices of offset j+2, feature rows of offset j+1, MFMAs of offset j
+    int iA0, iB0, iA1, iB1, iA2, iB2;
+    float4 xa[G], xb[G], ya[G], yb[G];
+    fetch(0, iA0, iB0);
+    fetch(1, iA1, iB1);
+    gather(iA0, iB0, xa, xb);
+    for (int j = 0; j < k_count; ++j) {
+      fetch(j + 2, iA2, iB2);
+      gather(iA1, iB1, ya, yb);
+      if (__ballot(iA0 >= 0 || iB0 >= 0)) {
+        const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + j];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const float4 w = *reinterpret_cast<const float4*>(wl_s + (kid * 16 + r16) * LD + 16 * g + 4 * q);
@@ -557,7 +564,9 @@ __global__ void __launch_bounds__(256) k_conv_wave16(Wave16Args a) {
           accB1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[g].w, w.w, accB1, 0, 0, 0);
         }
       }
-      iA = nA; iB = nB;
+#pragma unroll
+      for (int g = 0; g < G; ++g) { xa[g] = ya[g]; xb[g] = yb[g]; }
+      iA0 = iA1; iB0 = iB1; iA1 = iA2; iB1 = iB2;
     }
     // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
     if (r16 < a.cout) {
@@ -732,9 +741,9 @@ static int launch_wave16(const Wave16Args& a, hipStream_t s) {
     attr_set = true;
   }
   const long long tiles = pcc_cdiv(a.n_out, 32) + (a.rows ? PCC_MAP_MAX_SEG : 0);
-  const long long want = pcc_cdiv(tiles, 4);
-  const unsigned grid = (unsigned)(want < 512 ? want : 512);     // persistent: 2 workgroups per CU re-use the LDS weights
-  k_conv_wave16<CIN><<<grid, 256, lds, s>>>(a);
+  const long long want = pcc_cdiv(tiles, 8);
+  const unsigned grid = (unsigned)(want < 512 ? want : 512);     // persistent: 2 workgroups (16 waves) per CU re-use the LDS weights
+  k_conv_wave16<CIN><<<grid, 512, lds, s>>>(a);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

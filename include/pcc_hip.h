@@ -39,7 +39,7 @@ extern "C" {
 #define PCC_ACT_RELU 1    /* ME.MinkowskiReLU      (model/transforms.py:148,153,158)          */
 #define PCC_ACT_LEAKY 2   /* ME.MinkowskiLeakyReLU (model/entropy_models.py:179,181,187,189)  */
 
-#define PCC_MAP_HDR_INTS 256  /* int32 words of a kernel-map header (device resident)        */
+#define PCC_MAP_HDR_INTS 512  /* int32 words of a kernel-map header (device resident)        */
 #define PCC_MAP_MAX_SEG 8
 
 int pcc_version(void);

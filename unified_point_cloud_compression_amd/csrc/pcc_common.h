@@ -45,7 +45,8 @@ static constexpr int SEG_POS_BEGIN = 0, SEG_POS_COUNT = 1, SEG_K_COUNT = 2, SEG_
                      SEG_NBR_LO = 4, SEG_NBR_HI = 5;
 static constexpr int SEG_WORDS = 6;
 static constexpr int HDR_KOFFS = 64;       // int32[K] kernel-offset id of each listed offset
-static_assert(PCC_MAP_HDR_INTS >= HDR_KOFFS + 192, "header too small");
+static constexpr int HDR_ORDER = 256;      // int32[K] per segment: slot visiting order (z innermost, see pcc_map.hip)
+static_assert(PCC_MAP_HDR_INTS >= HDR_ORDER + 192, "header too small");
 
 static inline size_t pcc_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int64_t pcc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

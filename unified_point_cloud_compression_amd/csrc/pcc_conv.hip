@@ -107,8 +107,9 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
     if (w == 0) {
       int n = 0;
       for (int j0 = 0; j0 < k_count; j0 += 64) {
-        const int j = j0 + lane;
-        const bool f = (j < k_count) && act_flag[j];
+        const int u = j0 + lane;                                          // visiting position -> slot
+        const int j = (u < k_count) ? a.hdr[HDR_ORDER + koff_begin + u] : 0;
+        const bool f = (u < k_count) && act_flag[j];
         const unsigned long long m = __ballot(f);
         if (f) {
           const int p = n + __popcll(m & ((1ull << lane) - 1ull));
@@ -524,9 +525,11 @@ __global__ void __launch_bounds__(512) k_conv_wave16(Wave16Args a) {
     }
     const bool vA = r16 < npos, vB = 16 + r16 < npos;
     f32x4 accA0 = {0.f, 0.f, 0.f, 0.f}, accA1 = accA0, accB0 = accA0, accB1 = accA0;
-    auto fetch = [&](int j, int& iA, int& iB) {
+    auto slot_of = [&](int u) { return identity ? 0 : a.hdr[HDR_ORDER + koff_begin + u]; };
+    auto fetch = [&](int u, int& iA, int& iB) {
       iA = -1; iB = -1;
-      if (j < k_count) {
+      if (u < k_count) {
+        const int j = slot_of(u);
         if (vA) iA = identity ? (int)(pos0 + r16) : seg_nbr[(long long)j * spc + r16];
         if (vB) iB = identity ? (int)(pos0 + 16 + r16) : seg_nbr[(long long)j * spc + 16 + r16];
       }
@@ -550,7 +553,7 @@ __global__ void __launch_bounds__(512) k_conv_wave16(Wave16Args a) {
       fetch(j + 2, iA2, iB2);
       gather(iA1, iB1, ya, yb);
       if (__ballot(iA0 >= 0 || iB0 >= 0)) {
-        const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + j];
+        const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + slot_of(j)];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const float4 w = *reinterpret_cast<const float4*>(wl_s + (kid * 16 + r16) * LD + 16 * g + 4 * q);
@@ -725,9 +728,16 @@ static int launch_mfma(const ConvArgs& a, int tiles_bound_extra, hipStream_t s) 
   const int bn = bn_for(a.cout);
   const unsigned gy = (unsigned)(a.cout_pad / bn);
   auto tiles = [&](int bm) { return (unsigned)(pcc_cdiv(a.n_out, bm) + tiles_bound_extra); };
-  if (bn == 128) k_conv_mfma<2, 2, 2, 2, MODE><<<dim3(tiles(128), gy), 256, 0, s>>>(a);
-  else if (bn == 64) k_conv_mfma<2, 2, 2, 1, MODE><<<dim3(tiles(128), gy), 256, 0, s>>>(a);
-  else k_conv_mfma<4, 1, 1, 1, MODE><<<dim3(tiles(128), gy), 256, 0, s>>>(a);
+  // few rows: shrink the row tile until the grid covers the 256 CUs about twice
+  const long long want = 512;
+  if (bn == 128) {
+    if ((long long)tiles(128) * gy >= want) k_conv_mfma<2, 2, 2, 2, MODE><<<dim3(tiles(128), gy), 256, 0, s>>>(a);
+    else if ((long long)tiles(64) * gy >= want) k_conv_mfma<2, 2, 1, 2, MODE><<<dim3(tiles(64), gy), 256, 0, s>>>(a);
+    else k_conv_mfma<1, 4, 1, 1, MODE><<<dim3(tiles(32), gy), 256, 0, s>>>(a);
+  } else if (bn == 64) {
+    if ((long long)tiles(128) * gy >= want) k_conv_mfma<2, 2, 2, 1, MODE><<<dim3(tiles(128), gy), 256, 0, s>>>(a);
+    else k_conv_mfma<2, 2, 1, 1, MODE><<<dim3(tiles(64), gy), 256, 0, s>>>(a);
+  } else k_conv_mfma<4, 1, 1, 1, MODE><<<dim3(tiles(128), gy), 256, 0, s>>>(a);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

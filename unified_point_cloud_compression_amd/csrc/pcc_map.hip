@@ -17,6 +17,7 @@ struct SegPlan {           // host-built, passed by value to k_write_hdr
   int k_count[PCC_MAP_MAX_SEG];
   int koff_begin[PCC_MAP_MAX_SEG];
   unsigned char koffs[192];
+  unsigned char order[192];  // per segment: visiting order of its slots (segment-local slot indices)
 };
 
 // class_begin: nullptr -> single segment covering [0, n_out)
@@ -43,7 +44,31 @@ __global__ void k_write_hdr(SegPlan plan, const int* __restrict__ class_begin, i
     seg[SEG_NBR_HI] = (int)(nbr_begin >> 32);
     nbr_begin += (int64_t)pc * plan.k_count[s];
   }
-  for (int i = 0; i < plan.K && i < 192; ++i) hdr[HDR_KOFFS + i] = plan.listed ? plan.koffs[i] : i;
+  for (int i = 0; i < plan.K && i < 192; ++i) {
+    hdr[HDR_KOFFS + i] = plan.listed ? plan.koffs[i] : i;
+    hdr[HDR_ORDER + i] = plan.order[i];
+  }
+}
+
+// Visiting order of a segment's offsets.  Tried on MI355X (round 1): "(dx,dy) major, dz minor" -- back-to-back
+// visits of the three dz-neighbours, which are the same input rows shifted by one lane -- made the gather-bound
+// kernels 20 % SLOWER (misses on lines still in flight serialise); the natural kernel-offset order stays.
+static constexpr bool ORDER_Z_INNERMOST = false;
+static void plan_order(SegPlan& plan, int ks) {
+  for (int s = 0; s < plan.nseg; ++s) {
+    const int kb = plan.koff_begin[s], kc = plan.k_count[s];
+    int key[192];
+    for (int j = 0; j < kc; ++j) {
+      const int kid = plan.listed ? plan.koffs[kb + j] : (kb + j);
+      key[j] = (kid % (ks * ks)) * ks + kid / (ks * ks);
+      plan.order[kb + j] = (unsigned char)j;
+    }
+    if (!ORDER_Z_INNERMOST) continue;
+    for (int a = 1; a < kc; ++a)            // insertion sort of <= 125 entries
+      for (int b = a; b > 0 && key[plan.order[kb + b]] < key[plan.order[kb + b - 1]]; --b) {
+        const unsigned char t = plan.order[kb + b]; plan.order[kb + b] = plan.order[kb + b - 1]; plan.order[kb + b - 1] = t;
+      }
+  }
 }
 
 // pair counting without global atomics: one partial per block, summed by k_sum_counts
@@ -211,6 +236,7 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
     plan.listed = 0;
     plan.k_count[0] = K;
     plan.koff_begin[0] = 0;
+    plan_order(plan, kernel_size);
     k_write_hdr<<<1, 1, 0, s>>>(plan, nullptr, 0, n_out, hdr);
     PCC_LAUNCH_CHECK();
     if (n_out == 0) return PCC_OK;
@@ -241,6 +267,7 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
     }
     plan.k_count[c] = fill - plan.koff_begin[c];
   }
+  plan_order(plan, kernel_size);
   if (n_out == 0) {
     k_write_hdr<<<1, 1, 0, s>>>(plan, nullptr, 0, 0, hdr);   // all segments empty
     PCC_LAUNCH_CHECK();

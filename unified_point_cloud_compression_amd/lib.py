@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcc_hip.so")
 
-MAP_HDR_INTS = 256
+MAP_HDR_INTS = 512
 MAP_MAX_SEG = 8
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 

@@ -88,6 +88,17 @@ int pcc_coords_expand(const int64_t* keys, int64_t n, int32_t kernel_size, int32
                       uint64_t bit_mask, int64_t* out_keys /*cap n*K*/, int64_t* d_count, void* ws,
                       size_t ws_bytes, void* stream);
 
+/* a3(i)+(ii) fused: generative output set AND its transposed kernel map in CSR form from ONE sort.
+ * Candidates are sorted as 32-bit cell indices of the output lattice h_lattice = {lo_x,lo_y,lo_z, cells_x,cells_y,
+ * cells_z, pitch (= ts_out), batches} (needs <= 2^32 cells) with the pair id i*K+k as payload:
+ *   out_keys[o]                       the output coordinate set (capacity n*K), *d_count rows
+ *   pair_ids[first[o] .. first[o+1])  the (input row, offset) pairs landing on output row o, ascending
+ * pair_ids: n*K ints, first: n*K+1 ints. */
+size_t pcc_expand_csr_ws_bytes(int64_t n, int32_t kernel_size);
+int pcc_coords_expand_csr(const int64_t* keys, int64_t n, int32_t kernel_size, int32_t ts_out,
+                          const int32_t* h_lattice, int64_t* out_keys, int64_t* d_count, int32_t* pair_ids,
+                          int32_t* first, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * a2(ii) / a3  kernel map              (ME kernel map behind every conv forward)
  *
@@ -152,6 +163,12 @@ int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* 
                   const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* hdr,
                   const int32_t* nbr, const int32_t* rows, int64_t n_out, float* T, float* out, int32_t act,
                   float slope, void* stream);
+
+/* same with the CSR pair lists of pcc_coords_expand_csr (row pair_id of T); outputs in canonical row order */
+int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                      const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* first,
+                      const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
+                      void* stream);
 
 /* a5  fused GDN / IGDN (GDN1 form), MinkowskiGDN.forward model/blocks.py:26-57:
  *   norm = beta + |x| @ gamma^T ; out = x / norm (inverse=0) or x * norm (inverse=1)

@@ -92,9 +92,11 @@ def test_stride_matches_oracle(seed, size, p, ts):
         assert np.array_equal(n(cs2.keys)[:cs2.n], co.stride_keys(want, 2 * m))
 
 
+@pytest.mark.parametrize("use_csr", [True, False], ids=["csr", "sort64"])
 @pytest.mark.parametrize("ks,ts_in", [(5, 2), (2, 2), (2, 32), (5, 8), (3, 2)])
-def test_expand_matches_oracle(ks, ts_in):
+def test_expand_matches_oracle(ks, ts_in, use_csr, monkeypatch):
     S, L = _S()
+    monkeypatch.setattr(S, "USE_CSR", use_csr)
     keys = cloud_keys(7, 20, 0.08, ts_in, batch=2)       # includes coordinates at 0 -> negative outputs for k5
     C = co.unpack_keys(keys)
     cs = S.CoordSet(t(keys), len(keys), ts_in, S.Bounds(1, C[:, 1:].min(0), C[:, 1:].max(0)))
@@ -103,3 +105,15 @@ def test_expand_matches_oracle(ks, ts_in):
     assert got.n == len(want)
     assert np.array_equal(n(got.keys)[:got.n], want)
     assert got.ts == ts_in // 2
+    csr = cs.csr_map(ks, ts_in // 2)
+    assert (csr is not None) == use_csr
+    if csr is not None:      # CSR lists == the oracle's transposed map: pair id = in_row * K + k, ascending per output
+        first, pair_ids = n(csr[0]), n(csr[1])
+        nbr = co.kernel_map(keys, want, ks, ts_in // 2, transposed=True)          # [K, n_out]
+        K = ks ** 3
+        assert first[0] == 0 and first[-1] == len(keys) * K and len(first) == len(want) + 1
+        for o in list(range(0, len(want), max(len(want) // 200, 1))) + [len(want) - 1]:
+            lst = pair_ids[first[o]:first[o + 1]]
+            ks_valid = np.nonzero(nbr[:, o] >= 0)[0]
+            want_ids = np.sort(nbr[ks_valid, o].astype(np.int64) * K + ks_valid)
+            assert np.array_equal(lst, want_ids), o

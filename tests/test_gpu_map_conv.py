@@ -113,6 +113,10 @@ def test_generative_transpose_features(cin, cout, ks):
     pairs = codec.kernel_map_pairs(keys, out_keys, ks, 1, transposed=True)
     want = codec.conv_pairs(f, W, b, pairs, len(out_keys))
     assert_close(n(got), want, what="generative transpose (input stationary)")
+    csr = cs.csr_map(ks, 1)
+    assert csr is not None
+    got3 = S.convt_forward_csr(t(f), S.PackedConv(True).get(torch.nn.Parameter(t(W))), t(b), K, cin, cout, csr, out.n)
+    assert_close(n(got3), want, what="generative transpose (CSR pair lists)")
     assert_close(n(got2), want, what="generative transpose (output stationary)")
 
 

@@ -67,6 +67,9 @@ class _ConvBase(nn.Module):
         if torch.is_grad_enabled() and (x.F.requires_grad or self.kernel.requires_grad and self.training):
             raise L.PccError("libpcc_hip convolution has no backward yet: wrap inference in torch.no_grad() / model.eval()")
         packed = self._packed.get(self.kernel)
+        if isinstance(kmap, tuple):          # CSR pair lists from the fused coordinate expansion
+            return S.convt_forward_csr(x._canonical_features(), packed, self.bias, self.kernel_volume,
+                                       self.in_channels, self.out_channels, kmap, out_set.n, act, slope)
         fwd = S.convt_forward if self.TRANSPOSED else S.conv_forward
         return fwd(x._canonical_features(), packed, self.bias, self.kernel_volume, self.in_channels,
                    self.out_channels, kmap, out_set.n, act, slope)
@@ -109,7 +112,8 @@ class MinkowskiGenerativeConvolutionTranspose(_ConvBase):
             raise L.PccError(f"tensor_stride {cs.ts} not divisible by up-sampling stride {self.stride}")
         ts_out = cs.ts // self.stride
         out_set = cs.expand(self.kernel_size, ts_out)
-        kmap = cs.kernel_map(out_set, self.kernel_size, transposed=True, up_stride=self.stride)
+        kmap = cs.csr_map(self.kernel_size, ts_out) or cs.kernel_map(out_set, self.kernel_size, transposed=True,
+                                                                    up_stride=self.stride)
         out = self._apply_conv(input, out_set, kmap)
         return SparseTensor._from_canonical(out_set, out)
 

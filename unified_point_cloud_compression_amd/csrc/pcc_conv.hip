@@ -969,6 +969,85 @@ extern "C" int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, co
   return PCC_OK;
 }
 
+// CSR form of the generative transposed convolution: out[o] = act(bias + sum_{t in [first[o], first[o+1])} T[pair_ids[t]])
+// (pair lists from pcc_coords_expand_csr; outputs are written in canonical row order, no `rows` indirection).
+struct GatherCsrArgs {
+  const float* T; const float* bias; const int* first; const int* pair_ids;
+  float* out; long long n_out; int cout, act; float slope; int lpr_log2;
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
+  typedef typename ThinVec<VEC>::T VT;
+  constexpr int JB = 4;
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << a.lpr_log2;
+  const int rpw = 64 >> a.lpr_log2;
+  const long long o = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> a.lpr_log2);
+  const int cl = lane & (lpr - 1);
+  if (o >= a.n_out) return;
+  const int cvec = a.cout / VEC;
+  const int t0 = a.first[o], t1 = a.first[o + 1];
+  for (int cv = cl; cv < cvec; cv += lpr) {
+    VT acc;
+    thin_zero(acc);
+    for (int t = t0; t < t1; t += JB) {
+      int pid[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) pid[u] = (t + u < t1) ? a.pair_ids[t + u] : -1;
+      VT x[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) {
+        thin_zero(x[u]);
+        if (pid[u] >= 0) x[u] = reinterpret_cast<const VT*>(a.T + (long long)pid[u] * a.cout)[cv];
+      }
+#pragma unroll
+      for (int u = 0; u < JB; ++u) thin_acc(acc, x[u]);     // fixed order: pair id ascending
+    }
+    VT b;
+    thin_zero(b);
+    if (a.bias) b = reinterpret_cast<const VT*>(a.bias)[cv];
+    thin_acc(acc, b);
+    thin_act(acc, a.act, a.slope);
+    reinterpret_cast<VT*>(a.out + o * a.cout)[cv] = acc;
+  }
+}
+
+extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                                 const float* bias, int32_t K, int32_t cout, const int32_t* first,
+                                 const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
+                                 void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out <= 0 || n_in <= 0) return PCC_OK;
+  PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && out, "pcc_convt_fwd_csr: NULL array");
+  PCC_REQUIRE(K >= 1 && K <= MAXK && mfma_ok(cin, K * cout), "pcc_convt_fwd_csr: unsupported shape K=%d cin=%d cout=%d", K, cin, cout);
+  PCC_REQUIRE(act >= 0 && act <= 2, "pcc_convt_fwd_csr: bad activation");
+  PCC_REQUIRE(n_in * K < (1ll << 31) && n_out < (1ll << 31), "pcc_convt_fwd_csr: too many rows");
+  ConvArgs a;
+  a.feat = feat_in; a.wp = packed_w; a.bias = nullptr; a.hdr = nullptr; a.nbr = nullptr; a.rows = nullptr; a.out = T;
+  a.n_out = n_in; a.cin = cin; a.cout = K * cout; a.cout_pad = cout_pad_for(K * cout);
+  a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
+  hipEvent_t e0, e1;
+  if (g_prof_on) PCC_TRY(prof_event(&e0, s));
+  PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));
+  if (g_prof_on) {
+    PCC_TRY(prof_event(&e1, s));
+    ++g_launches;
+  }
+  GatherCsrArgs g;
+  g.T = T; g.bias = bias; g.first = first; g.pair_ids = pair_ids; g.out = out; g.n_out = n_out; g.cout = cout;
+  g.act = act; g.slope = slope;
+  const int vec = (cout % 4 == 0) ? 4 : 1;
+  int l = 0;
+  while ((1 << l) < cout / vec && l < 6) ++l;
+  g.lpr_log2 = l;
+  const int64_t waves = pcc_cdiv(n_out, 64 >> l);
+  if (vec == 4) k_convt_gather_csr<4><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(g);
+  else k_convt_gather_csr<1><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(g);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // GDN
 // ------------------------------------------------------------------------------------------

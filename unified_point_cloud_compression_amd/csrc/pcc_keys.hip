@@ -198,7 +198,8 @@ static constexpr int RS_T = 256;
 static constexpr int RS_I = 8;
 static constexpr int RS_B = RS_T * RS_I;
 
-__global__ void __launch_bounds__(RS_T) k_rs_hist(const uint64_t* __restrict__ keys, int64_t n, int shift,
+template <typename KT>
+__global__ void __launch_bounds__(RS_T) k_rs_hist(const KT* __restrict__ keys, int64_t n, int shift,
                                                   int nblocks, int* __restrict__ hist) {
   __shared__ int h[256];
   h[threadIdx.x] = 0;
@@ -213,11 +214,11 @@ __global__ void __launch_bounds__(RS_T) k_rs_hist(const uint64_t* __restrict__ k
   hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-template <bool PAYLOAD>
-__global__ void __launch_bounds__(RS_T) k_rs_scatter(const uint64_t* __restrict__ keys,
+template <typename KT, bool PAYLOAD>
+__global__ void __launch_bounds__(RS_T) k_rs_scatter(const KT* __restrict__ keys,
                                                      const int* __restrict__ pay_in, int64_t n, int shift,
                                                      int nblocks, const int* __restrict__ offs,
-                                                     uint64_t* __restrict__ keys_out,
+                                                     KT* __restrict__ keys_out,
                                                      int* __restrict__ pay_out) {
   constexpr int NW = RS_T / PCC_WAVE;           // 4 waves
   constexpr int NWR = NW * RS_I;                // 32 wave-rounds, in element order
@@ -229,7 +230,7 @@ __global__ void __launch_bounds__(RS_T) k_rs_scatter(const uint64_t* __restrict_
   __syncthreads();
 
   const int64_t base = (int64_t)blockIdx.x * RS_B;
-  uint64_t key[RS_I];
+  KT key[RS_I];
   int rank[RS_I];
 #pragma unroll
   for (int r = 0; r < RS_I; ++r) {
@@ -319,13 +320,13 @@ extern "C" int pcc_sort_keys(const int64_t* keys_in, int64_t n, uint64_t bit_mas
     const bool to_out = ((np - 1 - i) % 2) == 0;
     uint64_t* dst_k = to_out ? (uint64_t*)keys_out : tmp_k;
     int* dst_p = perm_out ? (to_out ? perm_out : tmp_p) : nullptr;
-    k_rs_hist<<<(unsigned)nb, RS_T, 0, s>>>(src_k, n, shifts[i], (int)nb, hist);
+    k_rs_hist<uint64_t><<<(unsigned)nb, RS_T, 0, s>>>(src_k, n, shifts[i], (int)nb, hist);
     PCC_LAUNCH_CHECK();
     PCC_TRY(pcc_scan_exclusive_i32(hist, hist, nb * 256, scan_ws, scan_bytes, s));
     if (perm_out)
-      k_rs_scatter<true><<<(unsigned)nb, RS_T, 0, s>>>(src_k, src_p, n, shifts[i], (int)nb, hist, dst_k, dst_p);
+      k_rs_scatter<uint64_t, true><<<(unsigned)nb, RS_T, 0, s>>>(src_k, src_p, n, shifts[i], (int)nb, hist, dst_k, dst_p);
     else
-      k_rs_scatter<false><<<(unsigned)nb, RS_T, 0, s>>>(src_k, nullptr, n, shifts[i], (int)nb, hist, dst_k, nullptr);
+      k_rs_scatter<uint64_t, false><<<(unsigned)nb, RS_T, 0, s>>>(src_k, nullptr, n, shifts[i], (int)nb, hist, dst_k, nullptr);
     PCC_LAUNCH_CHECK();
     src_k = dst_k;
     src_p = dst_p;
@@ -485,5 +486,131 @@ extern "C" int pcc_coords_expand(const int64_t* keys, int64_t n, int32_t kernel_
   PCC_LAUNCH_CHECK();
   PCC_TRY(pcc_sort_keys(cand, m, bit_mask, sorted, nullptr, sort_ws, pcc_sort_ws_bytes(m), s));
   PCC_TRY(pcc_unique_sorted(sorted, m, out_keys, nullptr, d_count, uniq_ws, pcc_unique_ws_bytes(m), s));
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Generative expansion fused with its transposed kernel map.
+//   candidate t = i*K + k  ("pair id": input row i, kernel offset k)  ->  32-bit linear cell index of
+//   key[i] + off_k in the OUTPUT lattice (order preserving: ascending cell == ascending canonical key).
+//   One radix sort of (cell, pair id) + adjacent-unique yields the output coordinate set AND, for every output
+//   row o, the contiguous list pair_ids[first[o] .. first[o+1]) of the pairs that land on it -- the whole
+//   transposed map, with no neighbour search at all.  The sort is stable, so each list is ordered by pair id:
+//   a fixed summation order (deterministic).
+// ------------------------------------------------------------------------------------------
+struct Lattice { int lo[3]; int dims[3]; int ts_log2; int nbatch; };
+
+__global__ void k_expand_cells(const int64_t* __restrict__ in, int64_t n, int K, int ks, int step, Lattice L,
+                               unsigned* __restrict__ cells) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * K) return;
+  const int64_t i = t / K;
+  const int k = (int)(t - i * K);
+  const int64_t key = in[i] + pcc_delta_of(k, ks, step);
+  const int b = (int)(key >> 48);
+  const int cx = ((int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - L.lo[0]) >> L.ts_log2;
+  const int cy = ((int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - L.lo[1]) >> L.ts_log2;
+  const int cz = ((int)(key & 0xFFFF) - (int)PCC_BIAS - L.lo[2]) >> L.ts_log2;
+  cells[t] = (unsigned)((((long long)b * L.dims[0] + cx) * L.dims[1] + cy) * L.dims[2] + cz);
+}
+
+__global__ void k_cell_flags(const unsigned* __restrict__ c, int64_t n, int* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || c[i] != c[i - 1]) ? 1 : 0;
+}
+
+__global__ void k_cell_unique(const unsigned* __restrict__ c, int64_t n, const int* __restrict__ pos, Lattice L,
+                              int64_t* __restrict__ out_keys, int* __restrict__ first, int64_t* __restrict__ d_count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool f = (i == 0 || c[i] != c[i - 1]);
+  if (f) {
+    unsigned cell = c[i];
+    const int cz = cell % L.dims[2]; cell /= L.dims[2];
+    const int cy = cell % L.dims[1]; cell /= L.dims[1];
+    const int cx = cell % L.dims[0]; cell /= L.dims[0];
+    const int64_t x = ((int64_t)cx << L.ts_log2) + L.lo[0] + PCC_BIAS;
+    const int64_t y = ((int64_t)cy << L.ts_log2) + L.lo[1] + PCC_BIAS;
+    const int64_t z = ((int64_t)cz << L.ts_log2) + L.lo[2] + PCC_BIAS;
+    out_keys[pos[i]] = ((int64_t)cell << 48) | (x << 32) | (y << 16) | z;
+    first[pos[i]] = (int)i;
+  }
+  if (i == n - 1) {
+    const int64_t cnt = (int64_t)pos[i] + (f ? 1 : 0);
+    *d_count = cnt;
+    first[cnt] = (int)n;     // CSR end sentinel
+  }
+}
+
+extern "C" size_t pcc_expand_csr_ws_bytes(int64_t n, int32_t kernel_size) {
+  if (n <= 0) return 256;
+  const int64_t m = n * kernel_size * kernel_size * kernel_size;
+  const int64_t nb = pcc_cdiv(m, RS_B);
+  return 2 * pcc_align_up((size_t)m * 4) + pcc_align_up((size_t)m * 4) + pcc_align_up((size_t)nb * 256 * 4) +
+         pcc_scan_ws_bytes(nb * 256) + pcc_scan_ws_bytes(m) + 1024;
+}
+
+extern "C" int pcc_coords_expand_csr(const int64_t* keys, int64_t n, int32_t kernel_size, int32_t ts_out,
+                                     const int32_t* h_lattice, int64_t* out_keys, int64_t* d_count,
+                                     int32_t* pair_ids, int32_t* first, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(d_count && h_lattice, "pcc_coords_expand_csr: NULL argument");
+  PCC_REQUIRE(kernel_size >= 1 && kernel_size <= 5 && ts_out >= 1 && (ts_out & (ts_out - 1)) == 0,
+              "pcc_coords_expand_csr: unsupported kernel_size %d / ts_out %d", kernel_size, ts_out);
+  if (n <= 0) {
+    PCC_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int64_t), s));
+    if (first) PCC_CHECK_HIP(hipMemsetAsync(first, 0, sizeof(int32_t), s));
+    return PCC_OK;
+  }
+  PCC_REQUIRE(keys && out_keys && pair_ids && first && ws, "pcc_coords_expand_csr: NULL array");
+  Lattice L;
+  for (int i = 0; i < 3; ++i) { L.lo[i] = h_lattice[i]; L.dims[i] = h_lattice[3 + i]; }
+  PCC_REQUIRE(h_lattice[6] == ts_out, "pcc_coords_expand_csr: lattice pitch must equal ts_out");
+  int l = 0; while ((1 << l) < ts_out) ++l;
+  L.ts_log2 = l; L.nbatch = h_lattice[7];
+  const long long cells = (long long)L.nbatch * L.dims[0] * L.dims[1] * L.dims[2];
+  PCC_REQUIRE(cells > 0 && cells <= 0xFFFFFFFFll, "pcc_coords_expand_csr: lattice has %lld cells (needs <= 2^32; use pcc_coords_expand)", cells);
+  const int K = kernel_size * kernel_size * kernel_size;
+  const int64_t m = n * K;
+  PCC_REQUIRE(m < (1ll << 31), "pcc_coords_expand_csr: too many candidates");
+  if (ws_bytes < pcc_expand_csr_ws_bytes(n, kernel_size)) {
+    pcc_set_error("pcc_coords_expand_csr: workspace too small");
+    return PCC_EWS;
+  }
+  const int64_t nb = pcc_cdiv(m, RS_B);
+  char* p = (char*)ws;
+  unsigned* ka = (unsigned*)p;  p += pcc_align_up((size_t)m * 4);
+  unsigned* kb = (unsigned*)p;  p += pcc_align_up((size_t)m * 4);
+  int* pb = (int*)p;            p += pcc_align_up((size_t)m * 4);     // payload ping-pong partner of pair_ids
+  int* hist = (int*)p;          p += pcc_align_up((size_t)nb * 256 * 4);
+  void* scan_ws = p;
+  const size_t scan_bytes = ws_bytes - (size_t)(p - (char*)ws);
+  k_expand_cells<<<grid1(m), 256, 0, s>>>(keys, n, K, kernel_size, ts_out, L, ka);
+  PCC_LAUNCH_CHECK();
+  int np = 0;
+  while (np < 4 && (cells - 1) >> (8 * np)) ++np;     // 8-bit digits that can differ
+  if (np == 0) np = 1;
+  // payload must end in pair_ids: with np passes the first destination alternates accordingly
+  const unsigned* src_k = ka;
+  const int* src_p = nullptr;
+  for (int i = 0; i < np; ++i) {
+    const bool to_out = ((np - 1 - i) % 2) == 0;
+    unsigned* dst_k = (src_k == ka) ? kb : ka;
+    int* dst_p = to_out ? pair_ids : pb;
+    k_rs_hist<unsigned><<<(unsigned)nb, RS_T, 0, s>>>(src_k, m, 8 * i, (int)nb, hist);
+    PCC_LAUNCH_CHECK();
+    PCC_TRY(pcc_scan_exclusive_i32(hist, hist, nb * 256, scan_ws, scan_bytes, s));
+    k_rs_scatter<unsigned, true><<<(unsigned)nb, RS_T, 0, s>>>(src_k, src_p, m, 8 * i, (int)nb, hist, dst_k, dst_p);
+    PCC_LAUNCH_CHECK();
+    src_k = dst_k;
+    src_p = dst_p;
+  }
+  // unique over the sorted cells; `pos` re-uses the histogram scratch region sized for m ints
+  int* pos = (int*)((src_k == ka) ? kb : ka);          // the idle key buffer holds m ints
+  k_cell_flags<<<grid1(m), 256, 0, s>>>(src_k, m, pos);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(pos, pos, m, scan_ws, scan_bytes, s));
+  k_cell_unique<<<grid1(m), 256, 0, s>>>(src_k, m, pos, L, out_keys, first, d_count);
+  PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

@@ -36,6 +36,8 @@ SIGNATURES = {
     "pcc_coords_stride": (C.c_int, [_p, _i64, _i32, _u64, _p, _p, _p, _sz, _p]),
     "pcc_expand_ws_bytes": (_sz, [_i64, _i32]),
     "pcc_coords_expand": (C.c_int, [_p, _i64, _i32, _i32, _u64, _p, _p, _p, _sz, _p]),
+    "pcc_expand_csr_ws_bytes": (_sz, [_i64, _i32]),
+    "pcc_coords_expand_csr": (C.c_int, [_p, _i64, _i32, _i32, C.POINTER(_i32), _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_map_nbr_elems": (_i64, [_i64, _i32, _i32, _i32]),
     "pcc_map_ws_bytes": (_sz, [_i64]),
     "pcc_kernel_map_build": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p,
@@ -51,6 +53,7 @@ SIGNATURES = {
     "pcc_convt_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_convt_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "pcc_convt_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _f32, _p]),
+    "pcc_convt_fwd_csr": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p]),
     "pcc_gdn_packed_elems": (_i64, [_i32]),
     "pcc_gdn_pack": (C.c_int, [_p, _p, _i32, _f32, _p, _p, _p]),
     "pcc_gdn_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p]),

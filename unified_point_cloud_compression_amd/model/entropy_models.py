@@ -88,7 +88,8 @@ class MeanScaleHyperprior(CompressionModel):
         cs = x._cset
         if isinstance(layer, ME.MinkowskiGenerativeConvolutionTranspose):
             out_set = cs.expand(layer.kernel_size, cs.ts // layer.stride)
-            kmap = cs.kernel_map(out_set, layer.kernel_size, transposed=True, up_stride=layer.stride)
+            kmap = cs.csr_map(layer.kernel_size, cs.ts // layer.stride) or cs.kernel_map(
+                out_set, layer.kernel_size, transposed=True, up_stride=layer.stride)
         else:
             out_set = cs if layer.stride == 1 else cs.stride(cs.ts * layer.stride)
             kmap = cs.kernel_map(out_set, layer.kernel_size)

@@ -61,6 +61,7 @@ class KernelMap:
 
 
 COUNT_PAIRS = False   # bench.py switches this on for its FLOP accounting pass
+USE_CSR = True        # generative expansion also emits the transposed map as CSR pair lists (False: class map + lookup)
 USE_GRID = True       # neighbour lookup through the bitmap+rank grid index (False: binary search; tests run both)
 GRID_MAX_BYTES = 8 << 30
 
@@ -130,12 +131,30 @@ class CoordSet:
         return self._derived[key]
 
     def expand(self, ksize, ts_out):
-        """Output set of a generative transposed conv (a3-i): unique{c + off_k*ts_out}."""
+        """Output set of a generative transposed conv (a3-i): unique{c + off_k*ts_out}.  When the output lattice has
+        at most 2^32 cells the same sort also yields the transposed map in CSR form (`csr_map`)."""
         key = ("expand", ksize, ts_out)
         if key not in self._derived:
             dev = self.device
             K = ksize ** 3
             ob = self.bounds.expanded(ksize, ts_out)
+            dims = [(ob.hi[i] - ob.lo[i]) // ts_out + 1 for i in range(3)]
+            cells = (ob.bmax + 1) * dims[0] * dims[1] * dims[2]
+            if USE_CSR and self.n > 0 and cells <= 0xFFFFFFFF and self.n * K < (1 << 31):
+                h = (C.c_int32 * 8)(ob.lo[0], ob.lo[1], ob.lo[2], dims[0], dims[1], dims[2], ts_out, ob.bmax + 1)
+                m = self.n * K
+                out = torch.empty(m, dtype=torch.int64, device=dev)
+                pair_ids = torch.empty(m, dtype=torch.int32, device=dev)
+                first = torch.empty(m + 1, dtype=torch.int32, device=dev)
+                cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+                ws = L.workspace(L.load().pcc_expand_csr_ws_bytes(self.n, ksize), dev)
+                L.call("pcc_coords_expand_csr", L.ptr(self.keys), self.n, ksize, ts_out, h, L.ptr(out), L.ptr(cnt),
+                       L.ptr(pair_ids), L.ptr(first), L.ptr(ws), ws.numel(), L.stream())
+                n = int(cnt.item())
+                cs = CoordSet(out[:n].clone(), n, ts_out, ob)
+                self._derived[key] = cs
+                self._derived[("csr", ksize, ts_out)] = (first[:n + 1].clone(), pair_ids)
+                return cs
             cap = max(self.n * K, 1)
             out = torch.empty(cap, dtype=torch.int64, device=dev)
             cnt = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -146,6 +165,11 @@ class CoordSet:
             n = int(cnt.item())
             self._derived[key] = CoordSet(out[:n].clone(), n, ts_out, ob)
         return self._derived[key]
+
+    def csr_map(self, ksize, ts_out):
+        """(first, pair_ids) of the transposed map to expand(ksize, ts_out), or None when it was not built."""
+        self.expand(ksize, ts_out)
+        return self._derived.get(("csr", ksize, ts_out))
 
     # ---- kernel maps ---------------------------------------------------------------------------
     def kernel_map(self, out_set, ksize, transposed=False, up_stride=1):
@@ -299,6 +323,21 @@ def convt_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NO
     b = bias.detach().reshape(-1).contiguous() if bias is not None else None
     L.call("pcc_convt_fwd", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(kmap.hdr),
            L.ptr(kmap.nbr), L.ptr(kmap.rows), n_out, L.ptr(T), L.ptr(out), act, float(slope), L.stream())
+    return out
+
+
+def convt_forward_csr(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT_NONE, slope=0.01):
+    """Generative transposed conv (a3) with the CSR pair lists produced by the coordinate expansion."""
+    feats = feats.contiguous()
+    n_in = feats.shape[0]
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    if n_out == 0 or n_in == 0:
+        return out
+    first, pair_ids = csr
+    T = torch.empty(n_in * K * cout, dtype=torch.float32, device=feats.device)
+    b = bias.detach().reshape(-1).contiguous() if bias is not None else None
+    L.call("pcc_convt_fwd_csr", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first),
+           L.ptr(pair_ids), n_out, L.ptr(T), L.ptr(out), act, float(slope), L.stream())
     return out
 
 

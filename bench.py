@@ -58,7 +58,7 @@ def account_flops(model, pc, q):
     """One un-timed step with pair counting on: algorithmic FLOPs (2*P*Cin*Cout) of the MFMA conv launches."""
     from unified_point_cloud_compression_amd import sparse as S
     calls = []
-    orig, orig_t = S.conv_forward, S.convt_forward
+    orig, orig_t, orig_c = S.conv_forward, S.convt_forward, S.convt_forward_csr
 
     def spy(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=0, slope=0.01):
         calls.append((kmap, K, cin, cout, n_out))
@@ -68,17 +68,21 @@ def account_flops(model, pc, q):
         calls.append((kmap, K, cin, cout, n_out))     # pairs = n_in*K: the dense GEMM does exactly the algorithmic FLOPs
         return orig_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act, slope)
 
-    S.COUNT_PAIRS, S.conv_forward, S.convt_forward = True, spy, spy_t
+    def spy_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
+        calls.append((feats.shape[0] * K, K, cin, cout, n_out))        # every (input row, offset) is one pair
+        return orig_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope)
+
+    S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr = True, spy, spy_t, spy_c
     try:
         step(model, pc, q)
         torch.cuda.synchronize()
     finally:
-        S.COUNT_PAIRS, S.conv_forward, S.convt_forward = False, orig, orig_t
+        S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr = False, orig, orig_t, orig_c
     flops, launches, pairs_total = 0.0, 0, 0
     for kmap, K, cin, cout, n_out in calls:
         if not mfma_shape(cin, cout):
             continue
-        p = kmap.pairs() if kmap is not None else n_out
+        p = kmap if isinstance(kmap, int) else (kmap.pairs() if kmap is not None else n_out)
         flops += 2.0 * p * cin * cout
         pairs_total += p
         launches += 1

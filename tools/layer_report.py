@@ -40,13 +40,25 @@ def spy_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=0, slope=0.01):
     return out
 
 
-S.COUNT_PAIRS, S.conv_forward, S.convt_forward = True, spy, spy_t
+orig_c = S.convt_forward_csr
+
+
+def spy_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = orig_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope)
+    e1.record()
+    calls.append((feats.shape[0] * K, -K, cin, cout, feats.shape[0], n_out, e0, e1))
+    return out
+
+
+S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr = True, spy, spy_t, spy_c
 bench.step(model, pc, q)
 torch.cuda.synchronize()
 tot_ms = tot_fl = 0
 print(f"{'K':>4s} {'cin':>4s} {'cout':>4s} {'n_in':>9s} {'n_out':>9s} {'pairs':>10s} {'P/n_out':>7s} {'GF':>8s} {'ms':>8s} {'TF/s':>7s}")
 for kmap, K, cin, cout, n_in, n_out, e0, e1 in calls:
-    p = kmap.pairs() if kmap is not None else n_out
+    p = kmap if isinstance(kmap, int) else (kmap.pairs() if kmap is not None else n_out)
     ms = e0.elapsed_time(e1)
     fl = 2.0 * p * cin * cout
     tot_ms += ms

@@ -525,11 +525,9 @@ __global__ void __launch_bounds__(512) k_conv_wave16(Wave16Args a) {
     }
     const bool vA = r16 < npos, vB = 16 + r16 < npos;
     f32x4 accA0 = {0.f, 0.f, 0.f, 0.f}, accA1 = accA0, accB0 = accA0, accB1 = accA0;
-    auto slot_of = [&](int u) { return identity ? 0 : a.hdr[HDR_ORDER + koff_begin + u]; };
-    auto fetch = [&](int u, int& iA, int& iB) {
+    auto fetch = [&](int j, int& iA, int& iB) {     // natural slot order: no dependent table read ahead of the index load
       iA = -1; iB = -1;
-      if (u < k_count) {
-        const int j = slot_of(u);
+      if (j < k_count) {
         if (vA) iA = identity ? (int)(pos0 + r16) : seg_nbr[(long long)j * spc + r16];
         if (vB) iB = identity ? (int)(pos0 + 16 + r16) : seg_nbr[(long long)j * spc + 16 + r16];
       }
@@ -553,7 +551,7 @@ __global__ void __launch_bounds__(512) k_conv_wave16(Wave16Args a) {
       fetch(j + 2, iA2, iB2);
       gather(iA1, iB1, ya, yb);
       if (__ballot(iA0 >= 0 || iB0 >= 0)) {
-        const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + slot_of(j)];
+        const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + j];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const float4 w = *reinterpret_cast<const float4*>(wl_s + (kid * 16 + r16) * LD + 16 * g + 4 * q);

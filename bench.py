@@ -30,11 +30,14 @@ R2_CONFIG = {
 }
 
 
-def build_model(device, seed=0, gain=3.0):
+def build_model(device, seed=0, gain=3.0, coder="pcc_streams"):
+    import copy
     from unified_point_cloud_compression_amd.model import UnifiedModel
     from unified_point_cloud_compression_amd.MinkowskiEngine.modules import _ConvBase
     torch.manual_seed(seed)
-    model = UnifiedModel(R2_CONFIG)
+    cfg = copy.deepcopy(R2_CONFIG)
+    cfg["entropy_model"]["entropy_coder"] = coder
+    model = UnifiedModel(cfg)
     with torch.no_grad():   # no trained weights ship (README.md:122): seeded random init, scaled so latents are not all zero
         for m in model.modules():
             if isinstance(m, _ConvBase):
@@ -115,6 +118,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bits", type=int, default=BITS)
+    ap.add_argument("--coder", default="pcc_streams", choices=["pcc_streams", "ans", "symbols"],
+                    help="entropy coder inside the timed region (default: per-channel GPU rANS)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,7 +135,7 @@ def main():
     from unified_point_cloud_compression_amd import lib, synth, frames
     lib.load()
     cu, arch = lib.device_info()
-    model = build_model(device)
+    model = build_model(device, coder=args.coder)
     pc_np = synth.surface_cloud(seed=rank, bits=args.bits)
     pc = torch.from_numpy(pc_np).to(device)
     q = torch.tensor([[0.5, 0.5]], device=device)
@@ -173,6 +178,10 @@ def main():
                                  device)
     total_points = sum(r[1] for r in recs)
 
+    def count_bits(strings):   # `utils.count_bits` (utils.py:30-48)
+        return sum(count_bits(x) if isinstance(x, list) else len(x) * 8 for x in strings)
+    bpp = (count_bits(out[0]) / n_points) if args.coder != "symbols" else None
+
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
         # conv launches: only MFMA-shaped ones are event-timed inside the library
@@ -187,7 +196,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: one synthetic longdress-like vox{args.bits} frame per GPU "
                                    f"({n_points} points on rank 0), R2 architecture, random-init weights, q=[[0.5,0.5]], "
-                                   f"1 block; entropy-coder boundary carries integer symbols (rANS = SURVEY 8f next)",
+                                   f"1 block; entropy coder in the timed region: {args.coder}",
+                       "bpp_y_z_strings": bpp,
                        "frames_per_step": world, "encode_ms": recs[0][2] * 1e3, "decode_ms": recs[0][3] * 1e3,
                        "device": arch, "cus": cu},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

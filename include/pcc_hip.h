@@ -230,6 +230,38 @@ int pcc_eb_encode(const float* z, int64_t n, int32_t c, const float* eb_packed, 
                   int32_t* sym, float* z_hat, float* lik, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 8f-1  rANS entropy coder + CDF tables  (CompressAI `_CXX`: `pmf_to_quantized_cdf`, `BufferedRansEncoder`,
+ *       `RansDecoder`; reference call sites model/entropy_models.py:371-372,397-400,438,471,484, model/model.py:30-34)
+ * rans64 scheme: 64-bit state, 32-bit words, 16-bit probabilities, 4-bit bypass digits outside a table.
+ * Tables: cdf [rows, cdf_stride] int32, sizes[rows] (= pmf length + 2), offsets[rows]; a symbol with table row r is
+ * coded as value = symbol - offsets[r] in [0, sizes[r]-2), anything else through the bypass sentinel.
+ * ---------------------------------------------------------------------------------------- */
+int pcc_pmf_to_quantized_cdf(const float* h_pmf, int32_t n, int32_t precision, int32_t* h_cdf /*[n+1]*/);
+/* single stream on HOST buffers: the byte layout of BufferedRansEncoder.flush() */
+int64_t pcc_rans_max_bytes(int64_t n);
+int pcc_rans_encode_host(const int32_t* h_sym, const int32_t* h_idx, int64_t n, const int32_t* h_cdf,
+                         int32_t cdf_stride, const int32_t* h_sizes, const int32_t* h_offsets, uint8_t* h_out,
+                         int64_t cap, int64_t* h_nbytes);
+int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const int32_t* h_idx, int64_t n,
+                         const int32_t* h_cdf, int32_t cdf_stride, const int32_t* h_sizes, const int32_t* h_offsets,
+                         int32_t* h_sym);
+/* GPU, one stream per channel: stream s codes sym[s*stream_stride + i*elem_stride], i < n, with table row
+ * idx[same index] (idx NULL: row s, the factorised prior).  Container (device buffer `out`, capacity
+ * pcc_rans_container_max_bytes): u32 n_streams | u32 nwords[n_streams] | stream words ...  *d_nbytes: its size.
+ * The reference's [1,C,N] channel-major symbol order is exactly the concatenation of these C streams. */
+int64_t pcc_rans_container_max_bytes(int64_t n, int32_t n_streams);
+size_t pcc_rans_streams_ws_bytes(int64_t n, int32_t n_streams);
+int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t n_streams,
+                            int64_t elem_stride, int64_t stream_stride, const int32_t* cdf, int32_t cdf_stride,
+                            const int32_t* sizes, const int32_t* offsets, uint8_t* out, int64_t* d_nbytes, void* ws,
+                            size_t ws_bytes, void* stream);
+/* *d_status != 0 after the kernel: malformed container */
+int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n, int32_t n_streams,
+                            int64_t elem_stride, int64_t stream_stride, const int32_t* cdf, int32_t cdf_stride,
+                            const int32_t* sizes, const int32_t* offsets, int32_t* sym_out, int32_t* d_status,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * measurement support: per-launch HIP-event timing of the conv kernel (bench.py roofline)
  * ---------------------------------------------------------------------------------------- */
 int pcc_prof_enable(int32_t on);

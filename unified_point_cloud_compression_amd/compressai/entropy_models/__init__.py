@@ -5,6 +5,7 @@ Tensor layout at this surface is CompressAI's [B, C, N]; the HIP kernels work on
 (the layout the sparse convolutions produce), so the [N, C] entry points `*_rows` are what the
 build's own model uses and the [B, C, N] methods transpose around them.
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -32,9 +33,32 @@ def _rows(x):
     return perm.reshape(B * n, Cc), back
 
 
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pmf_to_quantized_cdf(pmf, precision=16):
+    """CompressAI `pmf_to_quantized_cdf` (C++ op) -> libpcc_hip host function."""
+    pmf = np.ascontiguousarray(np.asarray(pmf, dtype=np.float32))
+    out = np.zeros(len(pmf) + 1, dtype=np.int32)
+    L.check(L.load().pcc_pmf_to_quantized_cdf(_np_ptr(pmf), len(pmf), precision, _np_ptr(out)), "pcc_pmf_to_quantized_cdf")
+    return out
+
+
 class EntropyModel(nn.Module):
+    """Table container + entropy coding entry points.
+
+    `entropy_coder`:
+      "pcc_streams" (default)  GPU rANS, one stream per channel behind a length table (`pcc_rans_*_streams`)
+      "ans"                    single stream on the host in CompressAI's `BufferedRansEncoder` byte layout
+    Both use the same tables and the same rans64 arithmetic; only the container differs.
+    """
+
     def __init__(self, likelihood_bound=1e-9, entropy_coder=None, entropy_coder_precision=16):
         super().__init__()
+        self.entropy_coder = entropy_coder or "pcc_streams"
+        if self.entropy_coder not in ("pcc_streams", "ans"):
+            raise L.PccError(f"unknown entropy coder {self.entropy_coder!r}")
         self.entropy_coder_precision = int(entropy_coder_precision)
         self.use_likelihood_bound = likelihood_bound > 0
         if self.use_likelihood_bound:
@@ -43,16 +67,108 @@ class EntropyModel(nn.Module):
         self.register_buffer("_quantized_cdf", torch.IntTensor())
         self.register_buffer("_cdf_length", torch.IntTensor())
 
-    @staticmethod
-    def _no_coder():
-        raise L.PccError("rANS byte coding is SURVEY 8f row 1 (next): this round hands integer symbols across the "
-                         "entropy-coder boundary (`*_rows` APIs); compress()/decompress() to byte strings are not built")
+    # ---- tables -----------------------------------------------------------------------------------------
+    def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
+        """CompressAI `EntropyModel._pmf_to_cdf`: per row quantise [pmf[:length], tail] to 16-bit frequencies."""
+        pmf, tail = pmf.detach().cpu().float().numpy(), tail_mass.detach().cpu().float().numpy().reshape(len(pmf), -1)
+        length = pmf_length.detach().cpu().numpy()
+        cdf = np.zeros((len(length), int(max_length) + 2), dtype=np.int32)
+        for i in range(len(length)):
+            c = pmf_to_quantized_cdf(np.concatenate([pmf[i, :length[i]], tail[i, :1]]), self.entropy_coder_precision)
+            cdf[i, :len(c)] = c
+        return torch.from_numpy(cdf)
 
-    def compress(self, *a, **k):
-        self._no_coder()
+    def _check_tables(self):
+        if self._quantized_cdf.numel() == 0 or self._cdf_length.numel() == 0 or self._offset.numel() == 0:
+            raise L.PccError("entropy tables are empty: call model.update() first (`evaluate.py:89`)")
 
-    def decompress(self, *a, **k):
-        self._no_coder()
+    # ---- coding of [N, C] int32 symbol rows (the layout the kernels produce) -------------------------------
+    def compress_rows(self, sym, idx=None):
+        """sym [N,C] int32 (device) with table rows idx [N,C] (None: row = channel) -> bytes."""
+        self._check_tables()
+        sym = sym.contiguous()
+        n, c = sym.shape
+        dev = sym.device
+        cdf, sizes, offs = (t.to(dev).contiguous() for t in (self._quantized_cdf, self._cdf_length, self._offset))
+        if self.entropy_coder == "ans":
+            s = sym.t().contiguous().cpu().numpy().reshape(-1)                      # channel-major, as [1,C,N].reshape(-1)
+            i = (idx.t().contiguous().cpu().numpy().reshape(-1) if idx is not None
+                 else np.repeat(np.arange(c, dtype=np.int32), n))
+            return self._host_encode(s, np.ascontiguousarray(i, np.int32))
+        lib = L.load()
+        cap = lib.pcc_rans_container_max_bytes(n, c)
+        out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        nb = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = L.workspace(lib.pcc_rans_streams_ws_bytes(n, c), dev)
+        L.call("pcc_rans_encode_streams", L.ptr(sym), L.ptr(idx.contiguous()) if idx is not None else None, n, c, c, 1,
+               L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(out), L.ptr(nb), L.ptr(ws), ws.numel(),
+               L.stream())
+        return out[:int(nb.item())].cpu().numpy().tobytes()
+
+    def decompress_rows(self, data, n, c, idx=None, device=None):
+        """bytes -> sym [N,C] int32 on `device`."""
+        self._check_tables()
+        dev = torch.device(device) if device is not None else (idx.device if idx is not None else self._quantized_cdf.device)
+        cdf, sizes, offs = (t.to(dev).contiguous() for t in (self._quantized_cdf, self._cdf_length, self._offset))
+        if self.entropy_coder == "ans":
+            i = (idx.t().contiguous().cpu().numpy().reshape(-1) if idx is not None
+                 else np.repeat(np.arange(c, dtype=np.int32), n))
+            s = self._host_decode(data, np.ascontiguousarray(i, np.int32))
+            return torch.from_numpy(s.reshape(c, n).T.copy()).to(dev)
+        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        sym = torch.empty((n, c), dtype=torch.int32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.call("pcc_rans_decode_streams", L.ptr(buf), buf.numel(), L.ptr(idx.contiguous()) if idx is not None else None,
+               n, c, c, 1, L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(sym), L.ptr(status), L.stream())
+        st = int(status.item())
+        if st != 0:
+            raise L.PccError(f"malformed rANS container (status {st})")
+        return sym
+
+    def _host_tables(self):
+        return tuple(np.ascontiguousarray(t.detach().cpu().numpy().astype(np.int32))
+                     for t in (self._quantized_cdf, self._cdf_length, self._offset))
+
+    def _host_encode(self, sym, idx):
+        cdf, sizes, offs = self._host_tables()
+        lib = L.load()
+        sym = np.ascontiguousarray(sym, np.int32)
+        cap = lib.pcc_rans_max_bytes(len(sym))
+        out = np.zeros(cap, np.uint8)
+        nb = C.c_int64(0)
+        L.check(lib.pcc_rans_encode_host(_np_ptr(sym), _np_ptr(idx), len(sym), _np_ptr(cdf), cdf.shape[1], _np_ptr(sizes),
+                                         _np_ptr(offs), _np_ptr(out), cap, C.byref(nb)), "pcc_rans_encode_host")
+        return out[:nb.value].tobytes()
+
+    def _host_decode(self, data, idx):
+        cdf, sizes, offs = self._host_tables()
+        buf = np.frombuffer(data, np.uint8).copy()
+        out = np.zeros(len(idx), np.int32)
+        L.check(L.load().pcc_rans_decode_host(_np_ptr(buf), len(buf), _np_ptr(idx), len(idx), _np_ptr(cdf), cdf.shape[1],
+                                              _np_ptr(sizes), _np_ptr(offs), _np_ptr(out)), "pcc_rans_decode_host")
+        return out
+
+    # ---- CompressAI surface: [B, C, N] tensors, one string per batch element ----------------------------------
+    def compress(self, inputs, indexes, means=None):
+        """`EntropyModel.compress` (`model/entropy_models.py:397-400`): symbols = round(inputs - means), one string
+        per batch element over the channel-major flattening."""
+        sym = torch.round(inputs - means if means is not None else inputs).to(torch.int32)
+        out = []
+        for b in range(sym.shape[0]):
+            s = sym[b].reshape(sym.shape[1], -1).t().contiguous()               # [N, C]
+            i = indexes[b].reshape(sym.shape[1], -1).t().contiguous().to(torch.int32)
+            out.append(self.compress_rows(s, i))
+        return out
+
+    def decompress(self, strings, indexes, dtype=torch.float, means=None):
+        """`EntropyModel.decompress` (`model/entropy_models.py:471,484`)."""
+        outs = []
+        for b, data in enumerate(strings):
+            i = indexes[b].reshape(indexes.shape[1], -1).t().contiguous().to(torch.int32)
+            s = self.decompress_rows(data, i.shape[0], i.shape[1], i)
+            outs.append(s.t().reshape(indexes.shape[1:]))
+        out = torch.stack(outs, dim=0).to(dtype)
+        return out + means if means is not None else out
 
 
 class EntropyBottleneck(EntropyModel):
@@ -106,16 +222,37 @@ class EntropyBottleneck(EntropyModel):
         logits = self._logits_cumulative(self.quantiles, stop_gradient=True)
         return torch.abs(logits - self.target).sum()
 
+    @torch.no_grad()
     def update(self, force=False):
-        """Offsets / lengths of the per-channel tables; the quantised CDFs themselves belong to the rANS
-        stage (8f row 1) and are built there."""
+        """`EntropyBottleneck.update` (CompressAI): per channel the pmf over [median - minima, median + maxima] and its
+        quantised CDF (`model/model.py:30-34` calls this through `CompressionModel.update`).  Evaluated on the host
+        once per parameter update."""
         if self._offset.numel() > 0 and not force:
             return False
-        med = self.quantiles[:, 0, 1]
-        minima = torch.ceil(med - self.quantiles[:, 0, 0]).int().clamp(min=0)
-        maxima = torch.ceil(self.quantiles[:, 0, 2] - med).int().clamp(min=0)
-        self._offset = -minima
-        self._cdf_length = (maxima + minima + 1 + 2).int()
+        dev = self.quantiles.device
+        cpu = {k: v.detach().cpu().float() for k, v in self.named_parameters()}
+        q = cpu["quantiles"]
+        med = q[:, 0, 1]
+        minima = torch.ceil(med - q[:, 0, 0]).int().clamp(min=0)
+        maxima = torch.ceil(q[:, 0, 2] - med).int().clamp(min=0)
+        pmf_start = med - minima
+        pmf_length = maxima + minima + 1
+        max_length = int(pmf_length.max().item())
+        samples = (torch.arange(max_length)[None, :] + pmf_start[:, None])[:, None, :]
+
+        def logits(x):
+            for i in range(len(self.filters) + 1):
+                x = torch.matmul(torch.nn.functional.softplus(cpu[f"_matrix{i}"]), x) + cpu[f"_bias{i}"]
+                if i < len(self.filters):
+                    x = x + torch.tanh(cpu[f"_factor{i}"]) * torch.tanh(x)
+            return x
+        lower, upper = logits(samples - 0.5), logits(samples + 0.5)
+        sign = -torch.sign(lower + upper)
+        pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+        tail = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail, pmf_length, max_length).to(dev)
+        self._offset = (-minima).int().to(dev)
+        self._cdf_length = (pmf_length + 2).int().to(dev)
         return True
 
     def packed(self):
@@ -148,6 +285,22 @@ class EntropyBottleneck(EntropyModel):
                L.stream())
         return sym, zh, lik
 
+    def compress(self, x):
+        """`EntropyBottleneck.compress` (`model/entropy_models.py:371`): x [B,C,N] -> one string per batch element."""
+        out = []
+        for b in range(x.shape[0]):
+            sym, _, _ = self.encode_rows(x[b].reshape(x.shape[1], -1).t().contiguous(), want_likelihood=False)
+            out.append(self.compress_rows(sym))
+        return out
+
+    def decompress(self, strings, size):
+        """`EntropyBottleneck.decompress` (`model/entropy_models.py:372,438`): -> [B, C, *size] float."""
+        n = int(np.prod(size))
+        med = self.quantiles[:, 0, 1].detach().to(torch.float32)
+        outs = [self.decompress_rows(s, n, self.channels, device=med.device).to(torch.float32) + med[None, :]
+                for s in strings]
+        return torch.stack([o.t().reshape(self.channels, *size) for o in outs], dim=0)
+
     def forward(self, x, training=None):
         training = self.training if training is None else training
         if training:
@@ -177,27 +330,53 @@ class GaussianConditional(EntropyModel):
         self.update()
         return True
 
+    @staticmethod
+    def _standardized_cumulative(x):
+        return 0.5 * torch.erfc(-(2 ** -0.5) * x)
+
+    @torch.no_grad()
     def update(self):
-        """pmf support of each scale (offset / length); quantised CDFs belong to the rANS stage (8f row 1)."""
+        """`GaussianConditional.update` (CompressAI): per table scale the pmf over [-c, c], c = ceil(scale * 6.11), and
+        its quantised CDF with the tail mass as bypass sentinel."""
         from scipy.stats import norm
+        dev = self.scale_table.device
+        st = self.scale_table.detach().cpu().float()
         multiplier = -norm.ppf(self.tail_mass / 2)
-        pmf_center = torch.ceil(self.scale_table.cpu() * multiplier).int()
-        self._offset = (-pmf_center).to(self.scale_table.device)
-        self._cdf_length = (2 * pmf_center + 1 + 2).to(self.scale_table.device)
+        pmf_center = torch.ceil(st * multiplier).int()
+        pmf_length = 2 * pmf_center + 1
+        max_length = int(pmf_length.max().item())
+        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+        scale = st[:, None]
+        upper = self._standardized_cumulative((0.5 - samples) / scale)
+        lower = self._standardized_cumulative((-0.5 - samples) / scale)
+        pmf = upper - lower
+        tail = 2 * lower[:, :1]
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail, pmf_length, max_length).to(dev)
+        self._offset = (-pmf_center).int().to(dev)
+        self._cdf_length = (pmf_length + 2).int().to(dev)
 
     def _table(self, device):
         if self.scale_table.numel() == 0:
             raise L.PccError("GaussianConditional has no scale table: call model.update() first (`evaluate.py:89`)")
         return self.scale_table.to(device=device, dtype=torch.float32).contiguous()
 
+    def index_rows(self, params, keys=None, gain=None):
+        """Table rows of every element from (scales_hat | means_hat) alone: what the decoder needs before the symbols
+        exist (`model/entropy_models.py:468`)."""
+        return self.encode_rows(None, params, keys, gain, want_likelihood=False, want_symbols=False)[1]
+
     def encode_rows(self, y, params, keys=None, gain=None, want_likelihood=True, want_symbols=True):
         """Fused a7 kernel on [N,C] rows; params [N,2C] = (scales_hat | means_hat)."""
-        y, params = y.contiguous(), params.contiguous()
-        n, c = y.shape
-        tab = self._table(y.device)
-        sym = torch.empty((n, c), dtype=torch.int32, device=y.device) if want_symbols else None
-        idx = torch.empty((n, c), dtype=torch.int32, device=y.device)
-        lik = torch.empty_like(y) if want_likelihood else None
+        params = params.contiguous()
+        n, c = params.shape[0], params.shape[1] // 2
+        if y is None:
+            assert not want_likelihood and not want_symbols
+        else:
+            y = y.contiguous()
+        tab = self._table(params.device)
+        sym = torch.empty((n, c), dtype=torch.int32, device=params.device) if want_symbols else None
+        idx = torch.empty((n, c), dtype=torch.int32, device=params.device)
+        lik = torch.empty((n, c), dtype=torch.float32, device=params.device) if want_likelihood else None
         g = gain.contiguous() if gain is not None else None
         L.call("pcc_gauss_encode", L.ptr(y), L.ptr(params), L.ptr(keys), L.ptr(g), n, c, L.ptr(tab), tab.numel(),
                L.ptr(sym), L.ptr(idx), L.ptr(lik), L.stream())

@@ -37,6 +37,7 @@ __global__ void __launch_bounds__(256) k_gauss(const float* __restrict__ y, cons
   const float s = fmaxf(scale * g, SCALE_BOUND);
   if (idx) idx[t] = table_index(s, tab, nt);
   if (ENCODE) {
+    if (!sym && !lik) return;                       // index-only call (decoder side, before the symbols exist)
     const float q = rintf(y[t] * g - mean * g);
     if (sym) sym[t] = (int)q;
     if (lik) {
@@ -54,7 +55,8 @@ extern "C" int pcc_gauss_encode(const float* y, const float* params, const int64
                                 int64_t n, int32_t c, const float* table, int32_t n_table, int32_t* sym, int32_t* idx,
                                 float* lik, void* stream) {
   if (n <= 0) return PCC_OK;
-  PCC_REQUIRE(y && params && table && c >= 1 && n_table >= 2 && n_table <= 256, "pcc_gauss_encode: bad arguments");
+  PCC_REQUIRE(params && table && c >= 1 && n_table >= 2 && n_table <= 256, "pcc_gauss_encode: bad arguments");
+  PCC_REQUIRE(y || (!sym && !lik), "pcc_gauss_encode: y is NULL (allowed only for an index-only call)");
   PCC_REQUIRE(!gain || keys, "pcc_gauss_encode: gain needs keys");
   k_gauss<true><<<(unsigned)pcc_cdiv(n * c, 256), 256, 0, (hipStream_t)stream>>>(y, nullptr, params, keys, gain, n, c,
                                                                                  table, n_table, sym, idx, lik, nullptr);

@@ -1,0 +1,263 @@
+// rANS entropy coder: the coder CompressAI's `_CXX` extension provides to the reference at
+// model/entropy_models.py:371-372,397-400,438,471,484 -- 64-bit state, 32-bit renormalisation words, 16-bit
+// probabilities, 4-bit bypass digits for values outside a table (ryg_rans rans64 scheme).
+//
+// One implementation, two drivers:
+//   * host, single stream: byte layout of `BufferedRansEncoder.flush()` / `RansDecoder.decode_with_indexes`;
+//   * GPU, one stream per channel (lane = channel): the reference codes [1, C, N] tensors channel-major, so its
+//     symbol order splits into C independent sub-sequences; each lane codes one of them, reads are coalesced across
+//     lanes, and the streams are packed behind a small length table.  1.9 M sequential symbols become 128 x 14.8 k.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "pcc_common.h"
+
+#define RANS_HD __host__ __device__ inline
+
+static constexpr int R_PREC = 16;
+static constexpr int R_BYP = 4;
+static constexpr int R_MAXB = (1 << R_BYP) - 1;
+static constexpr unsigned long long R_L = 1ull << 31;
+
+struct RansTab { const int* cdf; int stride; const int* sizes; const int* offsets; };
+
+RANS_HD void r_put(unsigned long long& x, unsigned*& ptr, unsigned start, unsigned freq) {
+  const unsigned long long x_max = ((R_L >> R_PREC) << 32) * freq;
+  if (x >= x_max) { *--ptr = (unsigned)x; x >>= 32; }
+  x = ((x / freq) << R_PREC) + (x % freq) + start;
+}
+RANS_HD void r_put_bits(unsigned long long& x, unsigned*& ptr, unsigned val) {
+  const unsigned long long x_max = ((R_L >> 16) << 32) * (1u << (16 - R_BYP));
+  if (x >= x_max) { *--ptr = (unsigned)x; x >>= 32; }
+  x = (x << R_BYP) | val;
+}
+
+// encodes n symbols (read with stride) in reverse; words are written backwards from `end`; returns the first word
+RANS_HD unsigned* r_encode(const int* sym, const int* idx, int fixed_idx, long long n, long long stride, RansTab t,
+                           unsigned* end) {
+  unsigned long long x = R_L;
+  unsigned* ptr = end;
+  for (long long i = n - 1; i >= 0; --i) {
+    const int ci = idx ? idx[i * stride] : fixed_idx;
+    const int* c = t.cdf + (long long)ci * t.stride;
+    const int max_value = t.sizes[ci] - 2;
+    int value = sym[i * stride] - t.offsets[ci];
+    unsigned raw = 0;
+    bool bypass = false;
+    if (value < 0) { raw = (unsigned)(-2 * value - 1); value = max_value; bypass = true; }
+    else if (value >= max_value) { raw = (unsigned)(2 * (value - max_value)); value = max_value; bypass = true; }
+    if (bypass) {   // reverse of: main, count digits (15, 15, ..., rest), raw digits j = 0..nb-1
+      int nb = 0;
+      while (nb < 8 && (raw >> (nb * R_BYP)) != 0) ++nb;
+      for (int j = nb - 1; j >= 0; --j) r_put_bits(x, ptr, (raw >> (j * R_BYP)) & R_MAXB);
+      int val = nb, n15 = 0;
+      while (val >= R_MAXB) { val -= R_MAXB; ++n15; }
+      r_put_bits(x, ptr, (unsigned)val);
+      for (int j = 0; j < n15; ++j) r_put_bits(x, ptr, R_MAXB);
+    }
+    r_put(x, ptr, (unsigned)c[value], (unsigned)(c[value + 1] - c[value]));
+  }
+  ptr -= 2;
+  ptr[0] = (unsigned)x;
+  ptr[1] = (unsigned)(x >> 32);
+  return ptr;
+}
+
+RANS_HD unsigned r_get_bits(unsigned long long& x, const unsigned*& ptr) {
+  const unsigned v = (unsigned)(x & R_MAXB);
+  x >>= R_BYP;
+  if (x < R_L) x = (x << 32) | *ptr++;
+  return v;
+}
+
+// decodes n symbols forward; returns the pointer past the last word consumed
+RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int fixed_idx, long long n, long long stride,
+                                 RansTab t, int* out) {
+  unsigned long long x = (unsigned long long)ptr[0] | ((unsigned long long)ptr[1] << 32);
+  ptr += 2;
+  for (long long i = 0; i < n; ++i) {
+    const int ci = idx ? idx[i * stride] : fixed_idx;
+    const int* c = t.cdf + (long long)ci * t.stride;
+    const int size = t.sizes[ci];
+    const int max_value = size - 2;
+    const unsigned cum = (unsigned)(x & ((1u << R_PREC) - 1));
+    int lo = 0, hi = size - 1;                      // last s with c[s] <= cum  (c[0] = 0, c[size-1] = 2^16 > cum)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((unsigned)c[mid] <= cum) lo = mid; else hi = mid; }
+    const unsigned start = (unsigned)c[lo], freq = (unsigned)(c[lo + 1] - c[lo]);
+    x = (unsigned long long)freq * (x >> R_PREC) + cum - start;
+    if (x < R_L) x = (x << 32) | *ptr++;
+    int value = lo;
+    if (value == max_value) {
+      unsigned val = r_get_bits(x, ptr);
+      int nb = (int)val;
+      while (val == R_MAXB) { val = r_get_bits(x, ptr); nb += (int)val; }
+      unsigned raw = 0;
+      for (int j = 0; j < nb; ++j) raw |= r_get_bits(x, ptr) << (j * R_BYP);
+      value = (int)(raw >> 1);
+      value = (raw & 1) ? -value - 1 : value + max_value;
+    }
+    out[i * stride] = value + t.offsets[ci];
+  }
+  return ptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// host: CDF quantisation + single-stream coder
+// ------------------------------------------------------------------------------------------
+extern "C" int pcc_pmf_to_quantized_cdf(const float* h_pmf, int32_t n, int32_t precision, int32_t* h_cdf) {
+  PCC_REQUIRE(h_pmf && h_cdf && n >= 1 && precision >= 1 && precision <= 16, "pcc_pmf_to_quantized_cdf: bad arguments");
+  std::vector<uint32_t> cdf((size_t)n + 1);
+  cdf[0] = 0;
+  for (int i = 0; i < n; ++i) cdf[i + 1] = (uint32_t)roundf(h_pmf[i] * (float)(1 << precision));
+  uint32_t total = 0;
+  for (auto v : cdf) total += v;
+  PCC_REQUIRE(total != 0, "pcc_pmf_to_quantized_cdf: pmf sums to zero");
+  for (auto& v : cdf) v = (uint32_t)((((uint64_t)1 << precision) * v) / total);
+  for (size_t i = 1; i < cdf.size(); ++i) cdf[i] += cdf[i - 1];
+  cdf.back() = 1u << precision;
+  for (int i = 0; i < (int)cdf.size() - 1; ++i) {
+    if (cdf[i] == cdf[i + 1]) {
+      uint32_t best_freq = ~0u;
+      int best = -1;
+      for (int j = 0; j < (int)cdf.size() - 1; ++j) {
+        const uint32_t f = cdf[j + 1] - cdf[j];
+        if (f > 1 && f < best_freq) { best_freq = f; best = j; }
+      }
+      PCC_REQUIRE(best != -1, "pcc_pmf_to_quantized_cdf: cannot give every symbol a non-zero frequency");
+      if (best < i) for (int j = best + 1; j <= i; ++j) cdf[j]--;
+      else for (int j = i + 1; j <= best; ++j) cdf[j]++;
+    }
+  }
+  for (size_t i = 0; i < cdf.size(); ++i) h_cdf[i] = (int32_t)cdf[i];
+  return PCC_OK;
+}
+
+extern "C" int64_t pcc_rans_max_bytes(int64_t n) { return (2 * n + 4) * 4; }
+
+extern "C" int pcc_rans_encode_host(const int32_t* h_sym, const int32_t* h_idx, int64_t n, const int32_t* h_cdf,
+                                    int32_t cdf_stride, const int32_t* h_sizes, const int32_t* h_offsets, uint8_t* h_out,
+                                    int64_t cap, int64_t* h_nbytes) {
+  PCC_REQUIRE(h_nbytes && h_out && h_cdf && h_sizes && h_offsets && (n == 0 || (h_sym && h_idx)), "pcc_rans_encode_host: NULL");
+  PCC_REQUIRE(cap >= pcc_rans_max_bytes(n), "pcc_rans_encode_host: output capacity below pcc_rans_max_bytes");
+  std::vector<unsigned> buf((size_t)(2 * n + 4));
+  RansTab t{h_cdf, cdf_stride, h_sizes, h_offsets};
+  unsigned* end = buf.data() + buf.size();
+  unsigned* p = r_encode(h_sym, h_idx, 0, n, 1, t, end);
+  *h_nbytes = (int64_t)(end - p) * 4;
+  memcpy(h_out, p, (size_t)*h_nbytes);
+  return PCC_OK;
+}
+
+extern "C" int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const int32_t* h_idx, int64_t n,
+                                    const int32_t* h_cdf, int32_t cdf_stride, const int32_t* h_sizes,
+                                    const int32_t* h_offsets, int32_t* h_sym) {
+  PCC_REQUIRE(h_data && h_cdf && h_sizes && h_offsets && (n == 0 || (h_sym && h_idx)), "pcc_rans_decode_host: NULL");
+  PCC_REQUIRE(nbytes >= 8 && nbytes % 4 == 0, "pcc_rans_decode_host: truncated stream");
+  std::vector<unsigned> buf((size_t)nbytes / 4 + 4, 0u);     // zero padding: a corrupt stream cannot read out of bounds far
+  memcpy(buf.data(), h_data, (size_t)nbytes);
+  RansTab t{h_cdf, cdf_stride, h_sizes, h_offsets};
+  r_decode(buf.data(), h_idx, 0, n, 1, t, h_sym);
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// GPU: one stream per channel
+//   container: u32 n_streams | u32 nwords[n_streams] | words of stream 0 | words of stream 1 | ...
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_rans_encode(const int* __restrict__ sym, const int* __restrict__ idx, long long n,
+                                                    int n_streams, long long es, long long ss, RansTab t,
+                                                    unsigned* __restrict__ scratch, long long cap_words,
+                                                    int* __restrict__ nwords) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n_streams) return;
+  unsigned* end = scratch + (long long)(s + 1) * cap_words;
+  unsigned* p = r_encode(sym + s * ss, idx ? idx + s * ss : nullptr, s, n, es, t, end);
+  nwords[s] = (int)(end - p);
+}
+
+__global__ void __launch_bounds__(256) k_rans_pack(const unsigned* __restrict__ scratch, long long cap_words,
+                                                   const int* __restrict__ nwords, int n_streams,
+                                                   unsigned* __restrict__ out, long long* __restrict__ d_nbytes) {
+  __shared__ long long total;
+  // few hundred streams: a serial prefix by one thread is cheaper than a scan launch
+  extern __shared__ long long offs[];
+  if (threadIdx.x == 0) {
+    long long run = 0;
+    for (int s = 0; s < n_streams; ++s) { offs[s] = run; run += nwords[s]; }
+    total = run;
+    out[0] = (unsigned)n_streams;
+    *d_nbytes = 4ll * (1 + n_streams + run);
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < n_streams; s += 256) out[1 + s] = (unsigned)nwords[s];
+  unsigned* dst = out + 1 + n_streams;
+  for (int s = 0; s < n_streams; ++s) {
+    const unsigned* src = scratch + (long long)(s + 1) * cap_words - nwords[s];
+    for (int i = threadIdx.x; i < nwords[s]; i += 256) dst[offs[s] + i] = src[i];
+  }
+  (void)total;
+}
+
+__global__ void __launch_bounds__(64) k_rans_decode(const unsigned* __restrict__ data, long long nwords_total,
+                                                    const int* __restrict__ idx, long long n, int n_streams,
+                                                    long long es, long long ss, RansTab t, int* __restrict__ out,
+                                                    int* __restrict__ status) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n_streams) return;
+  if ((int)data[0] != n_streams) { *status = 1; return; }
+  long long off = 1 + n_streams;
+  for (int i = 0; i < s; ++i) off += data[1 + i];
+  const long long len = data[1 + s];
+  if (off + len > nwords_total || len < 2) { *status = 2; return; }
+  const unsigned* p = r_decode(data + off, idx ? idx + s * ss : nullptr, s, n, es, t, out + s * ss);
+  if (p - (data + off) > len) *status = 3;      // read past its own stream: corrupt input
+}
+
+extern "C" int64_t pcc_rans_container_max_bytes(int64_t n, int32_t n_streams) {
+  return 4 * (1 + (int64_t)n_streams) + (int64_t)n_streams * pcc_rans_max_bytes(n);
+}
+
+extern "C" size_t pcc_rans_streams_ws_bytes(int64_t n, int32_t n_streams) {
+  return (size_t)n_streams * (size_t)(2 * n + 4) * 4 + (size_t)n_streams * 4 + 1024;
+}
+
+extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t n_streams,
+                                       int64_t elem_stride, int64_t stream_stride, const int32_t* cdf,
+                                       int32_t cdf_stride, const int32_t* sizes, const int32_t* offsets, uint8_t* out,
+                                       int64_t* d_nbytes, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(sym && cdf && sizes && offsets && out && d_nbytes && ws, "pcc_rans_encode_streams: NULL array");
+  PCC_REQUIRE(n >= 0 && n_streams >= 1 && n_streams <= 4096, "pcc_rans_encode_streams: bad stream count %d", n_streams);
+  if (ws_bytes < pcc_rans_streams_ws_bytes(n, n_streams)) {
+    pcc_set_error("pcc_rans_encode_streams: workspace too small");
+    return PCC_EWS;
+  }
+  const long long cap = 2 * n + 4;
+  unsigned* scratch = (unsigned*)ws;
+  int* nwords = (int*)((char*)ws + (size_t)n_streams * cap * 4);
+  RansTab t{cdf, cdf_stride, sizes, offsets};
+  k_rans_encode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, 0, s>>>(sym, idx, n, n_streams, elem_stride, stream_stride, t,
+                                                                  scratch, cap, nwords);
+  PCC_LAUNCH_CHECK();
+  k_rans_pack<<<1, 256, (size_t)n_streams * sizeof(long long), s>>>(scratch, cap, nwords, n_streams, (unsigned*)out, (long long*)d_nbytes);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n,
+                                       int32_t n_streams, int64_t elem_stride, int64_t stream_stride,
+                                       const int32_t* cdf, int32_t cdf_stride, const int32_t* sizes,
+                                       const int32_t* offsets, int32_t* sym_out, int32_t* d_status, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(data && cdf && sizes && offsets && sym_out && d_status, "pcc_rans_decode_streams: NULL array");
+  PCC_REQUIRE(n >= 0 && n_streams >= 1 && n_streams <= 4096, "pcc_rans_decode_streams: bad stream count %d", n_streams);
+  PCC_REQUIRE(nbytes >= 4 * (1 + (int64_t)n_streams) && nbytes % 4 == 0, "pcc_rans_decode_streams: truncated container");
+  PCC_CHECK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
+  RansTab t{cdf, cdf_stride, sizes, offsets};
+  k_rans_decode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, 0, s>>>((const unsigned*)data, nbytes / 4, idx, n, n_streams,
+                                                                  elem_stride, stream_stride, t, sym_out, d_status);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}

@@ -10,7 +10,9 @@ Same module names (`h_a`, `h_s`, `scale_nn`, `rescale_nn`, `quant_nn`, `entropy_
   * LeakyReLU is fused into the producing convolution's epilogue;
   * scale bound, gain, table-index search, quantisation and likelihood are one kernel (`pcc_gauss_*`).
 
-The entropy-coder boundary carries integer symbols this round (rANS byte coding = SURVEY 8f row 1).
+The entropy-coder boundary carries rANS byte strings (`strings = [[y_string], [z_string]]` as in the reference); the
+coder is the per-channel GPU rANS of libpcc_hip by default (`entropy_coder="ans"`: single host stream in CompressAI's
+byte layout; `"symbols"`: hand the int32 symbol tensors across, for kernel-level measurements).
 """
 import torch
 import torch.nn as nn
@@ -57,11 +59,15 @@ class MeanScaleHyperprior(CompressionModel):
         self.adaptive_BN = config["adaptive_BN"] if "adaptive_BN" in config else True
         self.eps = 0.0001
         self.quantization_offset = config["quantization_offset"]
+        self.entropy_coder = config.get("entropy_coder", "pcc_streams")
+        if self.entropy_coder not in ("pcc_streams", "ans", "symbols"):
+            raise L.PccError(f"unknown entropy_coder {self.entropy_coder!r}")
+        coder = None if self.entropy_coder == "symbols" else self.entropy_coder
         if self.entropy_bottleneck_vbr:
             raise L.PccError("entropy_bottleneck_vbr is training-only in the reference (`model/entropy_models.py:275`) "
                              "and not built")
-        self.gaussian_conditional = GaussianConditional(None)
-        self.entropy_bottleneck = EntropyBottleneck(Ch)
+        self.gaussian_conditional = GaussianConditional(None, entropy_coder=coder)
+        self.entropy_bottleneck = EntropyBottleneck(Ch, entropy_coder=coder)
         conv, gen = ME.MinkowskiConvolution, SortedMinkowskiGenerativeConvolutionTranspose
         self.h_a = nn.Sequential(
             conv(in_channels=Cb, out_channels=Ch, kernel_size=3, dimension=3),
@@ -106,6 +112,9 @@ class MeanScaleHyperprior(CompressionModel):
         x = self._conv_act(self.h_s[2], x, L.ACT_LEAKY)
         return self._conv_act(self.h_s[4], x, L.ACT_NONE)
 
+    def gaussian_conditional_channels(self):
+        return self.h_s[4].out_channels // 2
+
     def get_offsets(self, stddev, scale):
         """`quant_nn` on (scale, stddev) pairs per element (`model/entropy_models.py:218-233`)."""
         return self.quant_nn(torch.stack([scale, stddev], dim=-1)).squeeze(-1)
@@ -125,17 +134,21 @@ class MeanScaleHyperprior(CompressionModel):
 
     # ---- reference API ---------------------------------------------------------------------------------
     def compress(self, y, q):
-        """Returns (points, symbols, shape): `points` = [y.C, z.C]; `symbols` = [y_symbols [Ny,C] int32,
-        z_symbols [Nz,Ch] int32] standing where the reference returns rANS strings
-        (`model/entropy_models.py:344-406`)."""
+        """Returns (points, strings, shape) like the reference (`model/entropy_models.py:344-406`):
+        points = [y.C, z.C], strings = [[y_string], [z_string]] (bytes), shape = [Nz].
+        With entropy_coder="symbols" the strings are the int32 symbol tensors [y_symbols, z_symbols]."""
         z = self.hyper_analysis(y)
         z_sym, z_hat_f, _ = self.entropy_bottleneck.encode_rows(z._canonical_features(), want_likelihood=False)
         z_hat = SparseTensor._from_canonical(z._cset, z_hat_f)
         params = self._gaussian_params(z_hat, y._cset)
         scale, _ = self._gains(q, y._cset, y.F.shape[1])
-        y_sym, _, _ = self.gaussian_conditional.encode_rows(y._canonical_features(), params, y._cset.keys, scale,
-                                                            want_likelihood=False)
-        return [y.C, z.C], [y_sym, z_sym], [z._cset.n]
+        y_sym, idx, _ = self.gaussian_conditional.encode_rows(y._canonical_features(), params, y._cset.keys, scale,
+                                                              want_likelihood=False)
+        if self.entropy_coder == "symbols":
+            return [y.C, z.C], [y_sym, z_sym], [z._cset.n]
+        z_string = self.entropy_bottleneck.compress_rows(z_sym)
+        y_string = self.gaussian_conditional.compress_rows(y_sym, idx)
+        return [y.C, z.C], [[y_string], [z_string]], [z._cset.n]
 
     def likelihoods(self, y, q):
         """Eval-mode likelihoods of y and z (what `forward` feeds the rate loss, `loss.py:63-81`)."""
@@ -147,16 +160,27 @@ class MeanScaleHyperprior(CompressionModel):
         return y_lik, z_lik
 
     def decompress(self, points, symbols, shape, q):
-        """points = [y coords | y SparseTensor, z coords]; symbols = [y_symbols, z_symbols]
-        (`model/entropy_models.py:409-490`).  Returns y_hat as a stride-8 SparseTensor."""
+        """points = [y CoordSet, z CoordSet]; symbols = strings [[y_string], [z_string]] (or the symbol tensors with
+        entropy_coder="symbols") (`model/entropy_models.py:409-490`).  Returns y_hat as a stride-8 SparseTensor."""
         assert isinstance(symbols, list) and len(symbols) == 2
         assert isinstance(points, list) and len(points) == 2
-        y_sym, z_sym = symbols
         y_cset, z_cset = points
+        dev = y_cset.device
+        c_y = self.gaussian_conditional_channels()
+        if self.entropy_coder == "symbols":
+            y_sym, z_sym = symbols
+        else:
+            (y_string,), (z_string,) = symbols
+            z_sym = self.entropy_bottleneck.decompress_rows(z_string, z_cset.n, self.entropy_bottleneck.channels,
+                                                            device=dev)
+            y_sym = None
         med = self.entropy_bottleneck.quantiles[:, 0, 1].detach().to(torch.float32)
         z_hat = SparseTensor._from_canonical(z_cset, z_sym.to(torch.float32) + med[None, :])
         params = self._gaussian_params(z_hat, y_cset)
-        scale, rescale = self._gains(q, y_cset, y_sym.shape[1])
+        scale, rescale = self._gains(q, y_cset, c_y)
+        if y_sym is None:
+            idx = self.gaussian_conditional.index_rows(params, y_cset.keys, scale)
+            y_sym = self.gaussian_conditional.decompress_rows(y_string, y_cset.n, c_y, idx)
         if self.quantization_offset:
             c = y_sym.shape[1]
             scales_hat, means_hat = params[:, :c], params[:, c:]

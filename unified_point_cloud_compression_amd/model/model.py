@@ -3,8 +3,8 @@
 Same call signatures and return structure as the reference when `path is None`:
   compress(pointcloud[N,6], q[1,2], block_size) -> (bitstreams, block_shapes, block_k, block_coordinates,
   block_q_vals), one entry per block; decompress(coordinates=, strings=, shape=, k=, q_vals=) -> [N,6].
-`bitstreams[i]` holds [y_symbols, z_symbols] (int32 device tensors) where the reference holds rANS strings
-(entropy coder = SURVEY 8f row 1); the file container / G-PCC coordinate coder (`path=`) are out of scope.
+`bitstreams[i]` = [[y_string], [z_string]] rANS byte strings as in the reference (`utils.count_bits` applies); the
+file container / G-PCC coordinate coder (`path=`) are out of scope.
 """
 import torch
 

@@ -119,11 +119,24 @@ class EntropyModel(nn.Module):
         sym = torch.empty((n, c), dtype=torch.int32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         L.call("pcc_rans_decode_streams", L.ptr(buf), buf.numel(), L.ptr(idx.contiguous()) if idx is not None else None,
-               n, c, c, 1, L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(sym), L.ptr(status), L.stream())
+               n, c, c, 1, L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._lut(dev)), L.ptr(sym),
+               L.ptr(status), L.stream())
         st = int(status.item())
         if st != 0:
             raise L.PccError(f"malformed rANS container (status {st})")
         return sym
+
+    def _lut(self, dev):
+        """Decoder bucket table of the current CDFs (rebuilt when the tables change)."""
+        tag = (self._quantized_cdf.data_ptr(), self._quantized_cdf._version, str(dev))
+        if getattr(self, "_lut_tag", None) != tag:
+            cdf, sizes, _ = self._host_tables()
+            lut = np.zeros(cdf.shape[0] * 256, dtype=np.uint16)
+            L.check(L.load().pcc_rans_build_lut(_np_ptr(cdf), cdf.shape[0], cdf.shape[1], _np_ptr(sizes), _np_ptr(lut)),
+                    "pcc_rans_build_lut")
+            self._lut_dev = torch.from_numpy(lut.view(np.int16)).to(dev)
+            self._lut_tag = tag
+        return self._lut_dev
 
     def _host_tables(self):
         return tuple(np.ascontiguousarray(t.detach().cpu().numpy().astype(np.int32))

@@ -23,10 +23,26 @@ static constexpr unsigned long long R_L = 1ull << 31;
 
 struct RansTab { const int* cdf; int stride; const int* sizes; const int* offsets; };
 
+// x / f and x % f for f < 2^16 and x < 2^47 * f (always true after renormalisation): three 32-bit divisions
+// instead of the 64-bit software division routine.
+RANS_HD void r_divmod(unsigned long long x, unsigned f, unsigned long long& q, unsigned& r) {
+  const unsigned hi = (unsigned)(x >> 32), lo = (unsigned)x;
+  const unsigned q0 = hi / f, r0 = hi - q0 * f;
+  const unsigned d1 = (r0 << 16) | (lo >> 16);
+  const unsigned q1 = d1 / f, r1 = d1 - q1 * f;
+  const unsigned d2 = (r1 << 16) | (lo & 0xFFFFu);
+  const unsigned q2 = d2 / f;
+  r = d2 - q2 * f;
+  q = ((unsigned long long)q0 << 32) | ((unsigned long long)q1 << 16) | q2;
+}
+
 RANS_HD void r_put(unsigned long long& x, unsigned*& ptr, unsigned start, unsigned freq) {
   const unsigned long long x_max = ((R_L >> R_PREC) << 32) * freq;
   if (x >= x_max) { *--ptr = (unsigned)x; x >>= 32; }
-  x = ((x / freq) << R_PREC) + (x % freq) + start;
+  unsigned long long q;
+  unsigned r;
+  r_divmod(x, freq, q, r);
+  x = (q << R_PREC) + r + start;
 }
 RANS_HD void r_put_bits(unsigned long long& x, unsigned*& ptr, unsigned val) {
   const unsigned long long x_max = ((R_L >> 16) << 32) * (1u << (16 - R_BYP));
@@ -34,30 +50,61 @@ RANS_HD void r_put_bits(unsigned long long& x, unsigned*& ptr, unsigned val) {
   x = (x << R_BYP) | val;
 }
 
-// encodes n symbols (read with stride) in reverse; words are written backwards from `end`; returns the first word
+// encodes n symbols (read with stride) in reverse; words are written backwards from `end`; returns the first word.
+// Symbols are taken in batches of RB: all table look-ups of a batch (independent of the coder state) are issued
+// first so their latencies overlap, then the state updates run from registers.
+static constexpr int RB = 16;
+
+RANS_HD void r_put_bypass(unsigned long long& x, unsigned*& ptr, unsigned raw) {
+  // reverse of: count digits (15, 15, ..., rest), raw digits j = 0..nb-1   (the main symbol follows, by the caller)
+  int nb = 0;
+  while (nb < 8 && (raw >> (nb * R_BYP)) != 0) ++nb;
+  for (int j = nb - 1; j >= 0; --j) r_put_bits(x, ptr, (raw >> (j * R_BYP)) & R_MAXB);
+  int val = nb, n15 = 0;
+  while (val >= R_MAXB) { val -= R_MAXB; ++n15; }
+  r_put_bits(x, ptr, (unsigned)val);
+  for (int j = 0; j < n15; ++j) r_put_bits(x, ptr, R_MAXB);
+}
+
 RANS_HD unsigned* r_encode(const int* sym, const int* idx, int fixed_idx, long long n, long long stride, RansTab t,
                            unsigned* end) {
   unsigned long long x = R_L;
   unsigned* ptr = end;
-  for (long long i = n - 1; i >= 0; --i) {
-    const int ci = idx ? idx[i * stride] : fixed_idx;
-    const int* c = t.cdf + (long long)ci * t.stride;
-    const int max_value = t.sizes[ci] - 2;
-    int value = sym[i * stride] - t.offsets[ci];
-    unsigned raw = 0;
-    bool bypass = false;
-    if (value < 0) { raw = (unsigned)(-2 * value - 1); value = max_value; bypass = true; }
-    else if (value >= max_value) { raw = (unsigned)(2 * (value - max_value)); value = max_value; bypass = true; }
-    if (bypass) {   // reverse of: main, count digits (15, 15, ..., rest), raw digits j = 0..nb-1
-      int nb = 0;
-      while (nb < 8 && (raw >> (nb * R_BYP)) != 0) ++nb;
-      for (int j = nb - 1; j >= 0; --j) r_put_bits(x, ptr, (raw >> (j * R_BYP)) & R_MAXB);
-      int val = nb, n15 = 0;
-      while (val >= R_MAXB) { val -= R_MAXB; ++n15; }
-      r_put_bits(x, ptr, (unsigned)val);
-      for (int j = 0; j < n15; ++j) r_put_bits(x, ptr, R_MAXB);
+  for (long long base = n; base > 0; base -= RB) {
+    int value[RB], ci[RB];
+    unsigned raw[RB], start[RB], freq[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const long long i = base - 1 - u;
+      ci[u] = (i >= 0) ? (idx ? idx[i * stride] : fixed_idx) : -1;
+      value[u] = (i >= 0) ? sym[i * stride] : 0;
     }
-    r_put(x, ptr, (unsigned)c[value], (unsigned)(c[value + 1] - c[value]));
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      raw[u] = 0xFFFFFFFFu;                                   // marker: not bypassed
+      if (ci[u] >= 0) {
+        const int max_value = t.sizes[ci[u]] - 2;
+        int v = value[u] - t.offsets[ci[u]];
+        if (v < 0) { raw[u] = (unsigned)(-2 * v - 1); v = max_value; }
+        else if (v >= max_value) { raw[u] = (unsigned)(2 * (v - max_value)); v = max_value; }
+        value[u] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      if (ci[u] >= 0) {
+        const int* c = t.cdf + (long long)ci[u] * t.stride;
+        start[u] = (unsigned)c[value[u]];
+        freq[u] = (unsigned)c[value[u] + 1] - start[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      if (ci[u] >= 0) {
+        if (raw[u] != 0xFFFFFFFFu) r_put_bypass(x, ptr, raw[u]);
+        r_put(x, ptr, start[u], freq[u]);
+      }
+    }
   }
   ptr -= 2;
   ptr[0] = (unsigned)x;
@@ -72,33 +119,52 @@ RANS_HD unsigned r_get_bits(unsigned long long& x, const unsigned*& ptr) {
   return v;
 }
 
-// decodes n symbols forward; returns the pointer past the last word consumed
+// decodes n symbols forward; returns the pointer past the last word consumed.  `lut` (nullable) is a per-row
+// bucket table: lut[row*256 + (cum >> 8)] = last s with cdf[s] <= (cum & ~255), the start of a short forward scan;
+// without it each symbol costs a binary search of dependent loads.
 RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int fixed_idx, long long n, long long stride,
-                                 RansTab t, int* out) {
+                                 RansTab t, const unsigned short* lut, int* out) {
   unsigned long long x = (unsigned long long)ptr[0] | ((unsigned long long)ptr[1] << 32);
   ptr += 2;
-  for (long long i = 0; i < n; ++i) {
-    const int ci = idx ? idx[i * stride] : fixed_idx;
-    const int* c = t.cdf + (long long)ci * t.stride;
-    const int size = t.sizes[ci];
-    const int max_value = size - 2;
-    const unsigned cum = (unsigned)(x & ((1u << R_PREC) - 1));
-    int lo = 0, hi = size - 1;                      // last s with c[s] <= cum  (c[0] = 0, c[size-1] = 2^16 > cum)
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((unsigned)c[mid] <= cum) lo = mid; else hi = mid; }
-    const unsigned start = (unsigned)c[lo], freq = (unsigned)(c[lo + 1] - c[lo]);
-    x = (unsigned long long)freq * (x >> R_PREC) + cum - start;
-    if (x < R_L) x = (x << 32) | *ptr++;
-    int value = lo;
-    if (value == max_value) {
-      unsigned val = r_get_bits(x, ptr);
-      int nb = (int)val;
-      while (val == R_MAXB) { val = r_get_bits(x, ptr); nb += (int)val; }
-      unsigned raw = 0;
-      for (int j = 0; j < nb; ++j) raw |= r_get_bits(x, ptr) << (j * R_BYP);
-      value = (int)(raw >> 1);
-      value = (raw & 1) ? -value - 1 : value + max_value;
+  for (long long base = 0; base < n; base += RB) {
+    int ci[RB], size[RB], off[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) ci[u] = (base + u < n) ? (idx ? idx[(base + u) * stride] : fixed_idx) : -1;
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      size[u] = ci[u] >= 0 ? t.sizes[ci[u]] : 0;
+      off[u] = ci[u] >= 0 ? t.offsets[ci[u]] : 0;
     }
-    out[i * stride] = value + t.offsets[ci];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      if (ci[u] < 0) continue;
+      const int* c = t.cdf + (long long)ci[u] * t.stride;
+      const int max_value = size[u] - 2;
+      const unsigned cum = (unsigned)(x & ((1u << R_PREC) - 1));
+      int lo;
+      if (lut) {
+        lo = lut[ci[u] * 256 + (cum >> 8)];
+        while ((unsigned)c[lo + 1] <= cum) ++lo;
+      } else {
+        int hi = size[u] - 1;                         // last s with c[s] <= cum  (c[0] = 0, c[size-1] = 2^16 > cum)
+        lo = 0;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((unsigned)c[mid] <= cum) lo = mid; else hi = mid; }
+      }
+      const unsigned start = (unsigned)c[lo], freq = (unsigned)(c[lo + 1] - c[lo]);
+      x = (unsigned long long)freq * (x >> R_PREC) + cum - start;
+      if (x < R_L) x = (x << 32) | *ptr++;
+      int value = lo;
+      if (value == max_value) {
+        unsigned val = r_get_bits(x, ptr);
+        int nb = (int)val;
+        while (val == R_MAXB) { val = r_get_bits(x, ptr); nb += (int)val; }
+        unsigned raw = 0;
+        for (int j = 0; j < nb; ++j) raw |= r_get_bits(x, ptr) << (j * R_BYP);
+        value = (int)(raw >> 1);
+        value = (raw & 1) ? -value - 1 : value + max_value;
+      }
+      out[(base + u) * stride] = value + off[u];
+    }
   }
   return ptr;
 }
@@ -134,6 +200,21 @@ extern "C" int pcc_pmf_to_quantized_cdf(const float* h_pmf, int32_t n, int32_t p
   return PCC_OK;
 }
 
+// bucket table for the decoder: lut[r*256 + b] = last s with cdf[r][s] <= b*256
+extern "C" int pcc_rans_build_lut(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
+                                  uint16_t* h_lut) {
+  PCC_REQUIRE(h_cdf && h_sizes && h_lut && rows >= 1, "pcc_rans_build_lut: bad arguments");
+  for (int r = 0; r < rows; ++r) {
+    const int32_t* c = h_cdf + (int64_t)r * cdf_stride;
+    int s = 0;
+    for (int b = 0; b < 256; ++b) {
+      while (s + 1 < h_sizes[r] - 1 && c[s + 1] <= b * 256) ++s;
+      h_lut[r * 256 + b] = (uint16_t)s;
+    }
+  }
+  return PCC_OK;
+}
+
 extern "C" int64_t pcc_rans_max_bytes(int64_t n) { return (2 * n + 4) * 4; }
 
 extern "C" int pcc_rans_encode_host(const int32_t* h_sym, const int32_t* h_idx, int64_t n, const int32_t* h_cdf,
@@ -158,7 +239,7 @@ extern "C" int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const
   std::vector<unsigned> buf((size_t)nbytes / 4 + 4, 0u);     // zero padding: a corrupt stream cannot read out of bounds far
   memcpy(buf.data(), h_data, (size_t)nbytes);
   RansTab t{h_cdf, cdf_stride, h_sizes, h_offsets};
-  r_decode(buf.data(), h_idx, 0, n, 1, t, h_sym);
+  r_decode(buf.data(), h_idx, 0, n, 1, t, nullptr, h_sym);
   return PCC_OK;
 }
 
@@ -202,7 +283,8 @@ __global__ void __launch_bounds__(256) k_rans_pack(const unsigned* __restrict__ 
 
 __global__ void __launch_bounds__(64) k_rans_decode(const unsigned* __restrict__ data, long long nwords_total,
                                                     const int* __restrict__ idx, long long n, int n_streams,
-                                                    long long es, long long ss, RansTab t, int* __restrict__ out,
+                                                    long long es, long long ss, RansTab t,
+                                                    const unsigned short* __restrict__ lut, int* __restrict__ out,
                                                     int* __restrict__ status) {
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= n_streams) return;
@@ -211,7 +293,7 @@ __global__ void __launch_bounds__(64) k_rans_decode(const unsigned* __restrict__
   for (int i = 0; i < s; ++i) off += data[1 + i];
   const long long len = data[1 + s];
   if (off + len > nwords_total || len < 2) { *status = 2; return; }
-  const unsigned* p = r_decode(data + off, idx ? idx + s * ss : nullptr, s, n, es, t, out + s * ss);
+  const unsigned* p = r_decode(data + off, idx ? idx + s * ss : nullptr, s, n, es, t, lut, out + s * ss);
   if (p - (data + off) > len) *status = 3;      // read past its own stream: corrupt input
 }
 
@@ -249,7 +331,8 @@ extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, i
 extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n,
                                        int32_t n_streams, int64_t elem_stride, int64_t stream_stride,
                                        const int32_t* cdf, int32_t cdf_stride, const int32_t* sizes,
-                                       const int32_t* offsets, int32_t* sym_out, int32_t* d_status, void* stream) {
+                                       const int32_t* offsets, const uint16_t* lut, int32_t* sym_out, int32_t* d_status,
+                                       void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(data && cdf && sizes && offsets && sym_out && d_status, "pcc_rans_decode_streams: NULL array");
   PCC_REQUIRE(n >= 0 && n_streams >= 1 && n_streams <= 4096, "pcc_rans_decode_streams: bad stream count %d", n_streams);
@@ -257,7 +340,7 @@ extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, cons
   PCC_CHECK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
   RansTab t{cdf, cdf_stride, sizes, offsets};
   k_rans_decode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, 0, s>>>((const unsigned*)data, nbytes / 4, idx, n, n_streams,
-                                                                  elem_stride, stream_stride, t, sym_out, d_status);
+                                                                  elem_stride, stream_stride, t, (const unsigned short*)lut, sym_out, d_status);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

@@ -251,19 +251,24 @@ int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const int32_t* h
  * The reference's [1,C,N] channel-major symbol order is exactly the concatenation of these C streams. */
 int64_t pcc_rans_container_max_bytes(int64_t n, int32_t n_streams);
 size_t pcc_rans_streams_ws_bytes(int64_t n, int32_t n_streams);
+/* enc_table (nullable, device): division-free entries from pcc_rans_build_enc_table (16 bytes per (row, value),
+ * layout [rows][cdf_stride]); NULL = 64-bit division per symbol.  Output bytes are identical either way. */
+int pcc_rans_build_enc_table(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
+                             void* h_table /*16*rows*cdf_stride bytes*/);
 int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t n_streams,
                             int64_t elem_stride, int64_t stream_stride, const int32_t* cdf, int32_t cdf_stride,
-                            const int32_t* sizes, const int32_t* offsets, uint8_t* out, int64_t* d_nbytes, void* ws,
-                            size_t ws_bytes, void* stream);
-/* decoder bucket table (host): lut[r*256 + b] = last s with cdf[r][s] <= 256*b; turns the per-symbol CDF search into
- * one look-up plus a short scan.  lut may be NULL in pcc_rans_decode_streams (binary search). */
+                            const int32_t* sizes, const int32_t* offsets, const void* enc_table, uint8_t* out,
+                            int64_t* d_nbytes, void* ws, size_t ws_bytes, void* stream);
+/* decoder bucket table (host): lut[r*256 + b] = s | start<<16 | freq<<32 of the last s with cdf[r][s] <= 256*b; turns
+ * the per-symbol CDF search into one look-up (kept in LDS when rows <= 64) plus a rare short scan.  lut may be NULL
+ * in pcc_rans_decode_streams (binary search). */
 int pcc_rans_build_lut(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
-                       uint16_t* h_lut /*[rows*256]*/);
+                       uint64_t* h_lut /*[rows*256]*/);
 /* *d_status != 0 after the kernel: malformed container */
 int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n, int32_t n_streams,
                             int64_t elem_stride, int64_t stream_stride, const int32_t* cdf, int32_t cdf_stride,
-                            const int32_t* sizes, const int32_t* offsets, const uint16_t* lut /*nullable*/,
-                            int32_t* sym_out, int32_t* d_status, void* stream);
+                            const int32_t* sizes, const int32_t* offsets, const uint64_t* lut /*nullable*/,
+                            int32_t lut_rows, int32_t* sym_out, int32_t* d_status, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * measurement support: per-launch HIP-event timing of the conv kernel (bench.py roofline)

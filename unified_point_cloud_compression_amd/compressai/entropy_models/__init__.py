@@ -101,8 +101,8 @@ class EntropyModel(nn.Module):
         nb = torch.zeros(1, dtype=torch.int64, device=dev)
         ws = L.workspace(lib.pcc_rans_streams_ws_bytes(n, c), dev)
         L.call("pcc_rans_encode_streams", L.ptr(sym), L.ptr(idx.contiguous()) if idx is not None else None, n, c, c, 1,
-               L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(out), L.ptr(nb), L.ptr(ws), ws.numel(),
-               L.stream())
+               L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._enc_table(dev)), L.ptr(out), L.ptr(nb),
+               L.ptr(ws), ws.numel(), L.stream())
         return out[:int(nb.item())].cpu().numpy().tobytes()
 
     def decompress_rows(self, data, n, c, idx=None, device=None):
@@ -119,8 +119,8 @@ class EntropyModel(nn.Module):
         sym = torch.empty((n, c), dtype=torch.int32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         L.call("pcc_rans_decode_streams", L.ptr(buf), buf.numel(), L.ptr(idx.contiguous()) if idx is not None else None,
-               n, c, c, 1, L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._lut(dev)), L.ptr(sym),
-               L.ptr(status), L.stream())
+               n, c, c, 1, L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._lut(dev)), cdf.shape[0],
+               L.ptr(sym), L.ptr(status), L.stream())
         st = int(status.item())
         if st != 0:
             raise L.PccError(f"malformed rANS container (status {st})")
@@ -131,12 +131,24 @@ class EntropyModel(nn.Module):
         tag = (self._quantized_cdf.data_ptr(), self._quantized_cdf._version, str(dev))
         if getattr(self, "_lut_tag", None) != tag:
             cdf, sizes, _ = self._host_tables()
-            lut = np.zeros(cdf.shape[0] * 256, dtype=np.uint16)
+            lut = np.zeros(cdf.shape[0] * 256, dtype=np.uint64)
             L.check(L.load().pcc_rans_build_lut(_np_ptr(cdf), cdf.shape[0], cdf.shape[1], _np_ptr(sizes), _np_ptr(lut)),
                     "pcc_rans_build_lut")
-            self._lut_dev = torch.from_numpy(lut.view(np.int16)).to(dev)
+            self._lut_dev = torch.from_numpy(lut.view(np.int64)).to(dev)
             self._lut_tag = tag
         return self._lut_dev
+
+    def _enc_table(self, dev):
+        """Division-free encoder entries of the current CDFs (rebuilt when the tables change)."""
+        tag = (self._quantized_cdf.data_ptr(), self._quantized_cdf._version, str(dev))
+        if getattr(self, "_enc_tag", None) != tag:
+            cdf, sizes, _ = self._host_tables()
+            tab = np.zeros(cdf.shape[0] * cdf.shape[1] * 2, dtype=np.uint64)
+            L.check(L.load().pcc_rans_build_enc_table(_np_ptr(cdf), cdf.shape[0], cdf.shape[1], _np_ptr(sizes),
+                                                      _np_ptr(tab)), "pcc_rans_build_enc_table")
+            self._enc_dev = torch.from_numpy(tab.view(np.int64)).to(dev)
+            self._enc_tag = tag
+        return self._enc_dev
 
     def _host_tables(self):
         return tuple(np.ascontiguousarray(t.detach().cpu().numpy().astype(np.int32))

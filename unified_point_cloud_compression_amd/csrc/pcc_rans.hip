@@ -23,6 +23,26 @@ static constexpr unsigned long long R_L = 1ull << 31;
 
 struct RansTab { const int* cdf; int stride; const int* sizes; const int* offsets; };
 
+// Per (table row, value) division-free encoder entry (ryg_rans `Rans64EncSymbol`): x -> x + bias + q*cmpl_freq with
+// q = mulhi(x, rcp_freq) >> rcp_shift equals ((x / freq) << 16) + (x % freq) + start exactly.
+struct RansEncSym { unsigned long long rcp_freq; unsigned bias; unsigned short cmpl_freq; unsigned short rcp_shift; };
+
+RANS_HD unsigned long long r_mulhi(unsigned long long a, unsigned long long b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (unsigned long long)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+RANS_HD void r_put_sym(unsigned long long& x, unsigned*& ptr, const RansEncSym& e) {
+  const unsigned freq = (1u << R_PREC) - e.cmpl_freq;
+  const unsigned long long x_max = ((R_L >> R_PREC) << 32) * freq;
+  if (x >= x_max) { *--ptr = (unsigned)x; x >>= 32; }
+  const unsigned long long q = r_mulhi(x, e.rcp_freq) >> e.rcp_shift;
+  x = x + e.bias + q * e.cmpl_freq;
+}
+
 // x / f and x % f for f < 2^16 and x < 2^47 * f (always true after renormalisation): three 32-bit divisions
 // instead of the 64-bit software division routine.
 RANS_HD void r_divmod(unsigned long long x, unsigned f, unsigned long long& q, unsigned& r) {
@@ -67,12 +87,13 @@ RANS_HD void r_put_bypass(unsigned long long& x, unsigned*& ptr, unsigned raw) {
 }
 
 RANS_HD unsigned* r_encode(const int* sym, const int* idx, int fixed_idx, long long n, long long stride, RansTab t,
-                           unsigned* end) {
+                           const RansEncSym* enc, unsigned* end) {
   unsigned long long x = R_L;
   unsigned* ptr = end;
   for (long long base = n; base > 0; base -= RB) {
     int value[RB], ci[RB];
     unsigned raw[RB], start[RB], freq[RB];
+    RansEncSym es[RB];
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
       const long long i = base - 1 - u;
@@ -93,16 +114,19 @@ RANS_HD unsigned* r_encode(const int* sym, const int* idx, int fixed_idx, long l
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
       if (ci[u] >= 0) {
-        const int* c = t.cdf + (long long)ci[u] * t.stride;
-        start[u] = (unsigned)c[value[u]];
-        freq[u] = (unsigned)c[value[u] + 1] - start[u];
+        if (enc) es[u] = enc[(long long)ci[u] * t.stride + value[u]];
+        else {
+          const int* c = t.cdf + (long long)ci[u] * t.stride;
+          start[u] = (unsigned)c[value[u]];
+          freq[u] = (unsigned)c[value[u] + 1] - start[u];
+        }
       }
     }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
       if (ci[u] >= 0) {
         if (raw[u] != 0xFFFFFFFFu) r_put_bypass(x, ptr, raw[u]);
-        r_put(x, ptr, start[u], freq[u]);
+        if (enc) r_put_sym(x, ptr, es[u]); else r_put(x, ptr, start[u], freq[u]);
       }
     }
   }
@@ -122,8 +146,9 @@ RANS_HD unsigned r_get_bits(unsigned long long& x, const unsigned*& ptr) {
 // decodes n symbols forward; returns the pointer past the last word consumed.  `lut` (nullable) is a per-row
 // bucket table: lut[row*256 + (cum >> 8)] = last s with cdf[s] <= (cum & ~255), the start of a short forward scan;
 // without it each symbol costs a binary search of dependent loads.
+// fat LUT entry: s | start << 16 | freq << 32 of the first symbol of bucket (cum >> 8)
 RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int fixed_idx, long long n, long long stride,
-                                 RansTab t, const unsigned short* lut, int* out) {
+                                 RansTab t, const unsigned long long* lut, int* out) {
   unsigned long long x = (unsigned long long)ptr[0] | ((unsigned long long)ptr[1] << 32);
   ptr += 2;
   for (long long base = 0; base < n; base += RB) {
@@ -142,15 +167,20 @@ RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int fixed_
       const int max_value = size[u] - 2;
       const unsigned cum = (unsigned)(x & ((1u << R_PREC) - 1));
       int lo;
+      unsigned start, freq;
       if (lut) {
-        lo = lut[ci[u] * 256 + (cum >> 8)];
-        while ((unsigned)c[lo + 1] <= cum) ++lo;
+        const unsigned long long e = lut[ci[u] * 256 + (cum >> 8)];
+        lo = (int)(e & 0xFFFF); start = (unsigned)((e >> 16) & 0xFFFF); freq = (unsigned)(e >> 32);
+        if (start + freq <= cum) {                    // not the first symbol of its bucket: short forward scan
+          do { ++lo; } while ((unsigned)c[lo + 1] <= cum);
+          start = (unsigned)c[lo]; freq = (unsigned)(c[lo + 1] - c[lo]);
+        }
       } else {
         int hi = size[u] - 1;                         // last s with c[s] <= cum  (c[0] = 0, c[size-1] = 2^16 > cum)
         lo = 0;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((unsigned)c[mid] <= cum) lo = mid; else hi = mid; }
+        start = (unsigned)c[lo]; freq = (unsigned)(c[lo + 1] - c[lo]);
       }
-      const unsigned start = (unsigned)c[lo], freq = (unsigned)(c[lo + 1] - c[lo]);
       x = (unsigned long long)freq * (x >> R_PREC) + cum - start;
       if (x < R_L) x = (x << 32) | *ptr++;
       int value = lo;
@@ -200,16 +230,47 @@ extern "C" int pcc_pmf_to_quantized_cdf(const float* h_pmf, int32_t n, int32_t p
   return PCC_OK;
 }
 
-// bucket table for the decoder: lut[r*256 + b] = last s with cdf[r][s] <= b*256
+// bucket table for the decoder: lut[r*256 + b] = (s | start << 16 | freq << 32) of the last s with cdf[r][s] <= b*256
 extern "C" int pcc_rans_build_lut(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
-                                  uint16_t* h_lut) {
+                                  uint64_t* h_lut) {
   PCC_REQUIRE(h_cdf && h_sizes && h_lut && rows >= 1, "pcc_rans_build_lut: bad arguments");
   for (int r = 0; r < rows; ++r) {
     const int32_t* c = h_cdf + (int64_t)r * cdf_stride;
     int s = 0;
     for (int b = 0; b < 256; ++b) {
       while (s + 1 < h_sizes[r] - 1 && c[s + 1] <= b * 256) ++s;
-      h_lut[r * 256 + b] = (uint16_t)s;
+      h_lut[r * 256 + b] = (uint64_t)s | ((uint64_t)(uint32_t)c[s] << 16) | ((uint64_t)(uint32_t)(c[s + 1] - c[s]) << 32);
+    }
+  }
+  return PCC_OK;
+}
+
+// division-free encoder entries, one per (row, value): layout [rows][cdf_stride] of 16-byte RansEncSym
+extern "C" int pcc_rans_build_enc_table(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
+                                        void* h_table) {
+  PCC_REQUIRE(h_cdf && h_sizes && h_table && rows >= 1, "pcc_rans_build_enc_table: bad arguments");
+  static_assert(sizeof(RansEncSym) == 16, "RansEncSym must be 16 bytes");
+  RansEncSym* out = (RansEncSym*)h_table;
+  memset(out, 0, sizeof(RansEncSym) * (size_t)rows * cdf_stride);
+  for (int r = 0; r < rows; ++r) {
+    const int32_t* c = h_cdf + (int64_t)r * cdf_stride;
+    for (int v = 0; v + 1 < h_sizes[r]; ++v) {
+      const uint32_t start = (uint32_t)c[v], freq = (uint32_t)(c[v + 1] - c[v]);
+      PCC_REQUIRE(freq >= 1 && freq < (1u << R_PREC), "pcc_rans_build_enc_table: bad frequency in row %d", r);
+      RansEncSym& e = out[(int64_t)r * cdf_stride + v];
+      e.cmpl_freq = (unsigned short)((1u << R_PREC) - freq);
+      if (freq < 2) {
+        e.rcp_freq = ~0ull; e.rcp_shift = 0; e.bias = start + (1u << R_PREC) - 1;
+      } else {
+        uint32_t shift = 0;
+        while (freq > (1u << shift)) ++shift;
+        uint64_t x0 = freq - 1;
+        const uint64_t x1 = 1ull << (shift + 31);
+        const uint64_t t1 = x1 / freq;
+        x0 += (x1 % freq) << 32;
+        const uint64_t t0 = x0 / freq;
+        e.rcp_freq = t0 + (t1 << 32); e.rcp_shift = (unsigned short)(shift - 1); e.bias = start;
+      }
     }
   }
   return PCC_OK;
@@ -225,7 +286,7 @@ extern "C" int pcc_rans_encode_host(const int32_t* h_sym, const int32_t* h_idx, 
   std::vector<unsigned> buf((size_t)(2 * n + 4));
   RansTab t{h_cdf, cdf_stride, h_sizes, h_offsets};
   unsigned* end = buf.data() + buf.size();
-  unsigned* p = r_encode(h_sym, h_idx, 0, n, 1, t, end);
+  unsigned* p = r_encode(h_sym, h_idx, 0, n, 1, t, nullptr, end);
   *h_nbytes = (int64_t)(end - p) * 4;
   memcpy(h_out, p, (size_t)*h_nbytes);
   return PCC_OK;
@@ -249,12 +310,13 @@ extern "C" int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_rans_encode(const int* __restrict__ sym, const int* __restrict__ idx, long long n,
                                                     int n_streams, long long es, long long ss, RansTab t,
+                                                    const RansEncSym* __restrict__ enc,
                                                     unsigned* __restrict__ scratch, long long cap_words,
                                                     int* __restrict__ nwords) {
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= n_streams) return;
   unsigned* end = scratch + (long long)(s + 1) * cap_words;
-  unsigned* p = r_encode(sym + s * ss, idx ? idx + s * ss : nullptr, s, n, es, t, end);
+  unsigned* p = r_encode(sym + s * ss, idx ? idx + s * ss : nullptr, s, n, es, t, enc, end);
   nwords[s] = (int)(end - p);
 }
 
@@ -284,9 +346,15 @@ __global__ void __launch_bounds__(256) k_rans_pack(const unsigned* __restrict__ 
 __global__ void __launch_bounds__(64) k_rans_decode(const unsigned* __restrict__ data, long long nwords_total,
                                                     const int* __restrict__ idx, long long n, int n_streams,
                                                     long long es, long long ss, RansTab t,
-                                                    const unsigned short* __restrict__ lut, int* __restrict__ out,
-                                                    int* __restrict__ status) {
-  const int s = blockIdx.x * 64 + threadIdx.x;
+                                                    const unsigned long long* __restrict__ lut, int lut_rows_lds,
+                                                    int* __restrict__ out, int* __restrict__ status) {
+  extern __shared__ unsigned long long lut_s[];
+  if (lut && lut_rows_lds > 0) {                       // small tables: the bucket LUT lives in LDS (latency)
+    for (int i = threadIdx.x; i < lut_rows_lds * 256; i += blockDim.x) lut_s[i] = lut[i];
+    __syncthreads();
+    lut = lut_s;
+  }
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_streams) return;
   if ((int)data[0] != n_streams) { *status = 1; return; }
   long long off = 1 + n_streams;
@@ -307,8 +375,9 @@ extern "C" size_t pcc_rans_streams_ws_bytes(int64_t n, int32_t n_streams) {
 
 extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t n_streams,
                                        int64_t elem_stride, int64_t stream_stride, const int32_t* cdf,
-                                       int32_t cdf_stride, const int32_t* sizes, const int32_t* offsets, uint8_t* out,
-                                       int64_t* d_nbytes, void* ws, size_t ws_bytes, void* stream) {
+                                       int32_t cdf_stride, const int32_t* sizes, const int32_t* offsets,
+                                       const void* enc_table, uint8_t* out, int64_t* d_nbytes, void* ws,
+                                       size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(sym && cdf && sizes && offsets && out && d_nbytes && ws, "pcc_rans_encode_streams: NULL array");
   PCC_REQUIRE(n >= 0 && n_streams >= 1 && n_streams <= 4096, "pcc_rans_encode_streams: bad stream count %d", n_streams);
@@ -321,7 +390,7 @@ extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, i
   int* nwords = (int*)((char*)ws + (size_t)n_streams * cap * 4);
   RansTab t{cdf, cdf_stride, sizes, offsets};
   k_rans_encode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, 0, s>>>(sym, idx, n, n_streams, elem_stride, stream_stride, t,
-                                                                  scratch, cap, nwords);
+                                                                  (const RansEncSym*)enc_table, scratch, cap, nwords);
   PCC_LAUNCH_CHECK();
   k_rans_pack<<<1, 256, (size_t)n_streams * sizeof(long long), s>>>(scratch, cap, nwords, n_streams, (unsigned*)out, (long long*)d_nbytes);
   PCC_LAUNCH_CHECK();
@@ -331,16 +400,26 @@ extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, i
 extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n,
                                        int32_t n_streams, int64_t elem_stride, int64_t stream_stride,
                                        const int32_t* cdf, int32_t cdf_stride, const int32_t* sizes,
-                                       const int32_t* offsets, const uint16_t* lut, int32_t* sym_out, int32_t* d_status,
-                                       void* stream) {
+                                       const int32_t* offsets, const uint64_t* lut, int32_t lut_rows, int32_t* sym_out,
+                                       int32_t* d_status, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(data && cdf && sizes && offsets && sym_out && d_status, "pcc_rans_decode_streams: NULL array");
   PCC_REQUIRE(n >= 0 && n_streams >= 1 && n_streams <= 4096, "pcc_rans_decode_streams: bad stream count %d", n_streams);
   PCC_REQUIRE(nbytes >= 4 * (1 + (int64_t)n_streams) && nbytes % 4 == 0, "pcc_rans_decode_streams: truncated container");
   PCC_CHECK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
   RansTab t{cdf, cdf_stride, sizes, offsets};
-  k_rans_decode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, 0, s>>>((const unsigned*)data, nbytes / 4, idx, n, n_streams,
-                                                                  elem_stride, stream_stride, t, (const unsigned short*)lut, sym_out, d_status);
+  // LUT in LDS when it fits 128 KB (<= 64 table rows, the Gaussian scale table); one workgroup per 64 streams
+  const bool in_lds = lut && lut_rows > 0 && (size_t)lut_rows * 256 * 8 <= 128 * 1024;
+  const size_t lds = in_lds ? (size_t)lut_rows * 256 * 8 : 0;
+  static bool attr_set = false;
+  if (in_lds && !attr_set) {
+    PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_rans_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_set = true;
+  }
+  k_rans_decode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, lds, s>>>((const unsigned*)data, nbytes / 4, idx, n, n_streams,
+                                                                    elem_stride, stream_stride, t,
+                                                                    (const unsigned long long*)lut, in_lds ? lut_rows : 0,
+                                                                    sym_out, d_status);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

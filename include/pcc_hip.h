@@ -245,18 +245,20 @@ int pcc_rans_encode_host(const int32_t* h_sym, const int32_t* h_idx, int64_t n, 
 int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const int32_t* h_idx, int64_t n,
                          const int32_t* h_cdf, int32_t cdf_stride, const int32_t* h_sizes, const int32_t* h_offsets,
                          int32_t* h_sym);
-/* GPU, one stream per channel: stream s codes sym[s*stream_stride + i*elem_stride], i < n, with table row
- * idx[same index] (idx NULL: row s, the factorised prior).  Container (device buffer `out`, capacity
- * pcc_rans_container_max_bytes): u32 n_streams | u32 nwords[n_streams] | stream words ...  *d_nbytes: its size.
- * The reference's [1,C,N] channel-major symbol order is exactly the concatenation of these C streams. */
+/* GPU, n_streams independent streams over a row-major [n, channels] int32 symbol matrix: stream s covers the
+ * channels/n_streams (a power of two) adjacent channels starting at s*channels/n_streams, row by row, with table row
+ * idx[same element] (idx NULL: row = channel, the factorised prior).  Container (device buffer `out`, capacity
+ * pcc_rans_container_max_bytes(n*channels/n_streams, n_streams)): u32 n_streams | u32 nwords[n_streams] | stream words.
+ * With n_streams = channels the concatenation of the streams is the reference's [1,C,N] channel-major order.
+ * Each stream costs 12 bytes of framing: few streams for rate, many for speed. */
 int64_t pcc_rans_container_max_bytes(int64_t n, int32_t n_streams);
 size_t pcc_rans_streams_ws_bytes(int64_t n, int32_t n_streams);
 /* enc_table (nullable, device): division-free entries from pcc_rans_build_enc_table (16 bytes per (row, value),
  * layout [rows][cdf_stride]); NULL = 64-bit division per symbol.  Output bytes are identical either way. */
 int pcc_rans_build_enc_table(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
                              void* h_table /*16*rows*cdf_stride bytes*/);
-int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t n_streams,
-                            int64_t elem_stride, int64_t stream_stride, const int32_t* cdf, int32_t cdf_stride,
+int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t channels,
+                            int32_t n_streams, const int32_t* cdf, int32_t cdf_stride,
                             const int32_t* sizes, const int32_t* offsets, const void* enc_table, uint8_t* out,
                             int64_t* d_nbytes, void* ws, size_t ws_bytes, void* stream);
 /* decoder bucket table (host): lut[r*256 + b] = s | start<<16 | freq<<32 of the last s with cdf[r][s] <= 256*b; turns
@@ -265,8 +267,8 @@ int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, i
 int pcc_rans_build_lut(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
                        uint64_t* h_lut /*[rows*256]*/);
 /* *d_status != 0 after the kernel: malformed container */
-int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n, int32_t n_streams,
-                            int64_t elem_stride, int64_t stream_stride, const int32_t* cdf, int32_t cdf_stride,
+int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n, int32_t channels,
+                            int32_t n_streams, const int32_t* cdf, int32_t cdf_stride,
                             const int32_t* sizes, const int32_t* offsets, const uint64_t* lut /*nullable*/,
                             int32_t lut_rows, int32_t* sym_out, int32_t* d_status, void* stream);
 

@@ -170,6 +170,7 @@ def test_gpu_streams_equal_host_coder_per_channel():
     sym = np.rint(rng.standard_normal((rows, c)) * st[idx] * 1.3).astype(np.int32)
     sym[::41, 0] += 9000
     sym[5::77, 3] = -123456
+    gc.STREAM_SYMBOLS = 1                                           # one stream per channel
     data = gc.compress_rows(t(sym), t(idx))
     w = np.frombuffer(data, "<u4")
     assert w[0] == c
@@ -186,6 +187,19 @@ def test_gpu_streams_equal_host_coder_per_channel():
         assert stream == rans.encode(sym[:, ch], idx[:, ch], cdf, sizes, offs)
     back = gc.decompress_rows(data, rows, c, t(idx))
     assert np.array_equal(n(back), sym)
+    # grouped streams (several channels per stream, row by row) round-trip too and carry less framing
+    rows2, c2 = 300, 8
+    idx2 = rng.integers(0, 64, (rows2, c2)).astype(np.int32)
+    sym2 = np.rint(rng.standard_normal((rows2, c2)) * st[idx2]).astype(np.int32)
+    gc.STREAM_SYMBOLS = 1200
+    assert gc.n_streams(rows2, c2) == 2
+    d2 = gc.compress_rows(t(sym2), t(idx2))
+    assert np.frombuffer(d2, "<u4")[0] == 2
+    assert np.array_equal(n(gc.decompress_rows(d2, rows2, c2, t(idx2))), sym2)
+    host4 = np.frombuffer(d2, "<u4")
+    grp = sym2[:, :4].reshape(-1), idx2[:, :4].reshape(-1)           # stream 0 = channels 0..3, row by row
+    assert host4[3:3 + host4[1]].tobytes() == host._host_encode(grp[0].copy(), grp[1].copy())
+    gc.STREAM_SYMBOLS = 1
     # a truncated / corrupted container is reported, not decoded
     from unified_point_cloud_compression_amd import lib as L
     bad = bytearray(data)

@@ -82,6 +82,21 @@ class EntropyModel(nn.Module):
         if self._quantized_cdf.numel() == 0 or self._cdf_length.numel() == 0 or self._offset.numel() == 0:
             raise L.PccError("entropy tables are empty: call model.update() first (`evaluate.py:89`)")
 
+    STREAM_SYMBOLS = 4096   # target symbols per GPU stream: each stream costs 12 bytes of framing
+
+    @classmethod
+    def n_streams(cls, n, c):
+        """Number of GPU streams for an [n, c] symbol matrix: a power-of-two split of the channels, as many streams as
+        keep >= STREAM_SYMBOLS symbols each (rate), at most one per channel (speed).  Encoder and decoder both derive
+        it from (n, c), so it is not transmitted."""
+        ns = c
+        while ns % 2 == 0 and n * (c // ns) < cls.STREAM_SYMBOLS:
+            g = c // (ns // 2)
+            if g & (g - 1):            # group size must stay a power of two
+                break
+            ns //= 2
+        return ns
+
     # ---- coding of [N, C] int32 symbol rows (the layout the kernels produce) -------------------------------
     def compress_rows(self, sym, idx=None):
         """sym [N,C] int32 (device) with table rows idx [N,C] (None: row = channel) -> bytes."""
@@ -96,11 +111,13 @@ class EntropyModel(nn.Module):
                  else np.repeat(np.arange(c, dtype=np.int32), n))
             return self._host_encode(s, np.ascontiguousarray(i, np.int32))
         lib = L.load()
-        cap = lib.pcc_rans_container_max_bytes(n, c)
+        ns = self.n_streams(n, c)
+        per = n * (c // ns)
+        cap = lib.pcc_rans_container_max_bytes(per, ns)
         out = torch.empty(cap, dtype=torch.uint8, device=dev)
         nb = torch.zeros(1, dtype=torch.int64, device=dev)
-        ws = L.workspace(lib.pcc_rans_streams_ws_bytes(n, c), dev)
-        L.call("pcc_rans_encode_streams", L.ptr(sym), L.ptr(idx.contiguous()) if idx is not None else None, n, c, c, 1,
+        ws = L.workspace(lib.pcc_rans_streams_ws_bytes(per, ns), dev)
+        L.call("pcc_rans_encode_streams", L.ptr(sym), L.ptr(idx.contiguous()) if idx is not None else None, n, c, ns,
                L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._enc_table(dev)), L.ptr(out), L.ptr(nb),
                L.ptr(ws), ws.numel(), L.stream())
         return out[:int(nb.item())].cpu().numpy().tobytes()
@@ -119,8 +136,8 @@ class EntropyModel(nn.Module):
         sym = torch.empty((n, c), dtype=torch.int32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         L.call("pcc_rans_decode_streams", L.ptr(buf), buf.numel(), L.ptr(idx.contiguous()) if idx is not None else None,
-               n, c, c, 1, L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._lut(dev)), cdf.shape[0],
-               L.ptr(sym), L.ptr(status), L.stream())
+               n, c, self.n_streams(n, c), L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._lut(dev)),
+               cdf.shape[0], L.ptr(sym), L.ptr(status), L.stream())
         st = int(status.item())
         if st != 0:
             raise L.PccError(f"malformed rANS container (status {st})")

@@ -86,10 +86,14 @@ RANS_HD void r_put_bypass(unsigned long long& x, unsigned*& ptr, unsigned raw) {
   for (int j = 0; j < n15; ++j) r_put_bits(x, ptr, R_MAXB);
 }
 
-RANS_HD unsigned* r_encode(const int* sym, const int* idx, int fixed_idx, long long n, long long stride, RansTab t,
+// Symbol j of a stream sits at (j >> gl) * stride + (j & (2^gl - 1)) relative to the stream's first element: the
+// stream covers 2^gl adjacent channels of a row-major [rows, stride] matrix, row by row (gl = 0: one column).
+// Table row of symbol j: idx[same address], or ch0 + (j & (2^gl - 1)) when idx is NULL (factorised prior).
+RANS_HD unsigned* r_encode(const int* sym, const int* idx, int ch0, long long n, int gl, long long stride, RansTab t,
                            const RansEncSym* enc, unsigned* end) {
   unsigned long long x = R_L;
   unsigned* ptr = end;
+  const long long gm = (1ll << gl) - 1;
   for (long long base = n; base > 0; base -= RB) {
     int value[RB], ci[RB];
     unsigned raw[RB], start[RB], freq[RB];
@@ -97,8 +101,9 @@ RANS_HD unsigned* r_encode(const int* sym, const int* idx, int fixed_idx, long l
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
       const long long i = base - 1 - u;
-      ci[u] = (i >= 0) ? (idx ? idx[i * stride] : fixed_idx) : -1;
-      value[u] = (i >= 0) ? sym[i * stride] : 0;
+      const long long a = (i >> gl) * stride + (i & gm);
+      ci[u] = (i >= 0) ? (idx ? idx[a] : ch0 + (int)(i & gm)) : -1;
+      value[u] = (i >= 0) ? sym[a] : 0;
     }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
@@ -147,14 +152,18 @@ RANS_HD unsigned r_get_bits(unsigned long long& x, const unsigned*& ptr) {
 // bucket table: lut[row*256 + (cum >> 8)] = last s with cdf[s] <= (cum & ~255), the start of a short forward scan;
 // without it each symbol costs a binary search of dependent loads.
 // fat LUT entry: s | start << 16 | freq << 32 of the first symbol of bucket (cum >> 8)
-RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int fixed_idx, long long n, long long stride,
+RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int ch0, long long n, int gl, long long stride,
                                  RansTab t, const unsigned long long* lut, int* out) {
   unsigned long long x = (unsigned long long)ptr[0] | ((unsigned long long)ptr[1] << 32);
   ptr += 2;
+  const long long gm = (1ll << gl) - 1;
   for (long long base = 0; base < n; base += RB) {
     int ci[RB], size[RB], off[RB];
 #pragma unroll
-    for (int u = 0; u < RB; ++u) ci[u] = (base + u < n) ? (idx ? idx[(base + u) * stride] : fixed_idx) : -1;
+    for (int u = 0; u < RB; ++u) {
+      const long long j = base + u;
+      ci[u] = (j < n) ? (idx ? idx[(j >> gl) * stride + (j & gm)] : ch0 + (int)(j & gm)) : -1;
+    }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
       size[u] = ci[u] >= 0 ? t.sizes[ci[u]] : 0;
@@ -193,7 +202,7 @@ RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int fixed_
         value = (int)(raw >> 1);
         value = (raw & 1) ? -value - 1 : value + max_value;
       }
-      out[(base + u) * stride] = value + off[u];
+      out[((base + u) >> gl) * stride + ((base + u) & gm)] = value + off[u];
     }
   }
   return ptr;
@@ -286,7 +295,7 @@ extern "C" int pcc_rans_encode_host(const int32_t* h_sym, const int32_t* h_idx, 
   std::vector<unsigned> buf((size_t)(2 * n + 4));
   RansTab t{h_cdf, cdf_stride, h_sizes, h_offsets};
   unsigned* end = buf.data() + buf.size();
-  unsigned* p = r_encode(h_sym, h_idx, 0, n, 1, t, nullptr, end);
+  unsigned* p = r_encode(h_sym, h_idx, 0, n, 0, 1, t, nullptr, end);
   *h_nbytes = (int64_t)(end - p) * 4;
   memcpy(h_out, p, (size_t)*h_nbytes);
   return PCC_OK;
@@ -300,7 +309,7 @@ extern "C" int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const
   std::vector<unsigned> buf((size_t)nbytes / 4 + 4, 0u);     // zero padding: a corrupt stream cannot read out of bounds far
   memcpy(buf.data(), h_data, (size_t)nbytes);
   RansTab t{h_cdf, cdf_stride, h_sizes, h_offsets};
-  r_decode(buf.data(), h_idx, 0, n, 1, t, nullptr, h_sym);
+  r_decode(buf.data(), h_idx, 0, n, 0, 1, t, nullptr, h_sym);
   return PCC_OK;
 }
 
@@ -309,14 +318,15 @@ extern "C" int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const
 //   container: u32 n_streams | u32 nwords[n_streams] | words of stream 0 | words of stream 1 | ...
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_rans_encode(const int* __restrict__ sym, const int* __restrict__ idx, long long n,
-                                                    int n_streams, long long es, long long ss, RansTab t,
+                                                    int n_streams, int gl, long long row_stride, RansTab t,
                                                     const RansEncSym* __restrict__ enc,
                                                     unsigned* __restrict__ scratch, long long cap_words,
                                                     int* __restrict__ nwords) {
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= n_streams) return;
   unsigned* end = scratch + (long long)(s + 1) * cap_words;
-  unsigned* p = r_encode(sym + s * ss, idx ? idx + s * ss : nullptr, s, n, es, t, enc, end);
+  const long long ch0 = (long long)s << gl;
+  unsigned* p = r_encode(sym + ch0, idx ? idx + ch0 : nullptr, (int)ch0, n << gl, gl, row_stride, t, enc, end);
   nwords[s] = (int)(end - p);
 }
 
@@ -345,7 +355,7 @@ __global__ void __launch_bounds__(256) k_rans_pack(const unsigned* __restrict__ 
 
 __global__ void __launch_bounds__(64) k_rans_decode(const unsigned* __restrict__ data, long long nwords_total,
                                                     const int* __restrict__ idx, long long n, int n_streams,
-                                                    long long es, long long ss, RansTab t,
+                                                    int gl, long long row_stride, RansTab t,
                                                     const unsigned long long* __restrict__ lut, int lut_rows_lds,
                                                     int* __restrict__ out, int* __restrict__ status) {
   extern __shared__ unsigned long long lut_s[];
@@ -361,10 +371,12 @@ __global__ void __launch_bounds__(64) k_rans_decode(const unsigned* __restrict__
   for (int i = 0; i < s; ++i) off += data[1 + i];
   const long long len = data[1 + s];
   if (off + len > nwords_total || len < 2) { *status = 2; return; }
-  const unsigned* p = r_decode(data + off, idx ? idx + s * ss : nullptr, s, n, es, t, lut, out + s * ss);
+  const long long ch0 = (long long)s << gl;
+  const unsigned* p = r_decode(data + off, idx ? idx + ch0 : nullptr, (int)ch0, n << gl, gl, row_stride, t, lut, out + ch0);
   if (p - (data + off) > len) *status = 3;      // read past its own stream: corrupt input
 }
 
+// n = symbols per stream
 extern "C" int64_t pcc_rans_container_max_bytes(int64_t n, int32_t n_streams) {
   return 4 * (1 + (int64_t)n_streams) + (int64_t)n_streams * pcc_rans_max_bytes(n);
 }
@@ -373,23 +385,34 @@ extern "C" size_t pcc_rans_streams_ws_bytes(int64_t n, int32_t n_streams) {
   return (size_t)n_streams * (size_t)(2 * n + 4) * 4 + (size_t)n_streams * 4 + 1024;
 }
 
-extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t n_streams,
-                                       int64_t elem_stride, int64_t stream_stride, const int32_t* cdf,
+static int group_log2(int channels, int n_streams) {
+  if (n_streams < 1 || channels % n_streams) return -1;
+  const int g = channels / n_streams;
+  int l = 0;
+  while ((1 << l) < g) ++l;
+  return (1 << l) == g ? l : -1;
+}
+
+extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t channels,
+                                       int32_t n_streams, const int32_t* cdf,
                                        int32_t cdf_stride, const int32_t* sizes, const int32_t* offsets,
                                        const void* enc_table, uint8_t* out, int64_t* d_nbytes, void* ws,
                                        size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(sym && cdf && sizes && offsets && out && d_nbytes && ws, "pcc_rans_encode_streams: NULL array");
   PCC_REQUIRE(n >= 0 && n_streams >= 1 && n_streams <= 4096, "pcc_rans_encode_streams: bad stream count %d", n_streams);
-  if (ws_bytes < pcc_rans_streams_ws_bytes(n, n_streams)) {
+  const int gl = group_log2(channels, n_streams);
+  PCC_REQUIRE(gl >= 0, "pcc_rans_encode_streams: %d channels do not split into %d power-of-two groups", channels, n_streams);
+  const int64_t per_stream = n << gl;
+  if (ws_bytes < pcc_rans_streams_ws_bytes(per_stream, n_streams)) {
     pcc_set_error("pcc_rans_encode_streams: workspace too small");
     return PCC_EWS;
   }
-  const long long cap = 2 * n + 4;
+  const long long cap = 2 * per_stream + 4;
   unsigned* scratch = (unsigned*)ws;
   int* nwords = (int*)((char*)ws + (size_t)n_streams * cap * 4);
   RansTab t{cdf, cdf_stride, sizes, offsets};
-  k_rans_encode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, 0, s>>>(sym, idx, n, n_streams, elem_stride, stream_stride, t,
+  k_rans_encode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, 0, s>>>(sym, idx, n, n_streams, gl, channels, t,
                                                                   (const RansEncSym*)enc_table, scratch, cap, nwords);
   PCC_LAUNCH_CHECK();
   k_rans_pack<<<1, 256, (size_t)n_streams * sizeof(long long), s>>>(scratch, cap, nwords, n_streams, (unsigned*)out, (long long*)d_nbytes);
@@ -398,7 +421,7 @@ extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, i
 }
 
 extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n,
-                                       int32_t n_streams, int64_t elem_stride, int64_t stream_stride,
+                                       int32_t channels, int32_t n_streams,
                                        const int32_t* cdf, int32_t cdf_stride, const int32_t* sizes,
                                        const int32_t* offsets, const uint64_t* lut, int32_t lut_rows, int32_t* sym_out,
                                        int32_t* d_status, void* stream) {
@@ -406,6 +429,8 @@ extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, cons
   PCC_REQUIRE(data && cdf && sizes && offsets && sym_out && d_status, "pcc_rans_decode_streams: NULL array");
   PCC_REQUIRE(n >= 0 && n_streams >= 1 && n_streams <= 4096, "pcc_rans_decode_streams: bad stream count %d", n_streams);
   PCC_REQUIRE(nbytes >= 4 * (1 + (int64_t)n_streams) && nbytes % 4 == 0, "pcc_rans_decode_streams: truncated container");
+  const int gl = group_log2(channels, n_streams);
+  PCC_REQUIRE(gl >= 0, "pcc_rans_decode_streams: %d channels do not split into %d power-of-two groups", channels, n_streams);
   PCC_CHECK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
   RansTab t{cdf, cdf_stride, sizes, offsets};
   // LUT in LDS when it fits 128 KB (<= 64 table rows, the Gaussian scale table); one workgroup per 64 streams
@@ -417,7 +442,7 @@ extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, cons
     attr_set = true;
   }
   k_rans_decode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, lds, s>>>((const unsigned*)data, nbytes / 4, idx, n, n_streams,
-                                                                    elem_stride, stream_stride, t,
+                                                                    gl, channels, t,
                                                                     (const unsigned long long*)lut, in_lds ? lut_rows : 0,
                                                                     sym_out, d_status);
   PCC_LAUNCH_CHECK();

@@ -266,7 +266,7 @@ int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, i
  * in pcc_rans_decode_streams (binary search). */
 int pcc_rans_build_lut(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
                        uint64_t* h_lut /*[rows*256]*/);
-/* *d_status != 0 after the kernel: malformed container */
+/* *d_status != 0 after the kernel: malformed container.  `data` must be readable 4 bytes past nbytes (look-ahead). */
 int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n, int32_t channels,
                             int32_t n_streams, const int32_t* cdf, int32_t cdf_stride,
                             const int32_t* sizes, const int32_t* offsets, const uint64_t* lut /*nullable*/,

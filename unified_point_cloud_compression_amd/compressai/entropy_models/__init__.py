@@ -82,15 +82,14 @@ class EntropyModel(nn.Module):
         if self._quantized_cdf.numel() == 0 or self._cdf_length.numel() == 0 or self._offset.numel() == 0:
             raise L.PccError("entropy tables are empty: call model.update() first (`evaluate.py:89`)")
 
-    STREAM_SYMBOLS = 4096   # target symbols per GPU stream: each stream costs 12 bytes of framing
+    STREAM_SYMBOLS = 1536   # target symbols per GPU stream: each stream costs 12 bytes of framing
 
-    @classmethod
-    def n_streams(cls, n, c):
+    def n_streams(self, n, c):
         """Number of GPU streams for an [n, c] symbol matrix: a power-of-two split of the channels, as many streams as
         keep >= STREAM_SYMBOLS symbols each (rate), at most one per channel (speed).  Encoder and decoder both derive
         it from (n, c), so it is not transmitted."""
         ns = c
-        while ns % 2 == 0 and n * (c // ns) < cls.STREAM_SYMBOLS:
+        while ns % 2 == 0 and n * (c // ns) < self.STREAM_SYMBOLS:
             g = c // (ns // 2)
             if g & (g - 1):            # group size must stay a power of two
                 break
@@ -132,10 +131,10 @@ class EntropyModel(nn.Module):
                  else np.repeat(np.arange(c, dtype=np.int32), n))
             s = self._host_decode(data, np.ascontiguousarray(i, np.int32))
             return torch.from_numpy(s.reshape(c, n).T.copy()).to(dev)
-        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        buf = torch.frombuffer(bytearray(data) + bytearray(8), dtype=torch.uint8).to(dev)   # decoder looks one word ahead
         sym = torch.empty((n, c), dtype=torch.int32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        L.call("pcc_rans_decode_streams", L.ptr(buf), buf.numel(), L.ptr(idx.contiguous()) if idx is not None else None,
+        L.call("pcc_rans_decode_streams", L.ptr(buf), len(data), L.ptr(idx.contiguous()) if idx is not None else None,
                n, c, self.n_streams(n, c), L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._lut(dev)),
                cdf.shape[0], L.ptr(sym), L.ptr(status), L.stream())
         st = int(status.item())

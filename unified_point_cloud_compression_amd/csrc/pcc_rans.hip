@@ -141,10 +141,12 @@ RANS_HD unsigned* r_encode(const int* sym, const int* idx, int ch0, long long n,
   return ptr;
 }
 
-RANS_HD unsigned r_get_bits(unsigned long long& x, const unsigned*& ptr) {
+// The decoder keeps the next 32-bit word in a register (`nw`), re-loading right after it is consumed, so the
+// renormalisation read is off the state's critical path.
+RANS_HD unsigned r_get_bits(unsigned long long& x, const unsigned*& ptr, unsigned& nw) {
   const unsigned v = (unsigned)(x & R_MAXB);
   x >>= R_BYP;
-  if (x < R_L) x = (x << 32) | *ptr++;
+  if (x < R_L) { x = (x << 32) | nw; nw = *++ptr; }
   return v;
 }
 
@@ -156,6 +158,7 @@ RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int ch0, l
                                  RansTab t, const unsigned long long* lut, int* out) {
   unsigned long long x = (unsigned long long)ptr[0] | ((unsigned long long)ptr[1] << 32);
   ptr += 2;
+  unsigned nw = *ptr;                                 // look-ahead word (the buffer is padded by one word)
   const long long gm = (1ll << gl) - 1;
   for (long long base = 0; base < n; base += RB) {
     int ci[RB], size[RB], off[RB];
@@ -191,14 +194,14 @@ RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int ch0, l
         start = (unsigned)c[lo]; freq = (unsigned)(c[lo + 1] - c[lo]);
       }
       x = (unsigned long long)freq * (x >> R_PREC) + cum - start;
-      if (x < R_L) x = (x << 32) | *ptr++;
+      if (x < R_L) { x = (x << 32) | nw; nw = *++ptr; }
       int value = lo;
       if (value == max_value) {
-        unsigned val = r_get_bits(x, ptr);
+        unsigned val = r_get_bits(x, ptr, nw);
         int nb = (int)val;
-        while (val == R_MAXB) { val = r_get_bits(x, ptr); nb += (int)val; }
+        while (val == R_MAXB) { val = r_get_bits(x, ptr, nw); nb += (int)val; }
         unsigned raw = 0;
-        for (int j = 0; j < nb; ++j) raw |= r_get_bits(x, ptr) << (j * R_BYP);
+        for (int j = 0; j < nb; ++j) raw |= r_get_bits(x, ptr, nw) << (j * R_BYP);
         value = (int)(raw >> 1);
         value = (raw & 1) ? -value - 1 : value + max_value;
       }
@@ -317,17 +320,66 @@ extern "C" int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const
 // GPU: one stream per channel
 //   container: u32 n_streams | u32 nwords[n_streams] | words of stream 0 | words of stream 1 | ...
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_rans_encode(const int* __restrict__ sym, const int* __restrict__ idx, long long n,
-                                                    int n_streams, int gl, long long row_stride, RansTab t,
-                                                    const RansEncSym* __restrict__ enc,
+// Pass 1 (one thread per symbol, fully parallel): resolve every symbol to its division-free encoder entry and its
+// bypass payload, laid out [position in stream][stream] so that the sequential coder's reads are lane-contiguous.
+__global__ void __launch_bounds__(256) k_rans_prepare(const int* __restrict__ sym, const int* __restrict__ idx, long long n,
+                                                      int channels, int n_streams, int gl, RansTab t,
+                                                      const RansEncSym* __restrict__ enc, RansEncSym* __restrict__ pre_e,
+                                                      unsigned* __restrict__ pre_r) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * channels) return;
+  const long long i = e / channels;
+  const int ch = (int)(e - i * channels);
+  const int ci = idx ? idx[e] : ch;
+  const int max_value = t.sizes[ci] - 2;
+  int v = sym[e] - t.offsets[ci];
+  unsigned raw = 0xFFFFFFFFu;
+  if (v < 0) { raw = (unsigned)(-2 * v - 1); v = max_value; }
+  else if (v >= max_value) { raw = (unsigned)(2 * (v - max_value)); v = max_value; }
+  const long long j = (i << gl) + (ch & ((1 << gl) - 1));
+  const long long o = j * n_streams + (ch >> gl);
+  pre_e[o] = enc[(long long)ci * t.stride + v];
+  pre_r[o] = raw;
+}
+
+// Pass 2 (one lane per stream): the state recurrence, fed from the prepared entries.  Batches of RB entries are
+// loaded one batch ahead of their use, so the only serial dependence left is the coder state itself.
+__global__ void __launch_bounds__(64) k_rans_encode(const RansEncSym* __restrict__ pre_e, const unsigned* __restrict__ pre_r,
+                                                    long long n_per_stream, int n_streams,
                                                     unsigned* __restrict__ scratch, long long cap_words,
                                                     int* __restrict__ nwords) {
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= n_streams) return;
   unsigned* end = scratch + (long long)(s + 1) * cap_words;
-  const long long ch0 = (long long)s << gl;
-  unsigned* p = r_encode(sym + ch0, idx ? idx + ch0 : nullptr, (int)ch0, n << gl, gl, row_stride, t, enc, end);
-  nwords[s] = (int)(end - p);
+  unsigned* ptr = end;
+  unsigned long long x = R_L;
+  RansEncSym ea[RB], eb[RB];
+  unsigned ra[RB], rb[RB];
+  auto load = [&](long long base, RansEncSym (&e)[RB], unsigned (&r)[RB]) {
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const long long j = base - 1 - u;
+      r[u] = 0xFFFFFFFEu;                                     // marker: past the start of the stream
+      if (j >= 0) { e[u] = pre_e[j * n_streams + s]; r[u] = pre_r[j * n_streams + s]; }
+    }
+  };
+  load(n_per_stream, ea, ra);
+  for (long long base = n_per_stream; base > 0; base -= RB) {
+    load(base - RB, eb, rb);                                  // next batch in flight while this one is coded
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      if (ra[u] != 0xFFFFFFFEu) {
+        if (ra[u] != 0xFFFFFFFFu) r_put_bypass(x, ptr, ra[u]);
+        r_put_sym(x, ptr, ea[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) { ea[u] = eb[u]; ra[u] = rb[u]; }
+  }
+  ptr -= 2;
+  ptr[0] = (unsigned)x;
+  ptr[1] = (unsigned)(x >> 32);
+  nwords[s] = (int)(end - ptr);
 }
 
 __global__ void __launch_bounds__(256) k_rans_pack(const unsigned* __restrict__ scratch, long long cap_words,
@@ -382,7 +434,9 @@ extern "C" int64_t pcc_rans_container_max_bytes(int64_t n, int32_t n_streams) {
 }
 
 extern "C" size_t pcc_rans_streams_ws_bytes(int64_t n, int32_t n_streams) {
-  return (size_t)n_streams * (size_t)(2 * n + 4) * 4 + (size_t)n_streams * 4 + 1024;
+  // word scratch per stream + stream lengths + prepared entries (16 B) and bypass payloads (4 B) per symbol
+  return (size_t)n_streams * (size_t)(2 * n + 4) * 4 + pcc_align_up((size_t)n_streams * 4) +
+         pcc_align_up((size_t)n_streams * (size_t)n * 16) + pcc_align_up((size_t)n_streams * (size_t)n * 4) + 1024;
 }
 
 static int group_log2(int channels, int n_streams) {
@@ -400,6 +454,7 @@ extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, i
                                        size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(sym && cdf && sizes && offsets && out && d_nbytes && ws, "pcc_rans_encode_streams: NULL array");
+  PCC_REQUIRE(enc_table, "pcc_rans_encode_streams: enc_table is required (pcc_rans_build_enc_table)");
   PCC_REQUIRE(n >= 0 && n_streams >= 1 && n_streams <= 4096, "pcc_rans_encode_streams: bad stream count %d", n_streams);
   const int gl = group_log2(channels, n_streams);
   PCC_REQUIRE(gl >= 0, "pcc_rans_encode_streams: %d channels do not split into %d power-of-two groups", channels, n_streams);
@@ -409,11 +464,18 @@ extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, i
     return PCC_EWS;
   }
   const long long cap = 2 * per_stream + 4;
-  unsigned* scratch = (unsigned*)ws;
-  int* nwords = (int*)((char*)ws + (size_t)n_streams * cap * 4);
+  char* p = (char*)ws;
+  unsigned* scratch = (unsigned*)p;     p += (size_t)n_streams * cap * 4;
+  int* nwords = (int*)p;                p += pcc_align_up((size_t)n_streams * 4);
+  RansEncSym* pre_e = (RansEncSym*)p;   p += pcc_align_up((size_t)n_streams * (size_t)per_stream * 16);
+  unsigned* pre_r = (unsigned*)p;
   RansTab t{cdf, cdf_stride, sizes, offsets};
-  k_rans_encode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, 0, s>>>(sym, idx, n, n_streams, gl, channels, t,
-                                                                  (const RansEncSym*)enc_table, scratch, cap, nwords);
+  if (n > 0) {
+    k_rans_prepare<<<(unsigned)pcc_cdiv(n * channels, 256), 256, 0, s>>>(sym, idx, n, channels, n_streams, gl, t,
+                                                                        (const RansEncSym*)enc_table, pre_e, pre_r);
+    PCC_LAUNCH_CHECK();
+  }
+  k_rans_encode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, 0, s>>>(pre_e, pre_r, per_stream, n_streams, scratch, cap, nwords);
   PCC_LAUNCH_CHECK();
   k_rans_pack<<<1, 256, (size_t)n_streams * sizeof(long long), s>>>(scratch, cap, nwords, n_streams, (unsigned*)out, (long long*)d_nbytes);
   PCC_LAUNCH_CHECK();

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""HBM traffic of the MFMA convolution kernels from rocprofv3 PMC passes (MI355X_MICROARCH.md 'HBM' section):
+FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots); both count KiB; on gfx950 FETCH_SIZE reports exactly half
+of the bytes of a wide coalesced streaming read, so the read side is doubled (an upper-bound correction for the
+gather-heavy kernels, whose 16-byte row pieces are served at sector granularity).
+
+usage (on the GPU box, from the repo root):
+  python tools/pmc_traffic.py collect gpurun_out/pmc        # runs two rocprofv3 passes of bench.py
+  python tools/pmc_traffic.py parse   gpurun_out/pmc profiles/r01_pmc_traffic.json
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+KERNELS = ("k_conv_mfma", "k_conv_wave16")
+BENCH = ["python3", "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--coder", "symbols"]
+
+
+def collect(out):
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, ctr)
+        os.makedirs(d, exist_ok=True)
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + BENCH
+        print(" ".join(cmd), flush=True)
+        with open(os.path.join(d, "bench.log"), "w") as f:
+            subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, check=True, env=dict(os.environ, TMPDIR="/tmp"))
+
+
+def parse(out, dst):
+    res = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = glob.glob(os.path.join(out, ctr, "**", "*counter_collection.csv"), recursive=True)
+        assert files, f"no counter_collection csv under {out}/{ctr}"
+        tot, launches = 0.0, 0
+        for r in csv.DictReader(open(files[0])):
+            name = r["Kernel_Name"]
+            conv = "k_conv_wave16" in name or ("k_conv_mfma<" in name and ", 0>(" in name)   # MODE_CONV instances only
+            if r["Counter_Name"] == ctr and conv:
+                tot += float(r["Counter_Value"])
+                launches += 1
+        res[ctr] = {"kib_total": tot, "launches": launches}
+    n = res["FETCH_SIZE"]["launches"]
+    assert n == res["WRITE_SIZE"]["launches"] and n > 0
+    read = 2.0 * res["FETCH_SIZE"]["kib_total"] * 1024 / n      # gfx950: FETCH_SIZE reads half of wide streaming reads
+    write = res["WRITE_SIZE"]["kib_total"] * 1024 / n
+    rec = {"kernel": "k_conv_mfma<*,MODE_CONV> + k_conv_wave16 (pcc_conv_fwd / pcc_convt_fwd GEMM)", "launches": n,
+           "hbm_read_bytes_per_launch": read, "hbm_write_bytes_per_launch": write,
+           "hbm_bytes_per_launch": read + write,
+           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), KiB*1024, FETCH x2 (gfx950)",
+           "command": " ".join(BENCH)}
+    json.dump(rec, open(dst, "w"), indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "collect":
+        collect(sys.argv[2])
+    else:
+        parse(sys.argv[2], sys.argv[3])

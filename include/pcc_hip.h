@@ -106,7 +106,9 @@ int pcc_coords_expand_csr(const int64_t* keys, int64_t n, int32_t kernel_size, i
  *   hdr  int32[PCC_MAP_HDR_INTS]  segment table (written by the build kernels)
  *   nbr  int32[...]               per segment a [k_count][pos_count] table of input rows (-1 none)
  *   rows int32[n_out] or NULL     output row of each position (NULL: position == output row)
- * conv:       one segment, all K offsets, positions = output rows.
+ * conv:       one segment, all K offsets, positions = output rows; when `rows` is given (non-transposed build) the
+ *             positions are the output rows in Morton (Z-curve) order of their coordinates and rows[] receives that
+ *             permutation: tiles of consecutive positions are compact 3-D blobs (L1/L2 locality of the gathers).
  * transposed: outputs are grouped by their residue class modulo the up-sampling stride
  *             (stride^3 segments); a class only lists the offsets that can reach it.
  * ---------------------------------------------------------------------------------------- */
@@ -118,7 +120,7 @@ size_t pcc_map_ws_bytes(int64_t n_out);
  * *d_pairs (device int64, nullable) receives the number of valid (in,out) pairs. */
 int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys, int64_t n_out,
                          int32_t kernel_size, int32_t step, int32_t stride, int32_t transposed,
-                         int32_t* hdr, int32_t* nbr, int32_t* rows /*transposed only*/,
+                         int32_t* hdr, int32_t* nbr, int32_t* rows /*transposed: required; conv: optional (Morton)*/,
                          int64_t* d_pairs, const uint64_t* grid_bits /*nullable*/, const int32_t* grid_rank,
                          const int32_t* h_grid, void* ws, size_t ws_bytes, void* stream);
 

@@ -38,6 +38,18 @@ def test_conv_map_bit_exact(ks, stride, ts, lookup_mode):
     want = co.kernel_map(keys, out_keys, ks, ts)
     assert np.array_equal(n(m.dense()), want)
     assert cs.kernel_map(out, ks) is m                    # cached per (in set, out set, kernel)
+    mz = cs.kernel_map(out, ks, morton=True)              # Z-curve visiting order: same map, positions permuted
+    assert np.array_equal(n(mz.dense()), want)
+    rows = n(mz.rows)[:out.n]
+    assert np.array_equal(np.sort(rows), np.arange(out.n))
+    C = co.unpack_keys(out_keys)[rows].astype(np.int64)
+    code = np.zeros(len(C), dtype=np.int64)
+    g = C[:, 1:] + (1 << 15)
+    for bit in range(16):
+        for ax, sh in ((3, 0), (2, 1), (1, 2)):
+            code |= ((C[:, ax] + (1 << 15)) // (ts * stride if stride > 1 else ts) >> bit & 1) << (3 * bit + sh)
+    code |= C[:, 0] << 48
+    assert np.all(np.diff(code) > 0)                      # positions ascend along the Z-curve (batch major)
 
 
 @pytest.mark.parametrize("ks,ts_in", [(5, 2), (2, 2), (2, 32), (5, 8)])
@@ -69,7 +81,7 @@ def test_conv_features_k3(cin, cout):
     f = rng.standard_normal((len(keys), cin)).astype(np.float32)
     W = (rng.standard_normal((27, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32)
     b = rng.standard_normal((1, cout)).astype(np.float32)
-    m = cs.kernel_map(cs, 3)
+    m = cs.kernel_map(cs, 3, morton=(cin + cout) % 2 == 1)     # half of the shapes run on a Z-curve ordered map
     pk = S.PackedConv().get(torch.nn.Parameter(t(W)))
     for act, fn in ((L.ACT_NONE, lambda v: v), (L.ACT_RELU, ops.relu), (L.ACT_LEAKY, ops.leaky_relu)):
         got = S.conv_forward(t(f), pk, t(b), 27, cin, cout, m, len(keys), act)

@@ -101,16 +101,43 @@ __global__ void __launch_bounds__(1024) k_sum_counts(const int* __restrict__ c, 
 // conv: thread per (k, o), o fastest
 __global__ void __launch_bounds__(256) k_map_conv(PccGrid grid, const int64_t* __restrict__ in_keys, int n_in,
                                                   const int64_t* __restrict__ out_keys, int64_t n_out, int ks,
-                                                  int step, int* __restrict__ nbr,
+                                                  int step, const int* __restrict__ rows, int* __restrict__ nbr,
                                                   int* __restrict__ d_pairs) {
-  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // position
   const int k = blockIdx.y;
   int idx = -1;
   if (o < n_out) {
-    idx = pcc_lookup(grid, in_keys, n_in, out_keys[o] + pcc_delta_of(k, ks, step));
+    const int64_t key = out_keys[rows ? rows[o] : o];
+    idx = pcc_lookup(grid, in_keys, n_in, key + pcc_delta_of(k, ks, step));
     nbr[(int64_t)k * n_out + o] = idx;
   }
   count_pairs(idx >= 0, d_pairs);
+}
+
+// Morton (Z-curve) code of the lattice cell of every output row: bits of z, y, x interleaved (z lowest).  Tiles of
+// consecutive positions in this order are compact 3-D blobs, so the 27 (or 125) neighbour gathers of a tile hit a
+// few hundred distinct rows instead of a few thousand, and consecutive tiles share them (L1 / L2 locality).
+__device__ inline uint64_t spread3(uint32_t v) {     // 16 bits -> every third bit
+  uint64_t x = v & 0xFFFFull;
+  x = (x | (x << 32)) & 0x00FF00000000FFFFull;
+  x = (x | (x << 16)) & 0x00FF0000FF0000FFull;
+  x = (x | (x << 8)) & 0xF00F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x30C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x9249249249249249ull;
+  return x;
+}
+
+__global__ void k_morton(const int64_t* __restrict__ keys, int64_t n, int log2_step, uint64_t* __restrict__ code) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t k = keys[i];
+  const uint32_t x = (uint32_t)((k >> 32) & 0xFFFF) >> log2_step;
+  const uint32_t y = (uint32_t)((k >> 16) & 0xFFFF) >> log2_step;
+  const uint32_t z = (uint32_t)(k & 0xFFFF) >> log2_step;
+  const uint64_t b = (uint64_t)(k >> 48) & 0xFFFF;
+  // batch index stays the major key (48 bits of interleaved coordinates below it); 16-bit batch ids would overflow
+  // 64 bits together with 48 coordinate bits only for >= 2^16 batches, which the key format excludes
+  code[i] = (b << 48) | spread3(z) | (spread3(y) << 1) | (spread3(x) << 2);
 }
 
 // transposed: class id per output row (as a sortable 64-bit key)
@@ -242,7 +269,20 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
     if (n_out == 0) return PCC_OK;
     PCC_REQUIRE(in_keys && out_keys && nbr, "pcc_kernel_map_build: NULL array");
     dim3 gdim((unsigned)pcc_cdiv(n_out, 256), (unsigned)K);
-    k_map_conv<<<gdim, 256, 0, s>>>(grid, in_keys, (int)n_in, out_keys, n_out, kernel_size, step, nbr, block_counts);
+    const int* morton_rows = nullptr;
+    if (rows) {   // conv map with positions in Morton (Z-curve) order of the output coordinates
+      PCC_REQUIRE(ws && ws_bytes >= pcc_map_ws_bytes(n_out), "pcc_kernel_map_build: workspace too small");
+      char* p = (char*)ws + bc_bytes;
+      uint64_t* code = (uint64_t*)p;         p += pcc_align_up((size_t)n_out * 8);
+      uint64_t* code_sorted = (uint64_t*)p;  p += pcc_align_up((size_t)n_out * 8) + 1024;
+      k_morton<<<(unsigned)pcc_cdiv(n_out, 256), 256, 0, s>>>(out_keys, n_out, ilog2(step), code);
+      PCC_LAUNCH_CHECK();
+      PCC_TRY(pcc_sort_keys((const int64_t*)code, n_out, 0x0000FFFFFFFFFFFFull, (int64_t*)code_sorted, rows, p,
+                            ws_bytes - (size_t)(p - (char*)ws), s));
+      morton_rows = rows;
+    }
+    k_map_conv<<<gdim, 256, 0, s>>>(grid, in_keys, (int)n_in, out_keys, n_out, kernel_size, step, morton_rows, nbr,
+                                    block_counts);
     PCC_LAUNCH_CHECK();
     if (d_pairs) {
       k_sum_counts<<<1, 1024, 0, s>>>(block_counts, (int64_t)gdim.x * gdim.y, d_pairs);

@@ -61,6 +61,7 @@ class KernelMap:
 
 
 COUNT_PAIRS = False   # bench.py switches this on for its FLOP accounting pass
+MORTON_MIN_ROWS = 200_000   # conv maps over at least this many output rows visit them in Z-curve order
 USE_CSR = True        # generative expansion also emits the transposed map as CSR pair lists (False: class map + lookup)
 USE_GRID = True       # neighbour lookup through the bitmap+rank grid index (False: binary search; tests run both)
 GRID_MAX_BYTES = 8 << 30
@@ -172,9 +173,13 @@ class CoordSet:
         return self._derived.get(("csr", ksize, ts_out))
 
     # ---- kernel maps ---------------------------------------------------------------------------
-    def kernel_map(self, out_set, ksize, transposed=False, up_stride=1):
-        """Map from this (input) set to `out_set` (a2-ii / a3), cached per (out set, kernel, kind)."""
-        key = (id(out_set), ksize, bool(transposed), up_stride)
+    def kernel_map(self, out_set, ksize, transposed=False, up_stride=1, morton=None):
+        """Map from this (input) set to `out_set` (a2-ii / a3), cached per (out set, kernel, kind).
+        morton: visit the output rows in Z-curve order (default: for large stride-1 maps, see MORTON_MIN_ROWS)."""
+        if morton is None:
+            morton = (not transposed) and ksize > 1 and out_set.n >= MORTON_MIN_ROWS
+        morton = bool(morton) and not transposed
+        key = (id(out_set), ksize, bool(transposed), up_stride, morton)
         m = self._maps.get(key)
         if m is not None:
             return m
@@ -187,7 +192,7 @@ class CoordSet:
         m.hdr = torch.empty(L.MAP_HDR_INTS, dtype=torch.int32, device=dev)
         nelem = lib.pcc_map_nbr_elems(out_set.n, ksize, up_stride, 1 if transposed else 0)
         m.nbr = torch.empty(max(nelem, 1), dtype=torch.int32, device=dev)
-        m.rows = torch.empty(max(out_set.n, 1), dtype=torch.int32, device=dev) if transposed else None
+        m.rows = torch.empty(max(out_set.n, 1), dtype=torch.int32, device=dev) if (transposed or morton) else None
         m.d_pairs = torch.zeros(1, dtype=torch.int64, device=dev) if COUNT_PAIRS else None
         step = out_set.ts if transposed else self.ts
         g = self.grid() if USE_GRID else None

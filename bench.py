@@ -170,6 +170,22 @@ def main():
         lib.check(lib.load().pcc_prof_collect(C.byref(conv_ms), C.byref(conv_launches)), "pcc_prof_collect")
     lib.call("pcc_prof_enable", 0)
 
+    # auxiliary (un-timed for `value`): the same step with integer symbols handed across the entropy-coder boundary,
+    # i.e. the SURVEY 8a hot path alone (sparse convolutions + likelihood kernels), for comparison across rounds
+    hot_ms = None
+    if rank == 0 and args.coder != "symbols":
+        m2 = build_model(device, coder="symbols")
+        m2.load_state_dict(model.state_dict())
+        for _ in range(2):
+            step(m2, pc, q)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(3):
+            step(m2, pc, q)
+        torch.cuda.synchronize()
+        hot_ms = (time.time() - t1) / 3 * 1e3
+        del m2
+
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -197,7 +213,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: one synthetic longdress-like vox{args.bits} frame per GPU "
                                    f"({n_points} points on rank 0), R2 architecture, random-init weights, q=[[0.5,0.5]], "
                                    f"1 block; entropy coder in the timed region: {args.coder}",
-                       "bpp_y_z_strings": bpp,
+                       "bpp_y_z_strings": bpp, "ms_per_step_without_entropy_coder": hot_ms,
                        "frames_per_step": world, "encode_ms": recs[0][2] * 1e3, "decode_ms": recs[0][3] * 1e3,
                        "device": arch, "cus": cu},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -43,12 +43,12 @@ def test_conv_map_bit_exact(ks, stride, ts, lookup_mode):
     rows = n(mz.rows)[:out.n]
     assert np.array_equal(np.sort(rows), np.arange(out.n))
     C = co.unpack_keys(out_keys)[rows].astype(np.int64)
-    code = np.zeros(len(C), dtype=np.int64)
-    g = C[:, 1:] + (1 << 15)
+    code = C[:, 0] << 48
+    sh = int(np.log2(ts))
     for bit in range(16):
-        for ax, sh in ((3, 0), (2, 1), (1, 2)):
-            code |= ((C[:, ax] + (1 << 15)) // (ts * stride if stride > 1 else ts) >> bit & 1) << (3 * bit + sh)
-    code |= C[:, 0] << 48
+        for ax, pos in ((3, 0), (2, 1), (1, 2)):                     # z lowest, then y, then x
+            cell = (C[:, ax] + (1 << 15)) >> sh
+            code |= ((cell >> bit) & 1) << (3 * bit + pos)
     assert np.all(np.diff(code) > 0)                      # positions ascend along the Z-curve (batch major)
 
 

@@ -61,7 +61,7 @@ class KernelMap:
 
 
 COUNT_PAIRS = False   # bench.py switches this on for its FLOP accounting pass
-MORTON_MIN_ROWS = 200_000   # conv maps over at least this many output rows visit them in Z-curve order
+MORTON_MIN_ROWS = 1 << 62    # Z-curve visiting order of conv maps: measured no gain on MI355X (round 1), off by default
 USE_CSR = True        # generative expansion also emits the transposed map as CSR pair lists (False: class map + lookup)
 USE_GRID = True       # neighbour lookup through the bitmap+rank grid index (False: binary search; tests run both)
 GRID_MAX_BYTES = 8 << 30

@@ -275,6 +275,19 @@ int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* 
                             int32_t lut_rows, int32_t* sym_out, int32_t* d_status, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 8f-3  lossless coder for the stride-8 latent coordinates (replaces the PLY file + `tmc3` subprocess round trip of
+ *       UnifiedModel.gpcc_encode / gpcc_decode, model/model.py:388-486).  Host buffers.  Octree occupancy bits under an
+ *       adaptive binary range coder; stream = u32 n | u8 depth | payload.  Cells are (x,y,z) in [0, 2^depth), unique;
+ *       the decoder returns them in Morton order (x most significant).  Not G-PCC syntax; lossless.
+ * ---------------------------------------------------------------------------------------- */
+int64_t pcc_octree_max_bytes(int64_t n, int32_t depth);
+int pcc_octree_encode_host(const int32_t* h_cells /*[n,3]*/, int64_t n, int32_t depth, uint8_t* h_out, int64_t cap,
+                           int64_t* h_nbytes);
+/* h_cells NULL: only *h_n / *h_depth are returned (size query) */
+int pcc_octree_decode_host(const uint8_t* h_data, int64_t nbytes, int32_t* h_cells, int64_t cap_points, int64_t* h_n,
+                           int32_t* h_depth);
+
+/* ------------------------------------------------------------------------------------------
  * measurement support: per-launch HIP-event timing of the conv kernel (bench.py roofline)
  * ---------------------------------------------------------------------------------------- */
 int pcc_prof_enable(int32_t on);

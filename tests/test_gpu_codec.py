@@ -206,3 +206,37 @@ def test_gpu_streams_equal_host_coder_per_channel():
     bad[0] ^= 0xFF
     with pytest.raises(L.PccError):
         gc.decompress_rows(bytes(bad), rows, c, t(idx))
+
+
+def test_file_bitstream_roundtrip_and_rd_figures(tmp_path):
+    """compress(path=...) -> file -> decompress(path=...) equals the in-memory path; file bpp (`utils.py:471`) and
+    D1-PSNR (`metrics/metric.py:113-119`) are identical for the HIP path and the oracle (same geometry)."""
+    import os
+    from unified_point_cloud_compression_amd import synth, metrics
+    cfg = codec.small_config()
+    P = codec.random_params(cfg, 0, gain=4.0)
+    model = _model(cfg, P, "pcc_streams")
+    pc_np = synth.random_block(4, 48, 0.06)
+    pc, q = t(pc_np), t(np.array([[0.5, 0.5]], dtype=np.float32))
+    mem = model.compress(pc, q, block_size=32)                     # 8 blocks
+    rec_mem = model.decompress(coordinates=mem[3], strings=mem[0], shape=mem[1], k=mem[2], q_vals=mem[4])
+    path = os.path.join(tmp_path, "bitstream.bin")
+    assert model.compress(pc, q, path=path, block_size=32) is None
+    rec_file = model.decompress(path=path)
+    assert torch.equal(rec_file, rec_mem)
+    n_pts = pc_np.shape[0]
+    bpp_file = os.path.getsize(path) * 8 / n_pts
+    bpp_strings = metrics.count_bits(mem[0]) / n_pts
+    assert bpp_file > bpp_strings                                   # + coordinates + 44-byte block headers
+    coord_bits = sum(len(model.gpcc_encode(c)) for c in mem[3]) * 8
+    assert abs(os.path.getsize(path) * 8 - (metrics.count_bits(mem[0]) + coord_bits + 8 * (4 + 44 * len(mem[0])))) == 0
+    # D1 parity with the oracle: decode the same symbols with the oracle and compare the PSNR figure
+    sym_model = _model(cfg, P, "symbols")
+    a = sym_model.compress(pc, q, block_size=32)
+    blocks = [dict(y_keys=n(c._pcc_cset.keys)[:c.shape[0]], y_symbols=n(s[0]), z_symbols=n(s[1]), k=k, q=n(q))
+              for c, s, k in zip(a[3], a[0], a[2])]
+    rec_o = codec.decompress(P, cfg, blocks)
+    src = np.floor(pc_np[:, :3])
+    d_gpu = metrics.d1_psnr(src, n(rec_file)[:, :3], resolution=63)
+    d_ora = metrics.d1_psnr(src, rec_o[:, :3], resolution=63)
+    assert d_gpu == d_ora

@@ -1,0 +1,98 @@
+"""Bitstream container + lossless latent-coordinate coding.
+
+Field order follows the reference's `UnifiedModel.save_bitstream / load_bitstream` (`model/model.py:253-385`):
+    int32 num_blocks
+    per block:  int32 Nz | int32 len(points stream) | float64 q_g | float64 q_a | int32 len(y string) |
+                int32 len(z string) | int32 k1 | int32 k2 | int32 k3 | points stream | y string | z string
+Integers / floats are little-endian here (the reference writes them through the `bitstream` package, which is not
+available to check its byte order).  The points stream is the octree coder of libpcc_hip (`pcc_octree_*_host`) instead
+of an ASCII-PLY round trip through the external G-PCC `tmc3` binary (`model/model.py:388-486`); a second header
+(origin, pitch, depth: 17 bytes) in front of the octree payload carries what `tmc3` keeps in its own syntax.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def encode_points(coords, pitch=8):
+    """coords: [n,4] (b,x,y,z) or [n,3] integer tensor/array of lattice points (multiples of `pitch`) -> bytes."""
+    c = coords.detach().cpu().numpy() if torch.is_tensor(coords) else np.asarray(coords)
+    xyz = np.ascontiguousarray(c[:, -3:]).astype(np.int64)
+    n = xyz.shape[0]
+    if n == 0:
+        return struct.pack("<iiiiB", 0, 0, 0, pitch, 1) + struct.pack("<IB", 0, 1)
+    origin = xyz.min(axis=0)
+    cells = (xyz - origin) // pitch
+    if np.any((xyz - origin) % pitch):
+        raise L.PccError(f"latent coordinates are not on a pitch-{pitch} lattice")
+    depth = max(int(np.ceil(np.log2(int(cells.max()) + 1))), 1)
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    lib = L.load()
+    cap = lib.pcc_octree_max_bytes(n, depth)
+    out = np.zeros(cap, np.uint8)
+    nb = C.c_int64(0)
+    L.check(lib.pcc_octree_encode_host(_np_ptr(cells), n, depth, _np_ptr(out), cap, C.byref(nb)), "pcc_octree_encode_host")
+    return struct.pack("<iiiiB", int(origin[0]), int(origin[1]), int(origin[2]), pitch, depth) + out[:nb.value].tobytes()
+
+
+def decode_points(data):
+    """bytes -> int32 [n,3] array of (x,y,z), ascending (x,y,z) (= canonical order of a one-batch set)."""
+    ox, oy, oz, pitch, _depth = struct.unpack_from("<iiiiB", data, 0)
+    body = np.frombuffer(data, np.uint8, offset=17).copy()
+    lib = L.load()
+    n, depth = C.c_int64(0), C.c_int32(0)
+    L.check(lib.pcc_octree_decode_host(_np_ptr(body), len(body), None, 0, C.byref(n), C.byref(depth)), "pcc_octree_decode_host")
+    cells = np.zeros((max(n.value, 1), 3), np.int32)
+    L.check(lib.pcc_octree_decode_host(_np_ptr(body), len(body), _np_ptr(cells), n.value, C.byref(n), C.byref(depth)),
+            "pcc_octree_decode_host")
+    xyz = cells[:n.value].astype(np.int64) * pitch + np.array([ox, oy, oz])
+    order = np.lexsort((xyz[:, 2], xyz[:, 1], xyz[:, 0]))
+    return xyz[order].astype(np.int32)
+
+
+def save_bitstream(path, blocks_coordinates, blocks_strings, blocks_shapes, blocks_k, blocks_q):
+    """`UnifiedModel.save_bitstream` (`model/model.py:253-311`)."""
+    out = bytearray(struct.pack("<i", len(blocks_coordinates)))
+    for coords, strings, shape, k, q in zip(blocks_coordinates, blocks_strings, blocks_shapes, blocks_k, blocks_q):
+        pts = encode_points(coords)
+        qv = q.detach().cpu().double().reshape(-1)
+        out += struct.pack("<iidd", int(shape[0]), len(pts), float(qv[0]), float(qv[1]))
+        for s in strings:
+            out += struct.pack("<i", len(s[0]))
+        for ks in k:
+            out += struct.pack("<i", int(ks[0]))
+        out += pts
+        for s in strings:
+            out += s[0]
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+    return len(out)
+
+
+def load_bitstream(path):
+    """`UnifiedModel.load_bitstream` (`model/model.py:314-385`): coordinates come back as [n,3] int32 (x,y,z)."""
+    data = open(path, "rb").read()
+    (nblocks,), off = struct.unpack_from("<i", data, 0), 4
+    coords, strings, shapes, ks, qs = [], [], [], [], []
+    for _ in range(nblocks):
+        nz, lp, qg, qa, ly, lz, k1, k2, k3 = struct.unpack_from("<iiddiiiii", data, off)
+        off += struct.calcsize("<iiddiiiii")
+        pts = data[off:off + lp]; off += lp
+        ys = data[off:off + ly]; off += ly
+        zs = data[off:off + lz]; off += lz
+        coords.append(torch.from_numpy(decode_points(pts)))
+        strings.append([[ys], [zs]])
+        shapes.append([nz])
+        ks.append([[k1], [k2], [k3]])
+        qs.append(torch.tensor([[qg, qa]], dtype=torch.float32))
+    if off != len(data):
+        raise L.PccError("trailing bytes in bitstream file")
+    return coords, strings, shapes, ks, qs

@@ -76,6 +76,9 @@ SIGNATURES = {
     "pcc_rans_encode_streams": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_rans_build_lut": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "pcc_rans_decode_streams": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _p, _p, _i32, _p, _p, _p]),
+    "pcc_octree_max_bytes": (_i64, [_i64, _i32]),
+    "pcc_octree_encode_host": (C.c_int, [_p, _i64, _i32, _p, _i64, C.POINTER(_i64)]),
+    "pcc_octree_decode_host": (C.c_int, [_p, _i64, _p, _i64, C.POINTER(_i64), C.POINTER(_i32)]),
     "pcc_prof_enable": (C.c_int, [_i32]),
     "pcc_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64)]),
 }

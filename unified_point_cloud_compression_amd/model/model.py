@@ -3,11 +3,13 @@
 Same call signatures and return structure as the reference when `path is None`:
   compress(pointcloud[N,6], q[1,2], block_size) -> (bitstreams, block_shapes, block_k, block_coordinates,
   block_q_vals), one entry per block; decompress(coordinates=, strings=, shape=, k=, q_vals=) -> [N,6].
-`bitstreams[i]` = [[y_string], [z_string]] rANS byte strings as in the reference (`utils.count_bits` applies); the
-file container / G-PCC coordinate coder (`path=`) are out of scope.
+`bitstreams[i]` = [[y_string], [z_string]] rANS byte strings as in the reference (`utils.count_bits` applies).  With
+`path=` the blocks go through the file container of `container.py` (field order of `model/model.py:253-385`) with the
+stride-8 coordinates coded losslessly by the octree coder of libpcc_hip instead of the external `tmc3` subprocess.
 """
 import torch
 
+from .. import container
 from .. import lib as L
 from .. import sparse as S
 from ..MinkowskiEngine.sparse_tensor import SparseTensor
@@ -54,10 +56,25 @@ class UnifiedModel(CompressionModel):
                            x_block[:, 3:6].to(torch.float32)], dim=1)
         return SparseTensor(coordinates=coords, features=feats, device=x_block.device)
 
+    # ---- file container (`model/model.py:253-486`) ---------------------------------------------------------
+    def save_bitstream(self, path, blocks_coordinates, blocks_strings, blocks_shapes, blocks_k, blocks_q):
+        return container.save_bitstream(path, blocks_coordinates, blocks_strings, blocks_shapes, blocks_k, blocks_q)
+
+    def load_bitstream(self, path):
+        return container.load_bitstream(path)
+
+    def gpcc_encode(self, points, directory=None):
+        """Lossless coding of the latent coordinates; name kept from the reference (`model/model.py:388-440`), the
+        coder is libpcc_hip's octree coder, not the external G-PCC binary."""
+        return container.encode_points(points)
+
+    def gpcc_decode(self, bin, directory=None):
+        return torch.from_numpy(container.decode_points(bin))
+
     @torch.no_grad()
     def compress(self, pointcloud, q, path=None, block_size=1024, scaling_factor=1.0):
-        if path:
-            raise L.PccError("file container + G-PCC coordinate coder (`model/model.py:253-486`) are out of scope (8f)")
+        if path and self.entropy_model.entropy_coder == "symbols":
+            raise L.PccError("path= needs byte strings: build the model with entropy_coder 'pcc_streams' or 'ans'")
         if not pointcloud.is_cuda:
             raise L.PccError("compress expects the point cloud on the GPU (`utils.py:436-441` moves it there)")
         if scaling_factor != 1.0:
@@ -77,12 +94,20 @@ class UnifiedModel(CompressionModel):
             block_k.append(k)
             bitstreams.append(symbols)
             start += count
+        if path:
+            self.save_bitstream(path, block_coordinates, bitstreams, block_shapes, block_k, block_q_vals)
+            return None
         return bitstreams, block_shapes, block_k, block_coordinates, block_q_vals
 
     @torch.no_grad()
     def decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None, q_vals=None, trace=None):
+        device = self.g_s.down_conv.kernel.device
         if path:
-            raise L.PccError("file container + G-PCC coordinate coder (`model/model.py:253-486`) are out of scope (8f)")
+            coordinates, strings, shape, k, q_vals = self.load_bitstream(path)
+            for i, c in enumerate(coordinates):                 # [n,3] -> [n,4] with batch column 0 (`model/model.py:218-222`)
+                c = c.to(device)
+                coordinates[i] = torch.cat([torch.zeros((c.shape[0], 1), dtype=c.dtype, device=device), c], dim=1)
+                q_vals[i] = q_vals[i].to(device)
         feats, coords = [], []
         for i, (block_symbols, block_shape, block_coords, block_k) in enumerate(zip(strings, shape, coordinates, k)):
             y_cset = getattr(block_coords, "_pcc_cset", None)

@@ -277,7 +277,7 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
       uint64_t* code_sorted = (uint64_t*)p;  p += pcc_align_up((size_t)n_out * 8) + 1024;
       k_morton<<<(unsigned)pcc_cdiv(n_out, 256), 256, 0, s>>>(out_keys, n_out, ilog2(step), code);
       PCC_LAUNCH_CHECK();
-      PCC_TRY(pcc_sort_keys((const int64_t*)code, n_out, 0x0000FFFFFFFFFFFFull, (int64_t*)code_sorted, rows, p,
+      PCC_TRY(pcc_sort_keys((const int64_t*)code, n_out, 0x7FFFFFFFFFFFFFFFull, (int64_t*)code_sorted, rows, p,
                             ws_bytes - (size_t)(p - (char*)ws), s));
       morton_rows = rows;
     }

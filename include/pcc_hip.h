@@ -263,16 +263,17 @@ int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, i
                             int32_t n_streams, const int32_t* cdf, int32_t cdf_stride,
                             const int32_t* sizes, const int32_t* offsets, const void* enc_table, uint8_t* out,
                             int64_t* d_nbytes, void* ws, size_t ws_bytes, void* stream);
-/* decoder bucket table (host): lut[r*256 + b] = s | start<<16 | freq<<32 of the last s with cdf[r][s] <= 256*b; turns
- * the per-symbol CDF search into one look-up (kept in LDS when rows <= 64) plus a rare short scan.  lut may be NULL
- * in pcc_rans_decode_streams (binary search). */
-int pcc_rans_build_lut(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
-                       uint64_t* h_lut /*[rows*256]*/);
+/* compact decoder table (host): 16-bit CDF rows back to back + a 256-bucket start table per row, one blob of
+ * pcc_rans_dec_table_bytes() bytes; kept in LDS by pcc_rans_decode_streams when it fits (<= 150 KB), so the per-symbol
+ * CDF search runs at LDS latency.  dec_table may be NULL (binary search over the int32 tables in global memory). */
+int64_t pcc_rans_dec_table_bytes(int32_t rows, const int32_t* h_sizes);
+int pcc_rans_build_dec_table(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
+                             void* h_blob);
 /* *d_status != 0 after the kernel: malformed container.  `data` must be readable 4 bytes past nbytes (look-ahead). */
 int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n, int32_t channels,
                             int32_t n_streams, const int32_t* cdf, int32_t cdf_stride,
-                            const int32_t* sizes, const int32_t* offsets, const uint64_t* lut /*nullable*/,
-                            int32_t lut_rows, int32_t* sym_out, int32_t* d_status, void* stream);
+                            const int32_t* sizes, const int32_t* offsets, const void* dec_table /*nullable, device*/,
+                            int64_t dec_bytes, int32_t* sym_out, int32_t* d_status, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 8f-3  lossless coder for the stride-8 latent coordinates (replaces the PLY file + `tmc3` subprocess round trip of

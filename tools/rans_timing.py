@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Wall-clock of the entropy-coder calls on bench-sized symbol tensors (diagnostic)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from unified_point_cloud_compression_amd import synth
+dev = torch.device("cuda:0")
+model = bench.build_model(dev, coder="symbols")
+pc = torch.from_numpy(synth.surface_cloud(0, 10)).to(dev)
+q = torch.tensor([[0.5, 0.5]], device=dev)
+out = model.compress(pc, q)
+y_sym, z_sym = out[0][0]
+em = model.entropy_model
+y = model.g_a(model.block_input(pc))[0]
+z = em.hyper_analysis(y)
+_, zh, _ = em.entropy_bottleneck.encode_rows(z._canonical_features(), want_likelihood=False)
+from unified_point_cloud_compression_amd.MinkowskiEngine.sparse_tensor import SparseTensor
+params = em._gaussian_params(SparseTensor._from_canonical(z._cset, zh), y._cset)
+idx = em.gaussian_conditional.index_rows(params)
+def timeit(name, fn, n=5):
+    fn(); torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(n): r = fn()
+    torch.cuda.synchronize()
+    print(f"{name:28s} {(time.time()-t)/n*1e3:8.3f} ms"); return r
+ys = timeit("y compress_rows", lambda: em.gaussian_conditional.compress_rows(y_sym, idx))
+zs = timeit("z compress_rows", lambda: em.entropy_bottleneck.compress_rows(z_sym))
+print("bytes", len(ys), len(zs), "streams", em.gaussian_conditional.n_streams(*y_sym.shape), em.entropy_bottleneck.n_streams(*z_sym.shape))
+timeit("y decompress_rows", lambda: em.gaussian_conditional.decompress_rows(ys, y_sym.shape[0], y_sym.shape[1], idx))
+timeit("z decompress_rows", lambda: em.entropy_bottleneck.decompress_rows(zs, z_sym.shape[0], z_sym.shape[1], device=dev))
+timeit("index_rows", lambda: em.gaussian_conditional.index_rows(params))

@@ -121,8 +121,9 @@ class EntropyModel(nn.Module):
                L.ptr(ws), ws.numel(), L.stream())
         return out[:int(nb.item())].cpu().numpy().tobytes()
 
-    def decompress_rows(self, data, n, c, idx=None, device=None):
-        """bytes -> sym [N,C] int32 on `device`."""
+    def decompress_rows(self, data, n, c, idx=None, device=None, check=None):
+        """bytes -> sym [N,C] int32 on `device`.  `check`: list collecting the status words for a deferred check
+        (keeps the decode path free of host synchronisation)."""
         self._check_tables()
         dev = torch.device(device) if device is not None else (idx.device if idx is not None else self._quantized_cdf.device)
         cdf, sizes, offs = (t.to(dev).contiguous() for t in (self._quantized_cdf, self._cdf_length, self._offset))
@@ -135,24 +136,29 @@ class EntropyModel(nn.Module):
         sym = torch.empty((n, c), dtype=torch.int32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         L.call("pcc_rans_decode_streams", L.ptr(buf), len(data), L.ptr(idx.contiguous()) if idx is not None else None,
-               n, c, self.n_streams(n, c), L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._lut(dev)),
-               cdf.shape[0], L.ptr(sym), L.ptr(status), L.stream())
-        st = int(status.item())
-        if st != 0:
-            raise L.PccError(f"malformed rANS container (status {st})")
+               n, c, self.n_streams(n, c), L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs),
+               L.ptr(self._dec_table(dev)), self._dec_table(dev).numel(), L.ptr(sym), L.ptr(status), L.stream())
+        if check is None:                       # synchronous check (one device->host read)
+            st = int(status.item())
+            if st != 0:
+                raise L.PccError(f"malformed rANS container (status {st})")
+        else:                                   # deferred: the caller checks all status words once, at the end
+            check.append(status)
         return sym
 
-    def _lut(self, dev):
-        """Decoder bucket table of the current CDFs (rebuilt when the tables change)."""
+    def _dec_table(self, dev):
+        """Compact decoder table of the current CDFs (rebuilt when the tables change)."""
         tag = (self._quantized_cdf.data_ptr(), self._quantized_cdf._version, str(dev))
-        if getattr(self, "_lut_tag", None) != tag:
+        if getattr(self, "_dec_tag", None) != tag:
             cdf, sizes, _ = self._host_tables()
-            lut = np.zeros(cdf.shape[0] * 256, dtype=np.uint64)
-            L.check(L.load().pcc_rans_build_lut(_np_ptr(cdf), cdf.shape[0], cdf.shape[1], _np_ptr(sizes), _np_ptr(lut)),
-                    "pcc_rans_build_lut")
-            self._lut_dev = torch.from_numpy(lut.view(np.int64)).to(dev)
-            self._lut_tag = tag
-        return self._lut_dev
+            lib = L.load()
+            nb = lib.pcc_rans_dec_table_bytes(cdf.shape[0], _np_ptr(sizes))
+            blob = np.zeros(nb, dtype=np.uint8)
+            L.check(lib.pcc_rans_build_dec_table(_np_ptr(cdf), cdf.shape[0], cdf.shape[1], _np_ptr(sizes), _np_ptr(blob)),
+                    "pcc_rans_build_dec_table")
+            self._dec_dev = torch.from_numpy(blob).to(dev)
+            self._dec_tag = tag
+        return self._dec_dev
 
     def _enc_table(self, dev):
         """Division-free encoder entries of the current CDFs (rebuilt when the tables change)."""

@@ -150,12 +150,14 @@ RANS_HD unsigned r_get_bits(unsigned long long& x, const unsigned*& ptr, unsigne
   return v;
 }
 
-// decodes n symbols forward; returns the pointer past the last word consumed.  `lut` (nullable) is a per-row
-// bucket table: lut[row*256 + (cum >> 8)] = last s with cdf[s] <= (cum & ~255), the start of a short forward scan;
-// without it each symbol costs a binary search of dependent loads.
-// fat LUT entry: s | start << 16 | freq << 32 of the first symbol of bucket (cum >> 8)
+// decodes n symbols forward; returns the pointer past the last word consumed.  `d` (nullable pointers) is the
+// compact decoder table: 16-bit CDF rows back to back (row_off), plus per row a 256-entry bucket table
+// lut[row*256 + (cum >> 8)] = last s with cdf[s] <= (cum & ~255).  Small enough to live in LDS, so the symbol search
+// is one LDS look-up plus a short LDS scan; without it every symbol costs a binary search of dependent global loads.
+struct RansDecTab { const int* row_off; const unsigned short* lut; const unsigned short* cdf16; };
+
 RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int ch0, long long n, int gl, long long stride,
-                                 RansTab t, const unsigned long long* lut, int* out) {
+                                 RansTab t, RansDecTab d, int* out) {
   unsigned long long x = (unsigned long long)ptr[0] | ((unsigned long long)ptr[1] << 32);
   ptr += 2;
   unsigned nw = *ptr;                                 // look-ahead word (the buffer is padded by one word)
@@ -180,13 +182,13 @@ RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int ch0, l
       const unsigned cum = (unsigned)(x & ((1u << R_PREC) - 1));
       int lo;
       unsigned start, freq;
-      if (lut) {
-        const unsigned long long e = lut[ci[u] * 256 + (cum >> 8)];
-        lo = (int)(e & 0xFFFF); start = (unsigned)((e >> 16) & 0xFFFF); freq = (unsigned)(e >> 32);
-        if (start + freq <= cum) {                    // not the first symbol of its bucket: short forward scan
-          do { ++lo; } while ((unsigned)c[lo + 1] <= cum);
-          start = (unsigned)c[lo]; freq = (unsigned)(c[lo + 1] - c[lo]);
-        }
+      if (d.lut) {
+        const unsigned short* c16 = d.cdf16 + d.row_off[ci[u]];
+        lo = d.lut[ci[u] * 256 + (cum >> 8)];
+        const int last = size[u] - 2;                 // c16[size-1] is 2^16 stored as 0: never compare against it
+        while (lo < last && (unsigned)c16[lo + 1] <= cum) ++lo;
+        start = c16[lo];
+        freq = ((unsigned)c16[lo + 1] - start) & 0xFFFFu;
       } else {
         int hi = size[u] - 1;                         // last s with c[s] <= cum  (c[0] = 0, c[size-1] = 2^16 > cum)
         lo = 0;
@@ -242,18 +244,37 @@ extern "C" int pcc_pmf_to_quantized_cdf(const float* h_pmf, int32_t n, int32_t p
   return PCC_OK;
 }
 
-// bucket table for the decoder: lut[r*256 + b] = (s | start << 16 | freq << 32) of the last s with cdf[r][s] <= b*256
-extern "C" int pcc_rans_build_lut(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
-                                  uint64_t* h_lut) {
-  PCC_REQUIRE(h_cdf && h_sizes && h_lut && rows >= 1, "pcc_rans_build_lut: bad arguments");
+// compact decoder table blob:  int32 rows | int32 total | int32 row_off[rows+1] | u16 lut[rows*256] | u16 cdf16[total]
+extern "C" int64_t pcc_rans_dec_table_bytes(int32_t rows, const int32_t* h_sizes) {
+  int64_t total = 0;
+  for (int r = 0; r < rows; ++r) total += h_sizes[r];
+  const int64_t b = 8 + 4 * ((int64_t)rows + 1) + 2 * (int64_t)rows * 256 + 2 * total;
+  return (b + 15) / 16 * 16;
+}
+
+extern "C" int pcc_rans_build_dec_table(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
+                                        void* h_blob) {
+  PCC_REQUIRE(h_cdf && h_sizes && h_blob && rows >= 1, "pcc_rans_build_dec_table: bad arguments");
+  memset(h_blob, 0, (size_t)pcc_rans_dec_table_bytes(rows, h_sizes));
+  int* hd = (int*)h_blob;
+  int* row_off = hd + 2;
+  unsigned short* lut = (unsigned short*)(row_off + rows + 1);
+  unsigned short* cdf16 = lut + (size_t)rows * 256;
+  int total = 0;
   for (int r = 0; r < rows; ++r) {
+    row_off[r] = total;
     const int32_t* c = h_cdf + (int64_t)r * cdf_stride;
-    int s = 0;
+    for (int v = 0; v < h_sizes[r]; ++v) cdf16[total + v] = (unsigned short)(c[v] & 0xFFFF);   // 2^16 -> 0
+    int sidx = 0;
     for (int b = 0; b < 256; ++b) {
-      while (s + 1 < h_sizes[r] - 1 && c[s + 1] <= b * 256) ++s;
-      h_lut[r * 256 + b] = (uint64_t)s | ((uint64_t)(uint32_t)c[s] << 16) | ((uint64_t)(uint32_t)(c[s + 1] - c[s]) << 32);
+      while (sidx + 1 < h_sizes[r] - 1 && c[sidx + 1] <= b * 256) ++sidx;
+      lut[r * 256 + b] = (unsigned short)sidx;
     }
+    total += h_sizes[r];
   }
+  row_off[rows] = total;
+  hd[0] = rows;
+  hd[1] = total;
   return PCC_OK;
 }
 
@@ -312,7 +333,7 @@ extern "C" int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const
   std::vector<unsigned> buf((size_t)nbytes / 4 + 4, 0u);     // zero padding: a corrupt stream cannot read out of bounds far
   memcpy(buf.data(), h_data, (size_t)nbytes);
   RansTab t{h_cdf, cdf_stride, h_sizes, h_offsets};
-  r_decode(buf.data(), h_idx, 0, n, 0, 1, t, nullptr, h_sym);
+  r_decode(buf.data(), h_idx, 0, n, 0, 1, t, RansDecTab{nullptr, nullptr, nullptr}, h_sym);
   return PCC_OK;
 }
 
@@ -408,13 +429,21 @@ __global__ void __launch_bounds__(256) k_rans_pack(const unsigned* __restrict__ 
 __global__ void __launch_bounds__(64) k_rans_decode(const unsigned* __restrict__ data, long long nwords_total,
                                                     const int* __restrict__ idx, long long n, int n_streams,
                                                     int gl, long long row_stride, RansTab t,
-                                                    const unsigned long long* __restrict__ lut, int lut_rows_lds,
+                                                    const int* __restrict__ dec_blob, int dec_words_lds,
                                                     int* __restrict__ out, int* __restrict__ status) {
-  extern __shared__ unsigned long long lut_s[];
-  if (lut && lut_rows_lds > 0) {                       // small tables: the bucket LUT lives in LDS (latency)
-    for (int i = threadIdx.x; i < lut_rows_lds * 256; i += blockDim.x) lut_s[i] = lut[i];
-    __syncthreads();
-    lut = lut_s;
+  extern __shared__ int blob_s[];
+  RansDecTab d{nullptr, nullptr, nullptr};
+  if (dec_blob) {
+    const int* b = dec_blob;
+    if (dec_words_lds > 0) {                            // the whole table fits LDS: symbol search at LDS latency
+      for (int i = threadIdx.x; i < dec_words_lds; i += blockDim.x) blob_s[i] = dec_blob[i];
+      __syncthreads();
+      b = blob_s;
+    }
+    const int rows = b[0];
+    d.row_off = b + 2;
+    d.lut = (const unsigned short*)(b + 2 + rows + 1);
+    d.cdf16 = d.lut + (long long)rows * 256;
   }
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_streams) return;
@@ -424,7 +453,7 @@ __global__ void __launch_bounds__(64) k_rans_decode(const unsigned* __restrict__
   const long long len = data[1 + s];
   if (off + len > nwords_total || len < 2) { *status = 2; return; }
   const long long ch0 = (long long)s << gl;
-  const unsigned* p = r_decode(data + off, idx ? idx + ch0 : nullptr, (int)ch0, n << gl, gl, row_stride, t, lut, out + ch0);
+  const unsigned* p = r_decode(data + off, idx ? idx + ch0 : nullptr, (int)ch0, n << gl, gl, row_stride, t, d, out + ch0);
   if (p - (data + off) > len) *status = 3;      // read past its own stream: corrupt input
 }
 
@@ -485,7 +514,7 @@ extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, i
 extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n,
                                        int32_t channels, int32_t n_streams,
                                        const int32_t* cdf, int32_t cdf_stride, const int32_t* sizes,
-                                       const int32_t* offsets, const uint64_t* lut, int32_t lut_rows, int32_t* sym_out,
+                                       const int32_t* offsets, const void* dec_table, int64_t dec_bytes, int32_t* sym_out,
                                        int32_t* d_status, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(data && cdf && sizes && offsets && sym_out && d_status, "pcc_rans_decode_streams: NULL array");
@@ -495,17 +524,17 @@ extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, cons
   PCC_REQUIRE(gl >= 0, "pcc_rans_decode_streams: %d channels do not split into %d power-of-two groups", channels, n_streams);
   PCC_CHECK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
   RansTab t{cdf, cdf_stride, sizes, offsets};
-  // LUT in LDS when it fits 128 KB (<= 64 table rows, the Gaussian scale table); one workgroup per 64 streams
-  const bool in_lds = lut && lut_rows > 0 && (size_t)lut_rows * 256 * 8 <= 128 * 1024;
-  const size_t lds = in_lds ? (size_t)lut_rows * 256 * 8 : 0;
+  // decoder table in LDS when it fits (Gaussian scale table: ~90 KB; factorised prior: ~110 KB)
+  const bool in_lds = dec_table && dec_bytes > 0 && dec_bytes <= 150 * 1024;
+  const size_t lds = in_lds ? (size_t)dec_bytes : 0;
   static bool attr_set = false;
   if (in_lds && !attr_set) {
-    PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_rans_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_rans_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
   k_rans_decode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, lds, s>>>((const unsigned*)data, nbytes / 4, idx, n, n_streams,
-                                                                    gl, channels, t,
-                                                                    (const unsigned long long*)lut, in_lds ? lut_rows : 0,
+                                                                    gl, channels, t, (const int*)dec_table,
+                                                                    in_lds ? (int)(dec_bytes / 4) : 0,
                                                                     sym_out, d_status);
   PCC_LAUNCH_CHECK();
   return PCC_OK;

@@ -159,7 +159,7 @@ class MeanScaleHyperprior(CompressionModel):
         _, _, y_lik = self.gaussian_conditional.encode_rows(y._canonical_features(), params, y._cset.keys, scale)
         return y_lik, z_lik
 
-    def decompress(self, points, symbols, shape, q):
+    def decompress(self, points, symbols, shape, q, check=None):
         """points = [y CoordSet, z CoordSet]; symbols = strings [[y_string], [z_string]] (or the symbol tensors with
         entropy_coder="symbols") (`model/entropy_models.py:409-490`).  Returns y_hat as a stride-8 SparseTensor."""
         assert isinstance(symbols, list) and len(symbols) == 2
@@ -172,7 +172,7 @@ class MeanScaleHyperprior(CompressionModel):
         else:
             (y_string,), (z_string,) = symbols
             z_sym = self.entropy_bottleneck.decompress_rows(z_string, z_cset.n, self.entropy_bottleneck.channels,
-                                                            device=dev)
+                                                            device=dev, check=check)
             y_sym = None
         med = self.entropy_bottleneck.quantiles[:, 0, 1].detach().to(torch.float32)
         z_hat = SparseTensor._from_canonical(z_cset, z_sym.to(torch.float32) + med[None, :])
@@ -180,7 +180,7 @@ class MeanScaleHyperprior(CompressionModel):
         scale, rescale = self._gains(q, y_cset, c_y)
         if y_sym is None:
             idx = self.gaussian_conditional.index_rows(params, y_cset.keys, scale)
-            y_sym = self.gaussian_conditional.decompress_rows(y_string, y_cset.n, c_y, idx)
+            y_sym = self.gaussian_conditional.decompress_rows(y_string, y_cset.n, c_y, idx, check=check)
         if self.quantization_offset:
             c = y_sym.shape[1]
             scales_hat, means_hat = params[:, :c], params[:, c:]

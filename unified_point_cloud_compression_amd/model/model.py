@@ -108,7 +108,7 @@ class UnifiedModel(CompressionModel):
                 c = c.to(device)
                 coordinates[i] = torch.cat([torch.zeros((c.shape[0], 1), dtype=c.dtype, device=device), c], dim=1)
                 q_vals[i] = q_vals[i].to(device)
-        feats, coords = [], []
+        feats, coords, status = [], [], []
         for i, (block_symbols, block_shape, block_coords, block_k) in enumerate(zip(strings, shape, coordinates, k)):
             y_cset = getattr(block_coords, "_pcc_cset", None)
             if y_cset is None or y_cset.ts != 8:
@@ -116,10 +116,12 @@ class UnifiedModel(CompressionModel):
                                       tensor_stride=8, device=self.g_s.down_conv.kernel.device)._cset
             # z coordinates: two k3-s2 `down_conv`s in the reference (`model/model.py:227-229`) = coordinate-only stride
             z_cset = y_cset.stride(16).stride(32)
-            y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i])
+            y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i], check=status)
             x_hat = self.g_s(y_hat, k=block_k, trace=trace)
             feats.append(x_hat.F)
             coords.append(x_hat.C)
+        if status and int(torch.stack(status).abs().max().item()) != 0:     # one deferred check for all rANS containers
+            raise L.PccError("malformed rANS container in the bitstream")
         f = torch.cat(feats, dim=0)
         c = torch.cat(coords, dim=0)
         f = torch.clamp(torch.round(f * 255), 0.0, 255.0) / 255

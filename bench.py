@@ -53,6 +53,16 @@ def step(model, pc, q):
     return out, rec
 
 
+def pmc_traffic():
+    """HBM bytes per MFMA-conv launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE and
+    WRITE_SIZE in separate passes, KiB units, gfx950 FETCH x2 correction).  None when no measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        return float(json.load(open(path))["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def mfma_shape(cin, cout):
     return cout > 4 and (cin in (4, 8, 16) or (cin >= 32 and cin % 32 == 0))
 
@@ -64,15 +74,15 @@ def account_flops(model, pc, q):
     orig, orig_t, orig_c = S.conv_forward, S.convt_forward, S.convt_forward_csr
 
     def spy(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=0, slope=0.01):
-        calls.append((kmap, K, cin, cout, n_out))
+        calls.append((kmap, K, cin, cout, n_out, feats.shape[0]))
         return orig(feats, packed_w, bias, K, cin, cout, kmap, n_out, act, slope)
 
     def spy_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=0, slope=0.01):
-        calls.append((kmap, K, cin, cout, n_out))     # pairs = n_in*K: the dense GEMM does exactly the algorithmic FLOPs
+        calls.append((kmap, K, cin, cout, n_out, feats.shape[0]))     # pairs = n_in*K: the dense GEMM does exactly the algorithmic FLOPs
         return orig_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act, slope)
 
     def spy_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
-        calls.append((feats.shape[0] * K, K, cin, cout, n_out))        # every (input row, offset) is one pair
+        calls.append((feats.shape[0] * K, K, cin, cout, n_out, feats.shape[0]))        # every (input row, offset) is one pair
         return orig_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope)
 
     S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr = True, spy, spy_t, spy_c
@@ -81,15 +91,17 @@ def account_flops(model, pc, q):
         torch.cuda.synchronize()
     finally:
         S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr = False, orig, orig_t, orig_c
-    flops, launches, pairs_total = 0.0, 0, 0
-    for kmap, K, cin, cout, n_out in calls:
+    flops, launches, pairs_total, alg_bytes = 0.0, 0, 0, 0.0
+    for kmap, K, cin, cout, n_out, n_in in calls:
         if not mfma_shape(cin, cout):
             continue
         p = kmap if isinstance(kmap, int) else (kmap.pairs() if kmap is not None else n_out)
         flops += 2.0 * p * cin * cout
+        # compulsory traffic of the layer: every feature row, weight, map entry, coordinate touched once
+        alg_bytes += 4.0 * (n_in * cin + n_out * cout + K * cin * cout) + 8.0 * p + 16.0 * (n_in + n_out)
         pairs_total += p
         launches += 1
-    return flops, launches, pairs_total
+    return flops, launches, pairs_total, alg_bytes
 
 
 def cpu_baseline(bits=8, threads=None):
@@ -148,7 +160,7 @@ def main():
     for _ in range(args.warmup):
         step(model, pc, q)
     torch.cuda.synchronize()
-    flops_step, launches_step, pairs_step = account_flops(model, pc, q) if rank == 0 else (0.0, 0, 0)
+    flops_step, launches_step, pairs_step, alg_bytes_step = account_flops(model, pc, q) if rank == 0 else (0.0, 0, 0, 0.0)
 
     lib.call("pcc_prof_enable", 1 if rank == 0 else 0)
     barrier()
@@ -217,7 +229,9 @@ def main():
                        "frames_per_step": world, "encode_ms": recs[0][2] * 1e3, "decode_ms": recs[0][3] * 1e3,
                        "device": arch, "cus": cu},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None, "traffic": None,
+                         "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None, "traffic": pmc_traffic(),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                         "alg_bytes_per_launch": (alg_bytes_step / launches_step) if launches_step else None,
                          "kernel": "k_conv_mfma (pcc_conv_fwd)", "flop_per_step": flops_step,
                          "pairs_per_step": pairs_step, "launches_per_step": launches_step,
                          "avg_launch_ms": (conv_ms.value / conv_launches.value) if conv_launches.value else None,

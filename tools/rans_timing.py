@@ -30,3 +30,17 @@ print("bytes", len(ys), len(zs), "streams", em.gaussian_conditional.n_streams(*y
 timeit("y decompress_rows", lambda: em.gaussian_conditional.decompress_rows(ys, y_sym.shape[0], y_sym.shape[1], idx))
 timeit("z decompress_rows", lambda: em.entropy_bottleneck.decompress_rows(zs, z_sym.shape[0], z_sym.shape[1], device=dev))
 timeit("index_rows", lambda: em.gaussian_conditional.index_rows(params))
+# synthetic statistics: symbols drawn from the coder's own model (well matched), several scale regimes
+import numpy as np
+gc = em.gaussian_conditional
+tab = gc.scale_table.cpu().numpy()
+rng = np.random.default_rng(0)
+n, c = y_sym.shape
+for name, lo, hi in (("small scales (idx 0..8)", 0, 8), ("mid scales (idx 8..30)", 8, 30), ("all zeros, idx 0", 0, 1)):
+    ii = rng.integers(lo, hi, (n, c)).astype(np.int32)
+    ss = np.rint(rng.standard_normal((n, c)) * tab[ii]).astype(np.int32)
+    if hi == 1: ss[:] = 0
+    si, sidx = torch.from_numpy(ss).to(dev), torch.from_numpy(ii).to(dev)
+    data = timeit(f"enc {name}", lambda: gc.compress_rows(si, sidx))
+    timeit(f"dec {name}", lambda: gc.decompress_rows(data, n, c, sidx))
+    print("   bits/symbol", len(data) * 8 / (n * c))

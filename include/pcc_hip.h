@@ -232,6 +232,21 @@ int pcc_eb_encode(const float* z, int64_t n, int32_t c, const float* eb_packed, 
                   int32_t* sym, float* z_hat, float* lik, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * training (BASELINE config 4; reference train.py:221-227 back-propagates through every ME convolution)
+ *   data gradient  : the forward entry points on the inverse map with transposed weights (no extra kernel)
+ *   weight gradient: dW[k][ci][co] = sum over pairs (i,o) of offset k of feat_in[i][ci] * grad_out[o][co]
+ *                    MFMA GEMM whose reduction runs over the pair list; partial tiles per position slice are summed
+ *                    in slice order (deterministic).  hdr/nbr/rows: the FORWARD map (NULL hdr: K = 1 identity).
+ *   pcc_convt_scatter_rows: dT[pair] = grad_out[output row of pair] for the input-stationary transposed conv.
+ * ---------------------------------------------------------------------------------------- */
+size_t pcc_conv_wgrad_ws_bytes(int64_t n_out, int32_t K, int32_t cin, int32_t cout);
+int pcc_conv_wgrad(const float* feat_in, int64_t n_in, int32_t cin, const float* grad_out, int64_t n_out, int32_t cout,
+                   int32_t K, const int32_t* hdr, const int32_t* nbr, const int32_t* rows, float* dW /*[K,cin,cout]*/,
+                   void* ws, size_t ws_bytes, void* stream);
+int pcc_convt_scatter_rows(const float* grad_out, const int32_t* first, const int32_t* pair_ids, int64_t n_out,
+                           int32_t cout, float* dT /*[n_in*K, cout]*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 8f-1  rANS entropy coder + CDF tables  (CompressAI `_CXX`: `pmf_to_quantized_cdf`, `BufferedRansEncoder`,
  *       `RansDecoder`; reference call sites model/entropy_models.py:371-372,397-400,438,471,484, model/model.py:30-34)
  * rans64 scheme: 64-bit state, 32-bit words, 16-bit probabilities, 4-bit bypass digits outside a table.

@@ -64,8 +64,10 @@ class _ConvBase(nn.Module):
                 self.bias.uniform_(-a, a)
 
     def _apply_conv(self, x, out_set, kmap, act=L.ACT_NONE, slope=0.01):
-        if torch.is_grad_enabled() and (x.F.requires_grad or self.kernel.requires_grad and self.training):
-            raise L.PccError("libpcc_hip convolution has no backward yet: wrap inference in torch.no_grad() / model.eval()")
+        feats = x._canonical_features()
+        if torch.is_grad_enabled() and (feats.requires_grad or self.kernel.requires_grad):
+            from ..autograd import SparseConvFn            # training path (BASELINE config 4)
+            return SparseConvFn.apply(feats, self.kernel, self.bias, self, x._cset, out_set, kmap, act, slope)
         packed = self._packed.get(self.kernel)
         if isinstance(kmap, tuple):          # CSR pair lists from the fused coordinate expansion
             return S.convt_forward_csr(x._canonical_features(), packed, self.bias, self.kernel_volume,

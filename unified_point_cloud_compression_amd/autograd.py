@@ -1,0 +1,108 @@
+"""Autograd for the sparse convolutions (BASELINE config 4: one training step forward + backward).
+
+The reference back-propagates through every `ME.MinkowskiConvolution` / `MinkowskiGenerativeConvolutionTranspose`
+(`train.py:221-227`).  Here
+  * the DATA gradient is the forward kernel again: a convolution through the inverse map with transposed weights
+    (for odd kernels the inverse of offset k is offset K-1-k); for the input-stationary transposed conv it is the dense
+    GEMM dT @ Wflat^T after scattering grad_out onto the pairs;
+  * the WEIGHT gradient is `pcc_conv_wgrad` (MFMA GEMM whose reduction runs over the pair list, deterministic);
+  * the bias gradient is a column sum.
+Fused activations are differentiated from the saved output.
+"""
+import torch
+
+from . import lib as L
+from . import sparse as S
+
+
+def _pack(w3):
+    """Pack a [K, cin, cout] weight for conv_forward (one-off tensors of the backward pass)."""
+    p = S.PackedConv()
+    return p.get(w3.contiguous())
+
+
+def _pad4(t, dim):
+    r = (-t.shape[dim]) % 4
+    if r == 0:
+        return t
+    shape = list(t.shape)
+    shape[dim] = r
+    return torch.cat([t, t.new_zeros(shape)], dim=dim)
+
+
+def _conv_any(feats, w3, kmap, n_out):
+    """conv_forward for arbitrary (cin, cout): channel counts the kernels do not take are zero-padded to 4 / 32."""
+    K, cin, cout = w3.shape
+    if cin % 4 != 0:                                   # e.g. grad of a 1- or 3-channel head
+        feats, w3 = _pad4(feats, 1), _pad4(w3, 1)
+        cin = w3.shape[1]
+    if cin > 16 and cin % 32 != 0:                     # MFMA path takes 4/8/16 or multiples of 32
+        r = (-cin) % 32
+        feats = torch.cat([feats, feats.new_zeros((feats.shape[0], r))], dim=1)
+        w3 = torch.cat([w3, w3.new_zeros((K, r, cout))], dim=1)
+        cin += r
+    if cin not in (4, 8, 16) and cin % 32 != 0:        # 12 -> 16
+        r = 16 - cin
+        feats = torch.cat([feats, feats.new_zeros((feats.shape[0], r))], dim=1)
+        w3 = torch.cat([w3, w3.new_zeros((K, r, cout))], dim=1)
+        cin = 16
+    return S.conv_forward(feats, _pack(w3), None, K, cin, cout, kmap, n_out)
+
+
+class SparseConvFn(torch.autograd.Function):
+    """out = act(bias + conv(feats; kernel)) over a fixed kernel map (coordinates carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, bias, module, in_set, out_set, kmap, act, slope):
+        K, cin, cout = module.kernel_volume, module.in_channels, module.out_channels
+        packed = module._packed.get(kernel)
+        feats = feats.contiguous()
+        if isinstance(kmap, tuple):
+            out = S.convt_forward_csr(feats, packed, bias, K, cin, cout, kmap, out_set.n, act, slope)
+        elif module.TRANSPOSED:
+            out = S.convt_forward(feats, packed, bias, K, cin, cout, kmap, out_set.n, act, slope)
+        else:
+            out = S.conv_forward(feats, packed, bias, K, cin, cout, kmap, out_set.n, act, slope)
+        ctx.save_for_backward(feats, kernel, out if act != L.ACT_NONE else None)
+        ctx.meta = (module, in_set, out_set, kmap, act, slope, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, kernel, out = ctx.saved_tensors
+        module, in_set, out_set, kmap, act, slope, has_bias = ctx.meta
+        K, cin, cout = module.kernel_volume, module.in_channels, module.out_channels
+        g = g.contiguous()
+        if act == L.ACT_RELU:
+            g = g * (out > 0)
+        elif act == L.ACT_LEAKY:
+            g = torch.where(out > 0, g, g * slope)
+        w3 = kernel.detach() if kernel.dim() == 3 else kernel.detach().unsqueeze(0)        # [K, cin, cout]
+        g_feats = g_kernel = g_bias = None
+        if has_bias and ctx.needs_input_grad[2]:
+            g_bias = g.sum(dim=0, keepdim=True)
+        if module.TRANSPOSED:
+            if not isinstance(kmap, tuple):
+                raise L.PccError("backward of the transposed conv needs the CSR pair lists (sparse.USE_CSR)")
+            dT = S.convt_scatter_rows(g, kmap, feats.shape[0] * K, cout).view(feats.shape[0], K * cout)
+            if ctx.needs_input_grad[1]:
+                gw = S.conv_wgrad(feats, dT, 1, cin, K * cout, None)[0]                      # [cin, K*cout]
+                g_kernel = gw.view(cin, K, cout).permute(1, 0, 2).contiguous()
+            if ctx.needs_input_grad[0]:
+                wt = w3.permute(0, 2, 1).reshape(1, K * cout, cin)                           # Wflat^T
+                g_feats = _conv_any(dT, wt, None, feats.shape[0])
+        else:
+            if ctx.needs_input_grad[1]:
+                g_kernel = S.conv_wgrad(feats, g, K, cin, cout, kmap)
+            if ctx.needs_input_grad[0]:
+                if K == 1:
+                    g_feats = _conv_any(g, w3.permute(0, 2, 1), None, feats.shape[0])
+                else:
+                    if module.kernel_size % 2 == 0:
+                        raise L.PccError("backward of even-sized (non-generative) kernels is not supported")
+                    inv = out_set.kernel_map(in_set, module.kernel_size, step=in_set.ts)    # roles swapped
+                    wd = torch.flip(w3, dims=[0]).permute(0, 2, 1)                           # W'[k'] = W[K-1-k']^T
+                    g_feats = _conv_any(g, wd, inv, in_set.n)
+        if g_kernel is not None and kernel.dim() == 2:
+            g_kernel = g_kernel[0]
+        return g_feats, g_kernel, g_bias, None, None, None, None, None, None

@@ -1,0 +1,216 @@
+// Weight gradient of the sparse convolution (BASELINE config 4: training step forward + backward; reference
+// train.py:221-227 back-propagates through every ME.MinkowskiConvolution / GenerativeConvolutionTranspose):
+//     dW[k][ci][co] = sum over the pairs (i,o) of offset k of  X[i][ci] * G[o][co]
+// An MFMA GEMM per offset whose REDUCTION dimension is the pair list: M = ci, N = co, K = pairs.  A workgroup owns
+// one (offset slot, 128x128 tile of dW, slice of positions); it gathers 32 pairs at a time (the input row and the
+// output-gradient row of each pair) into LDS and feeds v_mfma_f32_32x32x2_f32 with transposed operand reads.
+// Slices write partial tiles that a second kernel sums in slice order: deterministic, no atomics.
+// The data gradient needs no kernel of its own: it is the forward kernel on the inverse map with W^T (sparse.py).
+#include "pcc_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int WG_PAIRS = 32;         // pairs staged per step
+static constexpr int WG_LD = 128 + 4;       // floats per staged row (128 channels + pad)
+static constexpr int WG_SLICE = 4096;       // positions per workgroup slice
+
+// 4 consecutive channels [col, col+4) of a row of `width` floats; 16-byte load when the row pitch allows it,
+// guarded scalar loads for the thin layers (1 / 3 channels) and at the tile edge
+__device__ inline float4 load4(const float* __restrict__ row, int width, int col) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((width & 3) == 0 && col + 3 < width) return *reinterpret_cast<const float4*>(row + col);
+  if (col < width) v.x = row[col];
+  if (col + 1 < width) v.y = row[col + 1];
+  if (col + 2 < width) v.z = row[col + 2];
+  if (col + 3 < width) v.w = row[col + 3];
+  return v;
+}
+
+struct WgradArgs {
+  const float* x;        // [n_in, cin]
+  const float* g;        // [n_out, cout]
+  const int* hdr;        // map header (null: identity, K = 1)
+  const int* nbr;
+  const int* rows;
+  float* partial;        // [nslices][K][cin][cout]
+  long long n_out;
+  int cin, cout, K, nslices;
+};
+
+// total (segment, slot) work items are enumerated on the host side as K slots of kernel offsets: slot kid in [0,K).
+// For transposed / class maps a kernel offset appears in exactly one segment; the kernel finds it in the header.
+__global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float Xs[WG_PAIRS * WG_LD];
+  __shared__ __attribute__((aligned(16))) float Gs[WG_PAIRS * WG_LD];
+  __shared__ int s_in[WG_PAIRS], s_out[WG_PAIRS];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kid = blockIdx.y;                       // kernel offset id
+  const int slice = blockIdx.x;
+  const int mt = blockIdx.z / ((a.cout + 127) / 128), nt = blockIdx.z % ((a.cout + 127) / 128);
+  const int m0 = mt * 128, n0 = nt * 128;
+
+  // locate the segment / slot that lists this kernel offset
+  long long pos_begin = 0, pos_count = a.n_out;
+  const int* seg_nbr = nullptr;
+  const bool identity = (a.hdr == nullptr);
+  if (!identity) {
+    const int nseg = a.hdr[HDR_NSEG];
+    bool found = false;
+    for (int s = 0; s < nseg && !found; ++s) {
+      const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+      for (int j = 0; j < sg[SEG_K_COUNT]; ++j)
+        if (a.hdr[HDR_KOFFS + sg[SEG_KOFF_BEGIN] + j] == kid) {
+          pos_begin = sg[SEG_POS_BEGIN]; pos_count = sg[SEG_POS_COUNT];
+          seg_nbr = a.nbr + (((long long)(unsigned)sg[SEG_NBR_LO]) | ((long long)sg[SEG_NBR_HI] << 32)) + (long long)j * pos_count;
+          found = true;
+          break;
+        }
+    }
+    if (!found) pos_count = 0;
+  }
+  const long long per = (pos_count + a.nslices - 1) / a.nslices;
+  const long long p_lo = (long long)slice * per;
+  const long long p_hi = min(pos_count, p_lo + per);
+
+  const int wm = w >> 1, wn = w & 1;                // 2x2 waves, each 64x64 of the 128x128 tile
+  const int half = lane >> 5, r31 = lane & 31;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  for (long long p0 = p_lo; p0 < p_hi; p0 += WG_PAIRS) {
+    __syncthreads();                                 // previous step's fragment reads are done
+    if (tid < WG_PAIRS) {
+      const long long p = p0 + tid;
+      int ir = -1, orow = -1;
+      if (p < p_hi) {
+        ir = identity ? (int)p : seg_nbr[p];
+        orow = a.rows ? a.rows[pos_begin + p] : (int)(pos_begin + p);
+      }
+      s_in[tid] = ir; s_out[tid] = (ir >= 0) ? orow : -1;
+    }
+    __syncthreads();
+    // stage: 32 pairs x 128 channels of X (columns m0..) and of G (columns n0..); 8 threads per row, 4 float4 each
+    {
+      const int r = tid >> 3, part = tid & 7;
+      const int ir = s_in[r], orow = s_out[r];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = (part + 8 * q) * 4;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), gv = xv;
+        if (ir >= 0) {
+          xv = load4(a.x + (long long)ir * a.cin, a.cin, m0 + c);
+          gv = load4(a.g + (long long)orow * a.cout, a.cout, n0 + c);
+        }
+        *reinterpret_cast<float4*>(&Xs[r * WG_LD + c]) = xv;
+        *reinterpret_cast<float4*>(&Gs[r * WG_LD + c]) = gv;
+      }
+    }
+    __syncthreads();
+    // D[ci][co] += sum_pairs X[pair][ci] * G[pair][co]:  A[i=ci][k=pair], B[k=pair][j=co]
+#pragma unroll 4
+    for (int kk = 0; kk < WG_PAIRS; kk += 2) {
+      float af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = Xs[(kk + half) * WG_LD + (wm * 2 + i) * 32 + r31];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = Gs[(kk + half) * WG_LD + (wn * 2 + j) * 32 + r31];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // partial tile -> [slice][kid][cin][cout]
+  float* dst = a.partial + ((long long)slice * a.K + kid) * a.cin * a.cout;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = n0 + (wn * 2 + j) * 32 + r31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (ci < a.cin && co < a.cout) dst[(long long)ci * a.cout + co] = acc[i][j][e];
+      }
+    }
+}
+
+__global__ void k_wgrad_reduce(const float* __restrict__ partial, long long elems, int nslices, float* __restrict__ dW) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= elems) return;
+  float s = 0.f;
+  for (int sl = 0; sl < nslices; ++sl) s += partial[(long long)sl * elems + t];     // fixed order
+  dW[t] = s;
+}
+
+static int wgrad_slices(int64_t n_out) {
+  int64_t s = pcc_cdiv(n_out, WG_SLICE);
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+extern "C" size_t pcc_conv_wgrad_ws_bytes(int64_t n_out, int32_t K, int32_t cin, int32_t cout) {
+  return (size_t)wgrad_slices(n_out) * (size_t)K * cin * cout * sizeof(float) + 256;
+}
+
+extern "C" int pcc_conv_wgrad(const float* feat_in, int64_t n_in, int32_t cin, const float* grad_out, int64_t n_out,
+                              int32_t cout, int32_t K, const int32_t* hdr, const int32_t* nbr, const int32_t* rows,
+                              float* dW, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(dW && K >= 1 && K <= 192 && cin >= 1 && cout >= 1, "pcc_conv_wgrad: bad arguments");
+  const long long elems = (long long)K * cin * cout;
+  if (n_out <= 0 || n_in <= 0) {
+    PCC_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)elems * sizeof(float), s));
+    return PCC_OK;
+  }
+  PCC_REQUIRE(feat_in && grad_out && ws, "pcc_conv_wgrad: NULL array");
+  PCC_REQUIRE(hdr ? (nbr != nullptr) : (K == 1 && n_in == n_out), "pcc_conv_wgrad: map missing (only K=1 may omit it)");
+  PCC_REQUIRE(n_in < (1ll << 31) && n_out < (1ll << 31), "pcc_conv_wgrad: too many rows");
+  if (ws_bytes < pcc_conv_wgrad_ws_bytes(n_out, K, cin, cout)) {
+    pcc_set_error("pcc_conv_wgrad: workspace too small");
+    return PCC_EWS;
+  }
+  WgradArgs a;
+  a.x = feat_in; a.g = grad_out; a.hdr = hdr; a.nbr = nbr; a.rows = rows; a.partial = (float*)ws; a.n_out = n_out;
+  a.cin = cin; a.cout = cout; a.K = K; a.nslices = wgrad_slices(n_out);
+  const unsigned tiles = (unsigned)(((cin + 127) / 128) * ((cout + 127) / 128));
+  k_wgrad<<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
+  PCC_LAUNCH_CHECK();
+  k_wgrad_reduce<<<(unsigned)pcc_cdiv(elems, 256), 256, 0, s>>>(a.partial, elems, a.nslices, dW);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// generative transposed conv backward: dT[pair] = grad_out[output row of the pair]   (every pair written once)
+template <typename VT>
+__global__ void k_convt_scatter(const VT* __restrict__ g, const int* __restrict__ first, const int* __restrict__ pair_ids,
+                                long long n_out, int vpr, VT* __restrict__ dT) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long o = t / vpr;
+  if (o >= n_out) return;
+  const int v = (int)(t - o * vpr);
+  const VT val = g[t];
+  for (int q = first[o]; q < first[o + 1]; ++q) dT[(long long)pair_ids[q] * vpr + v] = val;
+}
+
+extern "C" int pcc_convt_scatter_rows(const float* grad_out, const int32_t* first, const int32_t* pair_ids, int64_t n_out,
+                                      int32_t cout, float* dT, void* stream) {
+  if (n_out <= 0) return PCC_OK;
+  PCC_REQUIRE(grad_out && first && pair_ids && dT && cout >= 1, "pcc_convt_scatter_rows: bad arguments");
+  if (cout % 4 == 0) {
+    const int vpr = cout / 4;
+    k_convt_scatter<float4><<<(unsigned)pcc_cdiv(n_out * vpr, 256), 256, 0, (hipStream_t)stream>>>(
+        (const float4*)grad_out, first, pair_ids, n_out, vpr, (float4*)dT);
+  } else {
+    k_convt_scatter<float><<<(unsigned)pcc_cdiv(n_out * cout, 256), 256, 0, (hipStream_t)stream>>>(grad_out, first, pair_ids,
+                                                                                                 n_out, cout, dT);
+  }
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}

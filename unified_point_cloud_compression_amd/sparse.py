@@ -173,13 +173,13 @@ class CoordSet:
         return self._derived.get(("csr", ksize, ts_out))
 
     # ---- kernel maps ---------------------------------------------------------------------------
-    def kernel_map(self, out_set, ksize, transposed=False, up_stride=1, morton=None):
+    def kernel_map(self, out_set, ksize, transposed=False, up_stride=1, morton=None, step=None):
         """Map from this (input) set to `out_set` (a2-ii / a3), cached per (out set, kernel, kind).
         morton: visit the output rows in Z-curve order (default: for large stride-1 maps, see MORTON_MIN_ROWS)."""
         if morton is None:
             morton = (not transposed) and ksize > 1 and out_set.n >= MORTON_MIN_ROWS
         morton = bool(morton) and not transposed
-        key = (id(out_set), ksize, bool(transposed), up_stride, morton)
+        key = (id(out_set), ksize, bool(transposed), up_stride, morton, step)
         m = self._maps.get(key)
         if m is not None:
             return m
@@ -194,7 +194,8 @@ class CoordSet:
         m.nbr = torch.empty(max(nelem, 1), dtype=torch.int32, device=dev)
         m.rows = torch.empty(max(out_set.n, 1), dtype=torch.int32, device=dev) if (transposed or morton) else None
         m.d_pairs = torch.zeros(1, dtype=torch.int64, device=dev) if COUNT_PAIRS else None
-        step = out_set.ts if transposed else self.ts
+        if step is None:
+            step = out_set.ts if transposed else self.ts
         g = self.grid() if USE_GRID else None
         ws = L.workspace(lib.pcc_map_ws_bytes(out_set.n), dev)
         L.call("pcc_kernel_map_build", L.ptr(self.keys), self.n, L.ptr(out_set.keys), out_set.n, ksize, step,
@@ -344,6 +345,27 @@ def convt_forward_csr(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT
     L.call("pcc_convt_fwd_csr", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first),
            L.ptr(pair_ids), n_out, L.ptr(T), L.ptr(out), act, float(slope), L.stream())
     return out
+
+
+def conv_wgrad(feats_in, grad_out, K, cin, cout, kmap):
+    """dW[k][ci][co] = sum over pairs of offset k of feats_in[i][ci] * grad_out[o][co]  (kmap None: K = 1 identity)."""
+    feats_in, grad_out = feats_in.contiguous(), grad_out.contiguous()
+    dW = torch.empty((K, cin, cout), dtype=torch.float32, device=feats_in.device)
+    ws = L.workspace(L.load().pcc_conv_wgrad_ws_bytes(grad_out.shape[0], K, cin, cout), feats_in.device)
+    L.call("pcc_conv_wgrad", L.ptr(feats_in), feats_in.shape[0], cin, L.ptr(grad_out), grad_out.shape[0], cout, K,
+           L.ptr(kmap.hdr) if kmap is not None else None, L.ptr(kmap.nbr) if kmap is not None else None,
+           L.ptr(kmap.rows) if kmap is not None else None, L.ptr(dW), L.ptr(ws), ws.numel(), L.stream())
+    return dW
+
+
+def convt_scatter_rows(grad_out, csr, n_pairs, cout):
+    """dT[pair] = grad_out[output row of the pair] for the input-stationary transposed conv."""
+    first, pair_ids = csr
+    grad_out = grad_out.contiguous()
+    dT = torch.empty((n_pairs, cout), dtype=torch.float32, device=grad_out.device)
+    L.call("pcc_convt_scatter_rows", L.ptr(grad_out), L.ptr(first), L.ptr(pair_ids), grad_out.shape[0], cout, L.ptr(dT),
+           L.stream())
+    return dT
 
 
 def topk_mask(logits, seg_begin, ks):

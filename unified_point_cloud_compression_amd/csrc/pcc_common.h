@@ -93,6 +93,7 @@ __device__ inline int pcc_grid_find(const PccGrid& g, int64_t key) {
   const int y = (int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - g.lo[1];
   const int z = (int)(key & 0xFFFF) - (int)PCC_BIAS - g.lo[2];
   if ((x | y | z) < 0 || b >= g.nbatch) return -1;
+  if ((x | y | z) & ((1 << g.ts_log2) - 1)) return -1;   // off-lattice query (inverse maps of strided convs ask these)
   const int cx = x >> g.ts_log2, cy = y >> g.ts_log2, cz = z >> g.ts_log2;
   if (cx >= g.dims[0] || cy >= g.dims[1] || cz >= g.dims[2]) return -1;
   const long long cell = (((long long)b * g.dims[0] + cx) * g.dims[1] + cy) * g.dims[2] + cz;

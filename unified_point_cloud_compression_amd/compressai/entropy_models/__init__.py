@@ -302,6 +302,14 @@ class EntropyBottleneck(EntropyModel):
         self._cdf_length = (pmf_length + 2).int().to(dev)
         return True
 
+    def likelihood_rows(self, v):
+        """Differentiable likelihood of [N,C] rows (training path; torch ops): |sigmoid(s*u) - sigmoid(s*l)| >= 1e-9."""
+        x = v.t().unsqueeze(1)
+        lo, up = self._logits_cumulative(x - 0.5), self._logits_cumulative(x + 0.5)
+        sg = -torch.sign(lo + up).detach()
+        lik = torch.abs(torch.sigmoid(sg * up) - torch.sigmoid(sg * lo))[:, 0, :].t()
+        return self.likelihood_lower_bound(lik) if self.use_likelihood_bound else lik
+
     def packed(self):
         """[C,58] = softplus(matrices) | biases | tanh(factors) for `pcc_eb_encode` (filters (3,3,3,3) only)."""
         if self.filters != (3, 3, 3, 3):
@@ -406,6 +414,13 @@ class GaussianConditional(EntropyModel):
         if self.scale_table.numel() == 0:
             raise L.PccError("GaussianConditional has no scale table: call model.update() first (`evaluate.py:89`)")
         return self.scale_table.to(device=device, dtype=torch.float32).contiguous()
+
+    def likelihood_rows(self, values, scales, means):
+        """Differentiable Gaussian likelihood of [N,C] rows (training path; torch ops)."""
+        s = self.lower_bound_scale(scales)
+        a = torch.abs(values - means)
+        lik = self._standardized_cumulative((0.5 - a) / s) - self._standardized_cumulative((-0.5 - a) / s)
+        return self.likelihood_lower_bound(lik) if self.use_likelihood_bound else lik
 
     def index_rows(self, params, keys=None, gain=None):
         """Table rows of every element from (scales_hat | means_hat) alone: what the decoder needs before the symbols

@@ -130,7 +130,13 @@ class MeanScaleHyperprior(CompressionModel):
 
     def _gaussian_params(self, z_hat, y_cset):
         g = self.hyper_synthesis(z_hat)
-        return S.lookup_gather(g._cset, g._canonical_features(), y_cset.keys, y_cset.n)   # [Ny, 2C]
+        gf = g._canonical_features()
+        if torch.is_grad_enabled() and gf.requires_grad:       # training: differentiable row gather
+            rows = torch.empty(max(y_cset.n, 1), dtype=torch.int32, device=gf.device)
+            L.call("pcc_lookup_rows", L.ptr(g._cset.keys), g._cset.n, L.ptr(y_cset.keys), y_cset.n, L.ptr(rows), L.stream())
+            rows = rows[:y_cset.n].long()
+            return torch.where((rows >= 0).unsqueeze(1), gf[rows.clamp(min=0)], gf.new_zeros(1))
+        return S.lookup_gather(g._cset, gf, y_cset.keys, y_cset.n)   # [Ny, 2C]
 
     # ---- reference API ---------------------------------------------------------------------------------
     def compress(self, y, q):
@@ -197,6 +203,52 @@ class MeanScaleHyperprior(CompressionModel):
             y_hat, _ = self.gaussian_conditional.decode_rows(y_sym, params, y_cset.keys, scale)
         return SparseTensor._from_canonical(y_cset, y_hat)
 
+    noise_fn = None     # callable(tag, like) -> U(-.5,.5) noise; tests install a deterministic one
+
+    def _noise(self, tag, like):
+        if self.noise_fn is not None:
+            return self.noise_fn(tag, like)
+        return torch.empty_like(like).uniform_(-0.5, 0.5)
+
     def forward(self, y, q):
-        raise L.PccError("MeanScaleHyperprior.forward (training proxy quantisation + backward) is BASELINE config 4, "
-                         "not built in this round; use likelihoods() for eval-mode rate")
+        """Training forward (`model/entropy_models.py:236-340`) on [N,C] rows: proxy quantisation (additive uniform
+        noise / straight-through rounding), differentiable likelihoods, optional quantisation offsets.
+        Returns (y_hat SparseTensor at stride 8, (y_likelihoods [Ny,C], z_likelihoods [Nz,Ch]))."""
+        from ..compressai.ops.ops import quantize_ste
+        z = self.hyper_analysis(y)
+        zf, yf = z._canonical_features(), y._canonical_features()
+        yb = y._cset.keys[:y._cset.n] >> 48
+        scale, rescale = self._gains(q, y._cset, yf.shape[1])
+        if scale is not None:
+            scale = scale[yb]
+            rescale = rescale[yb].detach() if self.inverse_rescaling else rescale[yb]
+        else:
+            scale = rescale = torch.ones_like(yf)
+        eb, gc = self.entropy_bottleneck, self.gaussian_conditional
+        med = eb.quantiles[:, 0, 1].detach()
+        nz = self._noise("z", zf)
+        if self.quantization_mode == "uniform":
+            z_hat_f = zf + nz
+            z_lik = eb.likelihood_rows(z_hat_f)
+        else:
+            z_lik = eb.likelihood_rows(zf + nz)
+            z_hat_f = quantize_ste(zf - med) + med
+        params = self._gaussian_params(SparseTensor._from_canonical(z._cset, z_hat_f), y._cset)
+        c = yf.shape[1]
+        scales_hat, means_hat = params[:, :c], params[:, c:]
+        ny = self._noise("y", yf)
+        if self.quantization_offset:
+            tmp = scale * (yf - means_hat)
+            signs = torch.sign(tmp).detach()
+            a = torch.abs(tmp)
+            y_q_abs = a + ny if self.quantization_mode == "uniform" else quantize_ste(a)
+            y_lik = gc.likelihood_rows(yf * scale + ny, scales_hat * scale, means_hat * scale)
+            stdev = gc.lower_bound_scale(scales_hat * scale)
+            off = -self.get_offsets(stdev, scale.detach())
+            off = torch.where(y_q_abs < 0.0001, off.new_zeros(1), off)
+            y_hat = signs * (y_q_abs + off) * rescale + means_hat
+        else:
+            y_t = yf * scale + ny
+            y_lik = gc.likelihood_rows(y_t, scales_hat * scale, means_hat * scale)
+            y_hat = y_t * rescale
+        return SparseTensor._from_canonical(y._cset, y_hat), (y_lik, z_lik)

@@ -32,7 +32,16 @@ class UnifiedModel(CompressionModel):
         return self.entropy_model.aux_loss()
 
     def forward(self, x, q, Lambda):
-        raise L.PccError("UnifiedModel.forward (training step, BASELINE config 4) is not built in this round")
+        """Training forward (`model/model.py:45-90`): x = SparseTensor of colours; returns the dict the losses consume:
+        prediction, points (ground-truth coordinates at strides 4, 2, 1), occ_predictions, q_map, likelihoods."""
+        feats = torch.cat([torch.ones((x.C.shape[0], 1), device=x.device), x.F], dim=1)
+        x = SparseTensor(coordinates=x.C, features=feats, device=x.device)
+        coords = SparseTensor._from_canonical(x._cset, torch.ones((x._cset.n, 1), device=x.device))
+        y, k = self.g_a(x)
+        y_hat, likelihoods = self.entropy_model(y, q)
+        x_hat, points, predictions = self.g_s(y_hat, coords=coords, k=k)
+        return {"prediction": x_hat, "points": points, "occ_predictions": predictions, "q_map": Lambda,
+                "likelihoods": {"y": likelihoods[0], "z": likelihoods[1]}}
 
     @staticmethod
     def partition(pointcloud, block_size):

@@ -122,13 +122,17 @@ class SparseSynthesisTransform(nn.Module):
         reference `model/transforms.py:228-254`)."""
         seg, bids = batch_segments(prediction._cset)
         ks = [int(k[b]) if (seg[i + 1] > seg[i]) else 0 for i, b in enumerate(bids)]
-        return S.topk_mask(prediction._canonical_features(), seg, ks), sum(
+        return S.topk_mask(prediction._canonical_features().detach(), seg, ks), sum(
             min(kk, seg[i + 1] - seg[i]) for i, kk in enumerate(ks))
 
     @staticmethod
     def _prune_tensor(x, mask, n_keep):
         cs = x._cset
-        keys, feats, n = S.prune(cs.keys, cs.n, x._canonical_features(), mask, n_keep)
+        f = x._canonical_features()
+        if torch.is_grad_enabled() and f.requires_grad:      # training: row selection through autograd
+            keys, _, n = S.prune(cs.keys, cs.n, None, mask, n_keep)
+            return SparseTensor._from_canonical(S.CoordSet(keys, n, cs.ts, cs.bounds), f[mask])
+        keys, feats, n = S.prune(cs.keys, cs.n, f, mask, n_keep)
         return SparseTensor._from_canonical(S.CoordSet(keys, n, cs.ts, cs.bounds), feats)
 
     def forward(self, y, coords=None, k=None, trace=None):

@@ -18,6 +18,25 @@ def _idx(a):
     return torch.from_numpy(np.asarray(a, dtype=np.int64))
 
 
+class _LowerBound(torch.autograd.Function):
+    """CompressAI `LowerBound`: max(x, b); the gradient passes where x >= b OR it would push x up."""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        b = torch.tensor(float(bound), dtype=x.dtype)
+        ctx.save_for_backward(x, b)
+        return torch.max(x, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, b = ctx.saved_tensors
+        return ((x >= b) | (g < 0)).to(g.dtype) * g, None
+
+
+def lower_bound(x, b):
+    return _LowerBound.apply(x, b)
+
+
 def sparse_conv(f, W, b, pairs, n_out):
     W3 = W if W.dim() == 3 else W.unsqueeze(0)
     out = torch.zeros((n_out, W3.shape[2]), dtype=torch.float32)
@@ -45,7 +64,7 @@ def conv_layer(P, name, keys, f, ts, ks, stride=1, transposed=False, bias=True):
 
 def reparam(x, minimum=0.0):
     bound = (minimum + PEDESTAL) ** 0.5
-    return torch.clamp(x, min=bound) ** 2 - PEDESTAL          # LowerBound gradient differs only below the bound
+    return lower_bound(x, bound) ** 2 - PEDESTAL
 
 
 def gdn(P, name, f, inverse):
@@ -60,9 +79,9 @@ def std_cum(x):
 
 
 def gaussian_likelihood(v, scales, means):
-    s = torch.clamp(scales, min=0.11)
+    s = lower_bound(scales, 0.11)
     a = (v - means).abs()
-    return torch.clamp(std_cum((0.5 - a) / s) - std_cum((-0.5 - a) / s), min=1e-9)
+    return lower_bound(std_cum((0.5 - a) / s) - std_cum((-0.5 - a) / s), 1e-9)
 
 
 def eb_logits(P, x):     # x [C,1,N]
@@ -78,7 +97,7 @@ def eb_likelihood(P, v):  # v [N,C]
     x = v.t().unsqueeze(1)
     lo, up = eb_logits(P, x - 0.5), eb_logits(P, x + 0.5)
     sg = -torch.sign(lo + up).detach()
-    return torch.clamp((torch.sigmoid(sg * up) - torch.sigmoid(sg * lo)).abs(), min=1e-9)[:, 0, :].t()
+    return lower_bound((torch.sigmoid(sg * up) - torch.sigmoid(sg * lo)).abs(), 1e-9)[:, 0, :].t()
 
 
 def mlp(P, pre, x, n, softplus=False):
@@ -141,7 +160,7 @@ def forward_loss(P, cfg, C, rgb, q, Lambda, noise_y, noise_z, loss_cfg):
         a = tmp.abs()
         y_q_abs = a + noise_y if em["quantization_mode"] == "uniform" else a + (torch.round(a) - a).detach()
         y_lik = gaussian_likelihood(y * scale + noise_y, scales_hat * scale, means_hat * scale)
-        stdev = torch.clamp(scales_hat * scale, min=0.11)
+        stdev = lower_bound(scales_hat * scale, 0.11)
         off = -mlp(P, "entropy_model.quant_nn", torch.stack([scale.detach(), stdev], dim=-1), 3)[..., 0]
         off = torch.where(y_q_abs < 1e-4, torch.zeros(1), off)
         y_hat = signs * (y_q_abs + off) * rescale + means_hat

@@ -262,20 +262,25 @@ int pcc_rans_encode_host(const int32_t* h_sym, const int32_t* h_idx, int64_t n, 
 int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const int32_t* h_idx, int64_t n,
                          const int32_t* h_cdf, int32_t cdf_stride, const int32_t* h_sizes, const int32_t* h_offsets,
                          int32_t* h_sym);
-/* GPU, n_streams independent streams over a row-major [n, channels] int32 symbol matrix: stream s covers the
- * channels/n_streams (a power of two) adjacent channels starting at s*channels/n_streams, row by row, with table row
- * idx[same element] (idx NULL: row = channel, the factorised prior).  Container (device buffer `out`, capacity
- * pcc_rans_container_max_bytes(n*channels/n_streams, n_streams)): u32 n_streams | u32 nwords[n_streams] | stream words.
- * With n_streams = channels the concatenation of the streams is the reference's [1,C,N] channel-major order.
- * Each stream costs 12 bytes of framing: few streams for rate, many for speed. */
-int64_t pcc_rans_container_max_bytes(int64_t n, int32_t n_streams);
-size_t pcc_rans_streams_ws_bytes(int64_t n, int32_t n_streams);
-/* enc_table (nullable, device): division-free entries from pcc_rans_build_enc_table (16 bytes per (row, value),
- * layout [rows][cdf_stride]); NULL = 64-bit division per symbol.  Output bytes are identical either way. */
+/* GPU, n_groups * n_segments independent streams over a row-major [n, channels] int32 symbol matrix.  The matrix is
+ * cut into n_groups channel groups (channels/n_groups adjacent channels each, a power of two) and n_segments row
+ * segments of R = ceil(n / n_segments) rows; stream s = segment * n_groups + group codes its tile row by row, with table
+ * row idx[same element] (idx NULL: row = channel, the factorised prior).  Container (device buffer `out`, capacity
+ * pcc_rans_container_max_bytes(pcc_rans_stream_symbols(...), n_groups * n_segments)):
+ *   u32 n_streams | u32 nwords[n_streams] | stream words.
+ * Every stream is byte-identical to the host single-stream coder run on that tile.  With n_groups = channels and
+ * n_segments = 1 the concatenation of the streams is the reference's [1,C,N] channel-major order.  Each stream costs
+ * 12 bytes of framing: few streams for rate, many for speed (one lane per stream).  Limits: 65536 streams,
+ * n * channels < 2^31. */
+int64_t pcc_rans_stream_symbols(int64_t n, int32_t channels, int32_t n_groups, int32_t n_segments); /* longest stream; -1: bad geometry */
+int64_t pcc_rans_container_max_bytes(int64_t stream_symbols, int32_t n_streams);
+size_t pcc_rans_streams_ws_bytes(int64_t stream_symbols, int32_t n_streams);
+/* enc_table (device, required): division-free entries from pcc_rans_build_enc_table (16 bytes per (row, value),
+ * layout [rows][cdf_stride]). */
 int pcc_rans_build_enc_table(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
                              void* h_table /*16*rows*cdf_stride bytes*/);
 int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t channels,
-                            int32_t n_streams, const int32_t* cdf, int32_t cdf_stride,
+                            int32_t n_groups, int32_t n_segments, const int32_t* cdf, int32_t cdf_stride,
                             const int32_t* sizes, const int32_t* offsets, const void* enc_table, uint8_t* out,
                             int64_t* d_nbytes, void* ws, size_t ws_bytes, void* stream);
 /* compact decoder table (host): 16-bit CDF rows back to back + a 256-bucket start table per row, one blob of
@@ -284,9 +289,9 @@ int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, i
 int64_t pcc_rans_dec_table_bytes(int32_t rows, const int32_t* h_sizes);
 int pcc_rans_build_dec_table(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
                              void* h_blob);
-/* *d_status != 0 after the kernel: malformed container.  `data` must be readable 4 bytes past nbytes (look-ahead). */
+/* *d_status != 0 after the kernel: malformed container.  `data` must be readable 8 bytes past nbytes (look-ahead). */
 int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n, int32_t channels,
-                            int32_t n_streams, const int32_t* cdf, int32_t cdf_stride,
+                            int32_t n_groups, int32_t n_segments, const int32_t* cdf, int32_t cdf_stride,
                             const int32_t* sizes, const int32_t* offsets, const void* dec_table /*nullable, device*/,
                             int64_t dec_bytes, int32_t* sym_out, int32_t* d_status, void* stream);
 

@@ -82,19 +82,24 @@ class EntropyModel(nn.Module):
         if self._quantized_cdf.numel() == 0 or self._cdf_length.numel() == 0 or self._offset.numel() == 0:
             raise L.PccError("entropy tables are empty: call model.update() first (`evaluate.py:89`)")
 
-    STREAM_SYMBOLS = 1536   # target symbols per GPU stream: each stream costs 12 bytes of framing
+    STREAM_SYMBOLS = 1536    # channel grouping: merge channels until a stream holds this many symbols
+    SEGMENT_SYMBOLS = 4096   # row segmentation: cut streams longer than twice this (12 bytes of framing per stream)
+    MAX_STREAMS = 4096
 
     def n_streams(self, n, c):
-        """Number of GPU streams for an [n, c] symbol matrix: a power-of-two split of the channels, as many streams as
-        keep >= STREAM_SYMBOLS symbols each (rate), at most one per channel (speed).  Encoder and decoder both derive
-        it from (n, c), so it is not transmitted."""
-        ns = c
-        while ns % 2 == 0 and n * (c // ns) < self.STREAM_SYMBOLS:
-            g = c // (ns // 2)
+        """(channel groups, row segments) of the GPU streams for an [n, c] symbol matrix.  Small inputs: a power-of-two
+        merge of channels so that every stream keeps >= STREAM_SYMBOLS symbols (rate).  Large inputs: one group per
+        channel, rows cut into segments of >= SEGMENT_SYMBOLS symbols (speed: one GPU lane per stream).  Encoder and
+        decoder both derive it from (n, c), so it is not transmitted."""
+        ng = c
+        while ng % 2 == 0 and n * (c // ng) < self.STREAM_SYMBOLS:
+            g = c // (ng // 2)
             if g & (g - 1):            # group size must stay a power of two
                 break
-            ns //= 2
-        return ns
+            ng //= 2
+        per = n * (c // ng)
+        segs = max(1, min(per // max(1, self.SEGMENT_SYMBOLS), max(1, self.MAX_STREAMS // ng)))
+        return ng, segs
 
     # ---- coding of [N, C] int32 symbol rows (the layout the kernels produce) -------------------------------
     def compress_rows(self, sym, idx=None):
@@ -110,13 +115,14 @@ class EntropyModel(nn.Module):
                  else np.repeat(np.arange(c, dtype=np.int32), n))
             return self._host_encode(s, np.ascontiguousarray(i, np.int32))
         lib = L.load()
-        ns = self.n_streams(n, c)
-        per = n * (c // ns)
+        ng, segs = self.n_streams(n, c)
+        ns = ng * segs
+        per = lib.pcc_rans_stream_symbols(n, c, ng, segs)
         cap = lib.pcc_rans_container_max_bytes(per, ns)
         out = torch.empty(cap, dtype=torch.uint8, device=dev)
         nb = torch.zeros(1, dtype=torch.int64, device=dev)
         ws = L.workspace(lib.pcc_rans_streams_ws_bytes(per, ns), dev)
-        L.call("pcc_rans_encode_streams", L.ptr(sym), L.ptr(idx.contiguous()) if idx is not None else None, n, c, ns,
+        L.call("pcc_rans_encode_streams", L.ptr(sym), L.ptr(idx.contiguous()) if idx is not None else None, n, c, ng, segs,
                L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._enc_table(dev)), L.ptr(out), L.ptr(nb),
                L.ptr(ws), ws.numel(), L.stream())
         return out[:int(nb.item())].cpu().numpy().tobytes()
@@ -136,7 +142,7 @@ class EntropyModel(nn.Module):
         sym = torch.empty((n, c), dtype=torch.int32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         L.call("pcc_rans_decode_streams", L.ptr(buf), len(data), L.ptr(idx.contiguous()) if idx is not None else None,
-               n, c, self.n_streams(n, c), L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs),
+               n, c, *self.n_streams(n, c), L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs),
                L.ptr(self._dec_table(dev)), self._dec_table(dev).numel(), L.ptr(sym), L.ptr(status), L.stream())
         if check is None:                       # synchronous check (one device->host read)
             st = int(status.item())

@@ -338,64 +338,108 @@ extern "C" int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const
 }
 
 // ------------------------------------------------------------------------------------------
-// GPU: one stream per channel
+// GPU: many independent streams, one per lane
+//   The [n, channels] symbol matrix is cut into n_groups channel groups (2^gl adjacent channels each) times n_segments
+//   row segments of R = ceil(n / n_segments) rows; stream s = segment * n_groups + group codes its tile row by row.
 //   container: u32 n_streams | u32 nwords[n_streams] | words of stream 0 | words of stream 1 | ...
+//   A lone wave issues about one instruction every 4-5 cycles and the coder state is a serial chain, so speed comes
+//   from (a) many streams (segments), and (b) few instructions per symbol: 32-bit addressing, everything that does
+//   not depend on the state resolved up front, tables in LDS addressed as LDS.
 // ------------------------------------------------------------------------------------------
+static constexpr int GB = 8;                        // symbols per prefetch batch in the GPU coders
+static constexpr unsigned short R_ESC = 0x8000;     // RansEncSym::rcp_shift flag: bypass payload in pre_r
+
+struct StreamGeom { int n, channels, n_groups, gl, R, n_streams; };
+
+__device__ inline unsigned wave_incl_scan(unsigned v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ inline int wave_min(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
 // Pass 1 (one thread per symbol, fully parallel): resolve every symbol to its division-free encoder entry and its
 // bypass payload, laid out [position in stream][stream] so that the sequential coder's reads are lane-contiguous.
-__global__ void __launch_bounds__(256) k_rans_prepare(const int* __restrict__ sym, const int* __restrict__ idx, long long n,
-                                                      int channels, int n_streams, int gl, RansTab t,
-                                                      const RansEncSym* __restrict__ enc, RansEncSym* __restrict__ pre_e,
-                                                      unsigned* __restrict__ pre_r) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n * channels) return;
-  const long long i = e / channels;
-  const int ch = (int)(e - i * channels);
+__global__ void __launch_bounds__(256) k_rans_prepare(const int* __restrict__ sym, const int* __restrict__ idx, StreamGeom g,
+                                                      RansTab t, const RansEncSym* __restrict__ enc,
+                                                      RansEncSym* __restrict__ pre_e, unsigned* __restrict__ pre_r) {
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= (unsigned)g.n * (unsigned)g.channels) return;
+  const int i = (int)(e / (unsigned)g.channels);
+  const int ch = (int)(e - (unsigned)i * (unsigned)g.channels);
   const int ci = idx ? idx[e] : ch;
   const int max_value = t.sizes[ci] - 2;
   int v = sym[e] - t.offsets[ci];
-  unsigned raw = 0xFFFFFFFFu;
-  if (v < 0) { raw = (unsigned)(-2 * v - 1); v = max_value; }
-  else if (v >= max_value) { raw = (unsigned)(2 * (v - max_value)); v = max_value; }
-  const long long j = (i << gl) + (ch & ((1 << gl) - 1));
-  const long long o = j * n_streams + (ch >> gl);
-  pre_e[o] = enc[(long long)ci * t.stride + v];
-  pre_r[o] = raw;
+  unsigned raw = 0;
+  bool esc = false;
+  if (v < 0) { raw = (unsigned)(-2 * v - 1); v = max_value; esc = true; }
+  else if (v >= max_value) { raw = (unsigned)(2 * (v - max_value)); v = max_value; esc = true; }
+  const int seg = i / g.R;
+  const int j = ((i - seg * g.R) << g.gl) + (ch & ((1 << g.gl) - 1));
+  const size_t o = (size_t)j * g.n_streams + (seg * g.n_groups + (ch >> g.gl));
+  RansEncSym es = enc[(size_t)ci * t.stride + v];
+  if (esc) { es.rcp_shift |= R_ESC; pre_r[o] = raw; }
+  pre_e[o] = es;
 }
 
-// Pass 2 (one lane per stream): the state recurrence, fed from the prepared entries.  Batches of RB entries are
-// loaded one batch ahead of their use, so the only serial dependence left is the coder state itself.
+__device__ __forceinline__ void enc_one(unsigned long long& x, unsigned*& ptr, const RansEncSym& e,
+                                        const unsigned* __restrict__ pre_r, size_t o) {
+  if (e.rcp_shift & R_ESC) r_put_bypass(x, ptr, pre_r[o]);
+  const unsigned freq = (1u << R_PREC) - e.cmpl_freq;
+  if ((unsigned)(x >> 32) >= (freq << (31 - R_PREC))) { *--ptr = (unsigned)x; x >>= 32; }   // x >= freq << 47
+  const unsigned long long q = __umul64hi(x, e.rcp_freq) >> (e.rcp_shift & 63);
+  x = x + e.bias + q * e.cmpl_freq;
+}
+
+// Pass 2 (one lane per stream): the state recurrence, fed from the prepared entries in reverse symbol order.
+// Batches of GB entries are loaded one batch ahead of their use.
 __global__ void __launch_bounds__(64) k_rans_encode(const RansEncSym* __restrict__ pre_e, const unsigned* __restrict__ pre_r,
-                                                    long long n_per_stream, int n_streams,
-                                                    unsigned* __restrict__ scratch, long long cap_words,
+                                                    StreamGeom g, unsigned* __restrict__ scratch, long long cap_words,
                                                     int* __restrict__ nwords) {
   const int s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= n_streams) return;
-  unsigned* end = scratch + (long long)(s + 1) * cap_words;
+  const bool valid = s < g.n_streams;
+  const int seg = s / g.n_groups;
+  int rows = g.n - seg * g.R;
+  rows = rows < 0 ? 0 : (rows > g.R ? g.R : rows);
+  const int cnt = valid ? (rows << g.gl) : 0;
+  const int cfast = __builtin_amdgcn_readfirstlane(wave_min(valid ? cnt : 0x7FFFFFFF)) / GB * GB;
+  if (!valid) return;
+  const int cmax = g.R << g.gl;
+  unsigned* const end = scratch + (size_t)(s + 1) * cap_words;
   unsigned* ptr = end;
   unsigned long long x = R_L;
-  RansEncSym ea[RB], eb[RB];
-  unsigned ra[RB], rb[RB];
-  auto load = [&](long long base, RansEncSym (&e)[RB], unsigned (&r)[RB]) {
-#pragma unroll
-    for (int u = 0; u < RB; ++u) {
-      const long long j = base - 1 - u;
-      r[u] = 0xFFFFFFFEu;                                     // marker: past the start of the stream
-      if (j >= 0) { e[u] = pre_e[j * n_streams + s]; r[u] = pre_r[j * n_streams + s]; }
+  const unsigned ns = (unsigned)g.n_streams;
+  // ragged top (only where a wave spans the short last segment): per-lane predicate
+  for (int j = cmax - 1; j >= cfast; --j) {
+    if (j < cnt) {
+      const size_t o = (size_t)j * ns + s;
+      const RansEncSym e = pre_e[o];
+      enc_one(x, ptr, e, pre_r, o);
     }
-  };
-  load(n_per_stream, ea, ra);
-  for (long long base = n_per_stream; base > 0; base -= RB) {
-    load(base - RB, eb, rb);                                  // next batch in flight while this one is coded
+  }
+  // full batches, wave-uniform trip count
+  RansEncSym ea[GB], eb[GB];
+  if (cfast > 0) {
 #pragma unroll
-    for (int u = 0; u < RB; ++u) {
-      if (ra[u] != 0xFFFFFFFEu) {
-        if (ra[u] != 0xFFFFFFFFu) r_put_bypass(x, ptr, ra[u]);
-        r_put_sym(x, ptr, ea[u]);
-      }
+    for (int u = 0; u < GB; ++u) ea[u] = pre_e[(size_t)(cfast - 1 - u) * ns + s];
+  }
+  for (int base = cfast; base > 0; base -= GB) {
+    if (base > GB) {
+#pragma unroll
+      for (int u = 0; u < GB; ++u) eb[u] = pre_e[(size_t)(base - GB - 1 - u) * ns + s];
     }
 #pragma unroll
-    for (int u = 0; u < RB; ++u) { ea[u] = eb[u]; ra[u] = rb[u]; }
+    for (int u = 0; u < GB; ++u) enc_one(x, ptr, ea[u], pre_r, (size_t)(base - 1 - u) * ns + s);
+#pragma unroll
+    for (int u = 0; u < GB; ++u) ea[u] = eb[u];
   }
   ptr -= 2;
   ptr[0] = (unsigned)x;
@@ -403,61 +447,158 @@ __global__ void __launch_bounds__(64) k_rans_encode(const RansEncSym* __restrict
   nwords[s] = (int)(end - ptr);
 }
 
-__global__ void __launch_bounds__(256) k_rans_pack(const unsigned* __restrict__ scratch, long long cap_words,
-                                                   const int* __restrict__ nwords, int n_streams,
-                                                   unsigned* __restrict__ out, long long* __restrict__ d_nbytes) {
-  __shared__ long long total;
-  // few hundred streams: a serial prefix by one thread is cheaper than a scan launch
-  extern __shared__ long long offs[];
+// one block per stream: position = sum of the lengths before it
+__global__ void __launch_bounds__(64) k_rans_pack(const unsigned* __restrict__ scratch, long long cap_words,
+                                                  const int* __restrict__ nwords, int n_streams,
+                                                  unsigned* __restrict__ out, long long* __restrict__ d_nbytes) {
+  const int s = blockIdx.x;
+  unsigned part = 0;
+  for (int i = threadIdx.x; i < s; i += 64) part += (unsigned)nwords[i];
+  const unsigned off = __shfl(wave_incl_scan(part), 63, 64);
+  const int len = nwords[s];
   if (threadIdx.x == 0) {
-    long long run = 0;
-    for (int s = 0; s < n_streams; ++s) { offs[s] = run; run += nwords[s]; }
-    total = run;
-    out[0] = (unsigned)n_streams;
-    *d_nbytes = 4ll * (1 + n_streams + run);
+    out[1 + s] = (unsigned)len;
+    if (s == 0) out[0] = (unsigned)n_streams;
+    if (s == n_streams - 1) *d_nbytes = 4ll * (1 + n_streams + (long long)off + len);
   }
-  __syncthreads();
-  for (int s = threadIdx.x; s < n_streams; s += 256) out[1 + s] = (unsigned)nwords[s];
-  unsigned* dst = out + 1 + n_streams;
-  for (int s = 0; s < n_streams; ++s) {
-    const unsigned* src = scratch + (long long)(s + 1) * cap_words - nwords[s];
-    for (int i = threadIdx.x; i < nwords[s]; i += 256) dst[offs[s] + i] = src[i];
-  }
-  (void)total;
+  const unsigned* src = scratch + (size_t)(s + 1) * cap_words - len;
+  unsigned* dst = out + 1 + n_streams + off;
+  for (int i = threadIdx.x; i < len; i += 64) dst[i] = src[i];
 }
 
-__global__ void __launch_bounds__(64) k_rans_decode(const unsigned* __restrict__ data, long long nwords_total,
-                                                    const int* __restrict__ idx, long long n, int n_streams,
-                                                    int gl, long long row_stride, RansTab t,
-                                                    const int* __restrict__ dec_blob, int dec_words_lds,
-                                                    int* __restrict__ out, int* __restrict__ status) {
-  extern __shared__ int blob_s[];
-  RansDecTab d{nullptr, nullptr, nullptr};
-  if (dec_blob) {
-    const int* b = dec_blob;
-    if (dec_words_lds > 0) {                            // the whole table fits LDS: symbol search at LDS latency
-      for (int i = threadIdx.x; i < dec_words_lds; i += blockDim.x) blob_s[i] = dec_blob[i];
-      __syncthreads();
-      b = blob_s;
-    }
-    const int rows = b[0];
-    d.row_off = b + 2;
-    d.lut = (const unsigned short*)(b + 2 + rows + 1);
-    d.cdf16 = d.lut + (long long)rows * 256;
+// ---- decoder -------------------------------------------------------------------------------
+struct DecLds { const int* row_off; const unsigned short* lut; const unsigned short* c16; const int* offs; };
+
+__device__ __forceinline__ unsigned dec_bits(unsigned long long& x, unsigned& nw, unsigned& pos,
+                                             const unsigned* __restrict__ data, unsigned lim) {
+  const unsigned v = (unsigned)x & R_MAXB;
+  x >>= R_BYP;
+  if (x < R_L) { x = (x << 32) | nw; ++pos; nw = data[min(pos, lim)]; }
+  return v;
+}
+
+// rare path, kept out of line and register-to-register (by value) so the hot loop's state never touches memory
+struct DecState { unsigned long long x; unsigned nw, pos; int value; };
+__device__ __noinline__ DecState dec_bypass(unsigned long long x, unsigned nw, unsigned pos, const unsigned* __restrict__ data,
+                                            unsigned lim, int max_value) {
+  unsigned val = dec_bits(x, nw, pos, data, lim);
+  int nb = (int)val;
+  while (val == R_MAXB && nb < 64) { val = dec_bits(x, nw, pos, data, lim); nb += (int)val; }
+  unsigned raw = 0;
+  for (int j = 0; j < nb; ++j) { const unsigned b = dec_bits(x, nw, pos, data, lim); if (j < 8) raw |= b << (j * R_BYP); }
+  const int value = (int)(raw >> 1);
+  return DecState{x, nw, pos, (raw & 1) ? -value - 1 : value + max_value};
+}
+
+// One symbol: bucket look-up + short scan in the LDS tables, state update, renormalisation from the look-ahead word.
+__device__ __forceinline__ int dec_one(int ci, unsigned long long& x, unsigned& nw, unsigned& pos,
+                                       const unsigned* __restrict__ data, unsigned lim, const DecLds& d) {
+  const int ro = d.row_off[ci];
+  const int last = d.row_off[ci + 1] - ro - 2;          // c[last + 1] is 2^16 stored as 0: never compared against
+  const unsigned cum = (unsigned)x & 0xFFFFu;
+  int lo = d.lut[ci * 256 + (cum >> 8)];
+  const unsigned short* c = d.c16 + ro;
+  unsigned cur = c[lo], nxt = c[lo + 1];
+  while (lo < last && nxt <= cum) { ++lo; cur = nxt; nxt = c[lo + 1]; }
+  const unsigned freq = ((nxt - cur - 1u) & 0xFFFFu) + 1u;
+  x = (unsigned long long)freq * (x >> R_PREC) + (cum - cur);
+  if (x < R_L) { x = (x << 32) | nw; ++pos; nw = data[min(pos, lim)]; }
+  int value = lo;
+  if (lo == last) {
+    const DecState b = dec_bypass(x, nw, pos, data, lim, last);
+    x = b.x; nw = b.nw; pos = b.pos; value = b.value;
   }
+  return value + d.offs[ci];
+}
+
+template <bool HAS_IDX>
+__global__ void __launch_bounds__(256) k_rans_decode_lds(const unsigned* __restrict__ data, unsigned nwords_total,
+                                                         const int* __restrict__ idx, StreamGeom g,
+                                                         const int* __restrict__ offsets, const int* __restrict__ dec_blob,
+                                                         int dec_words, int* __restrict__ out, int* __restrict__ status) {
+  extern __shared__ int blob_s[];                      // decoder table | per-row value offsets | scan scratch
+  const int tid = threadIdx.x;
+  for (int i = tid; i < dec_words; i += 256) blob_s[i] = dec_blob[i];
+  __syncthreads();
+  const int rows_tab = blob_s[0];
+  int* offs_s = blob_s + dec_words;
+  for (int i = tid; i < rows_tab; i += 256) offs_s[i] = offsets[i];
+  unsigned* red = (unsigned*)(offs_s + rows_tab);      // [0..3] per-wave totals of `part`, [4..7] of `len`
+  DecLds d;
+  d.row_off = blob_s + 2;
+  d.lut = (const unsigned short*)(blob_s + 2 + rows_tab + 1);
+  d.c16 = d.lut + rows_tab * 256;
+  d.offs = offs_s;
+  if ((int)data[0] != g.n_streams) { if (tid == 0) *status = 1; return; }
+  // stream position: lengths of all earlier blocks (strided partial sums) + exclusive scan inside the block
+  const int s = blockIdx.x * 256 + tid;
+  unsigned part = 0;
+  for (int i = tid; i < blockIdx.x * 256; i += 256) part += data[1 + i];
+  const unsigned len = s < g.n_streams ? data[1 + s] : 0u;
+  const unsigned pscan = wave_incl_scan(part), lscan = wave_incl_scan(len);
+  if ((tid & 63) == 63) { red[tid >> 6] = pscan; red[4 + (tid >> 6)] = lscan; }
+  __syncthreads();
+  unsigned off = 1u + (unsigned)g.n_streams + red[0] + red[1] + red[2] + red[3] + (lscan - len);
+  for (int w = 0; w < (tid >> 6); ++w) off += red[4 + w];
+  const bool valid = s < g.n_streams;
+  const int seg = s / g.n_groups, grp = s - seg * g.n_groups;
+  int rows = g.n - seg * g.R;
+  rows = rows < 0 ? 0 : (rows > g.R ? g.R : rows);
+  const int cnt = valid ? (rows << g.gl) : 0;
+  const int cfast = __builtin_amdgcn_readfirstlane(wave_min(valid ? cnt : 0x7FFFFFFF)) / GB * GB;
+  if (!valid) return;
+  if ((unsigned long long)off + len > nwords_total || len < 2) { *status = 2; return; }
+  const unsigned lim = nwords_total + 1;               // the buffer is padded by two words
+  const int gm = (1 << g.gl) - 1;
+  const int ch0 = grp << g.gl;
+  const unsigned lane_base = (unsigned)(seg * g.R) * (unsigned)g.channels + (unsigned)ch0;
+  unsigned pos = off + 2;
+  unsigned long long x = (unsigned long long)data[off] | ((unsigned long long)data[off + 1] << 32);
+  unsigned nw = data[min(pos, lim)];
+  int j = 0;
+  for (; j < cfast; j += GB) {                         // wave-uniform trip count, no per-symbol predicates
+    int ci[GB];
+    unsigned a[GB];
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      a[u] = lane_base + (unsigned)((j + u) >> g.gl) * (unsigned)g.channels + (unsigned)((j + u) & gm);
+      ci[u] = HAS_IDX ? idx[a[u]] : ch0 + ((j + u) & gm);
+    }
+#pragma unroll
+    for (int u = 0; u < GB; ++u) out[a[u]] = dec_one(ci[u], x, nw, pos, data, lim, d);
+  }
+  const int cmax = g.R << g.gl;
+  for (; j < cmax; ++j) {
+    if (j < cnt) {
+      const unsigned a = lane_base + (unsigned)(j >> g.gl) * (unsigned)g.channels + (unsigned)(j & gm);
+      const int ci = HAS_IDX ? idx[a] : ch0 + (j & gm);
+      out[a] = dec_one(ci, x, nw, pos, data, lim, d);
+    }
+  }
+  if (pos - 1 - off > len) *status = 3;                // consumed past its own stream: corrupt input
+}
+
+// fallback when the decoder table does not fit LDS: generic search in global memory
+__global__ void __launch_bounds__(64) k_rans_decode_global(const unsigned* __restrict__ data, long long nwords_total,
+                                                           const int* __restrict__ idx, StreamGeom g, RansTab t,
+                                                           int* __restrict__ out, int* __restrict__ status) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_streams) return;
-  if ((int)data[0] != n_streams) { *status = 1; return; }
-  long long off = 1 + n_streams;
+  if (s >= g.n_streams) return;
+  if ((int)data[0] != g.n_streams) { *status = 1; return; }
+  long long off = 1 + g.n_streams;
   for (int i = 0; i < s; ++i) off += data[1 + i];
   const long long len = data[1 + s];
   if (off + len > nwords_total || len < 2) { *status = 2; return; }
-  const long long ch0 = (long long)s << gl;
-  const unsigned* p = r_decode(data + off, idx ? idx + ch0 : nullptr, (int)ch0, n << gl, gl, row_stride, t, d, out + ch0);
-  if (p - (data + off) > len) *status = 3;      // read past its own stream: corrupt input
+  const int seg = s / g.n_groups, grp = s - seg * g.n_groups;
+  long long rows = (long long)g.n - (long long)seg * g.R;
+  rows = rows < 0 ? 0 : (rows > g.R ? g.R : rows);
+  const long long e0 = (long long)seg * g.R * g.channels + ((long long)grp << g.gl);
+  const unsigned* p = r_decode(data + off, idx ? idx + e0 : nullptr, grp << g.gl, rows << g.gl, g.gl, g.channels, t,
+                               RansDecTab{nullptr, nullptr, nullptr}, out + e0);
+  if (p - (data + off) > len) *status = 3;
 }
 
-// n = symbols per stream
+// n = symbols per stream (the longest one)
 extern "C" int64_t pcc_rans_container_max_bytes(int64_t n, int32_t n_streams) {
   return 4 * (1 + (int64_t)n_streams) + (int64_t)n_streams * pcc_rans_max_bytes(n);
 }
@@ -468,74 +609,99 @@ extern "C" size_t pcc_rans_streams_ws_bytes(int64_t n, int32_t n_streams) {
          pcc_align_up((size_t)n_streams * (size_t)n * 16) + pcc_align_up((size_t)n_streams * (size_t)n * 4) + 1024;
 }
 
-static int group_log2(int channels, int n_streams) {
-  if (n_streams < 1 || channels % n_streams) return -1;
-  const int g = channels / n_streams;
+static int stream_geom(int64_t n, int channels, int n_groups, int n_segments, StreamGeom* g) {
+  if (n_groups < 1 || n_segments < 1 || channels < 1 || channels % n_groups) return -1;
+  const int grp = channels / n_groups;
   int l = 0;
-  while ((1 << l) < g) ++l;
-  return (1 << l) == g ? l : -1;
+  while ((1 << l) < grp) ++l;
+  if ((1 << l) != grp) return -1;
+  if ((int64_t)n_groups * n_segments > 65536 || n * channels >= (1ll << 31)) return -1;
+  g->n = (int)n; g->channels = channels; g->n_groups = n_groups; g->gl = l;
+  g->R = (int)((n + n_segments - 1) / n_segments);
+  if (g->R < 1) g->R = 1;
+  g->n_streams = n_groups * n_segments;
+  return 0;
+}
+
+extern "C" int64_t pcc_rans_stream_symbols(int64_t n, int32_t channels, int32_t n_groups, int32_t n_segments) {
+  StreamGeom g;
+  if (stream_geom(n, channels, n_groups, n_segments, &g)) return -1;
+  return (int64_t)g.R << g.gl;
 }
 
 extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t channels,
-                                       int32_t n_streams, const int32_t* cdf,
+                                       int32_t n_groups, int32_t n_segments, const int32_t* cdf,
                                        int32_t cdf_stride, const int32_t* sizes, const int32_t* offsets,
                                        const void* enc_table, uint8_t* out, int64_t* d_nbytes, void* ws,
                                        size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(sym && cdf && sizes && offsets && out && d_nbytes && ws, "pcc_rans_encode_streams: NULL array");
   PCC_REQUIRE(enc_table, "pcc_rans_encode_streams: enc_table is required (pcc_rans_build_enc_table)");
-  PCC_REQUIRE(n >= 0 && n_streams >= 1 && n_streams <= 4096, "pcc_rans_encode_streams: bad stream count %d", n_streams);
-  const int gl = group_log2(channels, n_streams);
-  PCC_REQUIRE(gl >= 0, "pcc_rans_encode_streams: %d channels do not split into %d power-of-two groups", channels, n_streams);
-  const int64_t per_stream = n << gl;
-  if (ws_bytes < pcc_rans_streams_ws_bytes(per_stream, n_streams)) {
+  StreamGeom g;
+  PCC_REQUIRE(n >= 0 && stream_geom(n, channels, n_groups, n_segments, &g) == 0,
+              "pcc_rans_encode_streams: bad geometry: %d channels, %d groups (power-of-two size), %d segments, "
+              "at most 65536 streams and 2^31 symbols", channels, n_groups, n_segments);
+  const int64_t per_stream = (int64_t)g.R << g.gl;
+  if (ws_bytes < pcc_rans_streams_ws_bytes(per_stream, g.n_streams)) {
     pcc_set_error("pcc_rans_encode_streams: workspace too small");
     return PCC_EWS;
   }
   const long long cap = 2 * per_stream + 4;
   char* p = (char*)ws;
-  unsigned* scratch = (unsigned*)p;     p += (size_t)n_streams * cap * 4;
-  int* nwords = (int*)p;                p += pcc_align_up((size_t)n_streams * 4);
-  RansEncSym* pre_e = (RansEncSym*)p;   p += pcc_align_up((size_t)n_streams * (size_t)per_stream * 16);
+  unsigned* scratch = (unsigned*)p;     p += (size_t)g.n_streams * cap * 4;
+  int* nwords = (int*)p;                p += pcc_align_up((size_t)g.n_streams * 4);
+  RansEncSym* pre_e = (RansEncSym*)p;   p += pcc_align_up((size_t)g.n_streams * (size_t)per_stream * 16);
   unsigned* pre_r = (unsigned*)p;
   RansTab t{cdf, cdf_stride, sizes, offsets};
   if (n > 0) {
-    k_rans_prepare<<<(unsigned)pcc_cdiv(n * channels, 256), 256, 0, s>>>(sym, idx, n, channels, n_streams, gl, t,
-                                                                        (const RansEncSym*)enc_table, pre_e, pre_r);
+    k_rans_prepare<<<(unsigned)pcc_cdiv(n * channels, 256), 256, 0, s>>>(sym, idx, g, t, (const RansEncSym*)enc_table,
+                                                                        pre_e, pre_r);
     PCC_LAUNCH_CHECK();
   }
-  k_rans_encode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, 0, s>>>(pre_e, pre_r, per_stream, n_streams, scratch, cap, nwords);
+  k_rans_encode<<<(unsigned)pcc_cdiv(g.n_streams, 64), 64, 0, s>>>(pre_e, pre_r, g, scratch, cap, nwords);
   PCC_LAUNCH_CHECK();
-  k_rans_pack<<<1, 256, (size_t)n_streams * sizeof(long long), s>>>(scratch, cap, nwords, n_streams, (unsigned*)out, (long long*)d_nbytes);
+  k_rans_pack<<<g.n_streams, 64, 0, s>>>(scratch, cap, nwords, g.n_streams, (unsigned*)out, (long long*)d_nbytes);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
 
 extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, const int32_t* idx, int64_t n,
-                                       int32_t channels, int32_t n_streams,
+                                       int32_t channels, int32_t n_groups, int32_t n_segments,
                                        const int32_t* cdf, int32_t cdf_stride, const int32_t* sizes,
                                        const int32_t* offsets, const void* dec_table, int64_t dec_bytes, int32_t* sym_out,
                                        int32_t* d_status, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(data && cdf && sizes && offsets && sym_out && d_status, "pcc_rans_decode_streams: NULL array");
-  PCC_REQUIRE(n >= 0 && n_streams >= 1 && n_streams <= 4096, "pcc_rans_decode_streams: bad stream count %d", n_streams);
-  PCC_REQUIRE(nbytes >= 4 * (1 + (int64_t)n_streams) && nbytes % 4 == 0, "pcc_rans_decode_streams: truncated container");
-  const int gl = group_log2(channels, n_streams);
-  PCC_REQUIRE(gl >= 0, "pcc_rans_decode_streams: %d channels do not split into %d power-of-two groups", channels, n_streams);
+  StreamGeom g;
+  PCC_REQUIRE(n >= 0 && stream_geom(n, channels, n_groups, n_segments, &g) == 0,
+              "pcc_rans_decode_streams: bad geometry: %d channels, %d groups (power-of-two size), %d segments, "
+              "at most 65536 streams and 2^31 symbols", channels, n_groups, n_segments);
+  PCC_REQUIRE(nbytes >= 4 * (1 + (int64_t)g.n_streams) && nbytes % 4 == 0 && nbytes < (1ll << 33),
+              "pcc_rans_decode_streams: truncated container");
   PCC_CHECK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
   RansTab t{cdf, cdf_stride, sizes, offsets};
   // decoder table in LDS when it fits (Gaussian scale table: ~90 KB; factorised prior: ~110 KB)
-  const bool in_lds = dec_table && dec_bytes > 0 && dec_bytes <= 150 * 1024;
-  const size_t lds = in_lds ? (size_t)dec_bytes : 0;
-  static bool attr_set = false;
-  if (in_lds && !attr_set) {
-    PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_rans_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
+  const bool in_lds = dec_table && dec_bytes > 0 && dec_bytes <= 150 * 1024 && dec_bytes % 4 == 0;
+  if (in_lds) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_rans_decode_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_rans_decode_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    // LDS: table + per-row offsets (row count = first word of the table, bounded by its size) + scan scratch
+    const size_t lds = (size_t)dec_bytes + (size_t)dec_bytes / 128 + 64;
+    const unsigned blocks = (unsigned)pcc_cdiv(g.n_streams, 256);
+    if (idx)
+      k_rans_decode_lds<true><<<blocks, 256, lds, s>>>((const unsigned*)data, (unsigned)(nbytes / 4), idx, g, offsets,
+                                                      (const int*)dec_table, (int)(dec_bytes / 4), sym_out, d_status);
+    else
+      k_rans_decode_lds<false><<<blocks, 256, lds, s>>>((const unsigned*)data, (unsigned)(nbytes / 4), idx, g, offsets,
+                                                       (const int*)dec_table, (int)(dec_bytes / 4), sym_out, d_status);
+  } else {
+    k_rans_decode_global<<<(unsigned)pcc_cdiv(g.n_streams, 64), 64, 0, s>>>((const unsigned*)data, nbytes / 4, idx, g, t,
+                                                                           sym_out, d_status);
   }
-  k_rans_decode<<<(unsigned)pcc_cdiv(n_streams, 64), 64, lds, s>>>((const unsigned*)data, nbytes / 4, idx, n, n_streams,
-                                                                    gl, channels, t, (const int*)dec_table,
-                                                                    in_lds ? (int)(dec_bytes / 4) : 0,
-                                                                    sym_out, d_status);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

@@ -490,7 +490,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Wave16Args {
   const float* feat; const float* wl; const float* bias; const int* hdr; const int* nbr; const int* rows;
-  float* out; long long n_out; int K, cout, act; float slope;
+  float* out; long long n_out, n_in; int K, cout, act; float slope;
 };
 
 template <int CIN>
@@ -599,6 +599,138 @@ __global__ void __launch_bounds__(512) k_conv_wave16(Wave16Args a) {
           const long long orow = a.rows ? a.rows[pos0 + rB] : pos0 + rB;
           a.out[orow * a.cout + r16] = act1(accB0[e] + accB1[e] + b, a.act, a.slope);
         }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_conv_wave16 for 3x3x3 conv maps in canonical row order (one segment, all 27 offsets, no row list), with z-run
+// reuse.  Rows are sorted with z fastest, so the dz = -1 / +1 neighbour of row r under offset (dx, dy) is, inside a
+// z-run, the dz = 0 neighbour of row r -/+ 1: the lane next door already holds it.  Per (dx, dy) group a wave gathers
+// the dz = 0 rows of its 16 positions once, takes the dz = -+1 operands from the adjacent lane (DPP row shift, guarded
+// by index equality, so any geometry is handled) and points the loads of everything it does not need at one shared
+// zero row (an L1 hit), which also removes every per-row validity branch.  PMC on the first version showed 7 VALU
+// instructions per MFMA competing for the SIMD; this one is written for instruction count: 32-bit offsets, no
+// identity / segment generality, tail rows clamped instead of predicated.
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+static constexpr int DPP_SHL1 = 0x101, DPP_SHR1 = 0x111;
+__device__ float g_zero_row[64];                 // zero-initialised: the row every absent neighbour reads
+
+template <int CIN>
+__global__ void __launch_bounds__(512) k_conv_wave16z(Wave16Args a) {
+  constexpr int LD = CIN + 4;
+  constexpr int G = CIN / 16;
+  constexpr int NW = 8;
+  extern __shared__ __attribute__((aligned(16))) float wl_s[];   // [27][16][LD]
+  for (int i = threadIdx.x; i < 27 * 16 * (CIN / 4); i += 512) {
+    const int row = i / (CIN / 4), c4 = i - row * (CIN / 4);
+    reinterpret_cast<float4*>(wl_s + row * LD)[c4] = reinterpret_cast<const float4*>(a.wl + (long long)row * CIN)[c4];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+  const unsigned spc = (unsigned)a.n_out;                          // one segment: positions = output rows
+  const unsigned total_tiles = (spc + 15) / 16;
+  const unsigned cpx = gridDim.x >> 3;
+  const unsigned per_xcd = (total_tiles + 7) / 8;
+  const unsigned xcd_lo = (blockIdx.x & 7) * per_xcd;
+  const unsigned xcd_hi = min(total_tiles, xcd_lo + per_xcd);
+  const float* wl_lane = wl_s + r16 * LD + 4 * q;
+  const char* fbase = reinterpret_cast<const char*>(a.feat) + 16 * q;
+  const char* zrow = reinterpret_cast<const char*>(g_zero_row) + 16 * q;
+
+  // One (dx,dy) group of a 16-row tile: the dz=0 rows, and the dz=-+1 rows, each either the neighbouring lane's dz=0
+  // row (mask k*) or loaded.  All rows come through buffer loads whose offset is out of range for an absent or
+  // not-needed row: those lanes read 0 without touching memory, the number of loads in flight is fixed (exact
+  // s_waitcnt distances; conditional loads made the compiler wait for the prefetch itself), and no branch is left.
+  struct Grp { float4 c[G], m[G], p[G]; unsigned km, kp; };
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.feat), (short)0, (int)(unsigned)((size_t)a.n_in * CIN * 4), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+
+  for (unsigned wt = xcd_lo + (blockIdx.x >> 3) * NW + (threadIdx.x >> 6); wt < xcd_hi; wt += cpx * NW) {
+    const unsigned pos0 = wt * 16;
+    const unsigned r = min(pos0 + r16, spc - 1);                   // tail rows repeat the last row, never stored
+    const int* nb = a.nbr + r;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+
+    auto issue = [&](int im, int ic, int ip, Grp& x) {
+      const int cm = dpp_i<DPP_SHR1>(ic), cp = dpp_i<DPP_SHL1>(ic);
+      const bool mm = im >= 0 && im == cm && r16 != 0;
+      const bool mp = ip >= 0 && ip == cp && r16 != 15;
+      x.km = mm ? 0xFFFFFFFFu : 0u;
+      x.kp = mp ? 0xFFFFFFFFu : 0u;
+      const unsigned oc = ic >= 0 ? (unsigned)ic * (CIN * 4) + 16 * q : OOB;
+      const unsigned om = (im >= 0 && !mm) ? (unsigned)im * (CIN * 4) + 16 * q : OOB;
+      const unsigned op = (ip >= 0 && !mp) ? (unsigned)ip * (CIN * 4) + 16 * q : OOB;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        x.c[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, oc + 64 * g, 0, 0));
+        x.m[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, om + 64 * g, 0, 0));
+        x.p[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, op + 64 * g, 0, 0));
+      }
+    };
+    auto mfma4 = [&](const float4& x, int slot, int g) {
+      const float4 w = *reinterpret_cast<const float4*>(wl_lane + (slot * 16) * LD + 16 * g);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, w.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, w.y, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, w.z, acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, w.w, acc3, 0, 0, 0);
+    };
+    auto mix = [](unsigned k, float shifted, float loaded) {   // (shifted & k) | loaded: loaded is 0 wherever k is set
+      return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, shifted) & k) | __builtin_bit_cast(unsigned, loaded));
+    };
+
+    // pipeline per wave: indices of group g9+2, feature rows of group g9+1, MFMAs of group g9
+    int im1 = nb[spc], ic1 = nb[10ull * spc], ip1 = nb[19ull * spc];                 // group 1
+    Grp x, y;
+    issue(nb[0], nb[9ull * spc], nb[18ull * spc], x);                                // group 0
+    auto compute = [&](const Grp& x, int g9) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float4 vm, vp;
+        vm.x = mix(x.km, dpp_f<DPP_SHR1>(x.c[g].x), x.m[g].x);  vp.x = mix(x.kp, dpp_f<DPP_SHL1>(x.c[g].x), x.p[g].x);
+        vm.y = mix(x.km, dpp_f<DPP_SHR1>(x.c[g].y), x.m[g].y);  vp.y = mix(x.kp, dpp_f<DPP_SHL1>(x.c[g].y), x.p[g].y);
+        vm.z = mix(x.km, dpp_f<DPP_SHR1>(x.c[g].z), x.m[g].z);  vp.z = mix(x.kp, dpp_f<DPP_SHL1>(x.c[g].z), x.p[g].z);
+        vm.w = mix(x.km, dpp_f<DPP_SHR1>(x.c[g].w), x.m[g].w);  vp.w = mix(x.kp, dpp_f<DPP_SHL1>(x.c[g].w), x.p[g].w);
+        mfma4(vm, g9, g);
+        mfma4(x.c[g], g9 + 9, g);
+        mfma4(vp, g9 + 18, g);
+      }
+    };
+    // two groups per trip, the buffers swapping roles, so that no register copy ties this group's MFMAs to the
+    // loads just issued for the next one (a copy made the compiler wait for them: no overlap at all)
+    // (sched_barrier: the machine scheduler otherwise sinks the prefetch loads next to their first use)
+#pragma unroll 1
+    for (int g9 = 0; g9 < 8; g9 += 2) {
+      const unsigned ga = (unsigned)(g9 + 2), gb = (unsigned)min(g9 + 3, 8);
+      const int am = nb[(size_t)ga * spc], ac = nb[(size_t)(ga + 9) * spc], ap = nb[(size_t)(ga + 18) * spc];
+      issue(im1, ic1, ip1, y);                                                       // group g9+1
+      __builtin_amdgcn_sched_barrier(0);
+      compute(x, g9);
+      __builtin_amdgcn_sched_barrier(0);
+      const int bm = nb[(size_t)gb * spc], bc = nb[(size_t)(gb + 9) * spc], bp = nb[(size_t)(gb + 18) * spc];
+      issue(am, ac, ap, x);                                                          // group g9+2
+      __builtin_amdgcn_sched_barrier(0);
+      compute(y, g9 + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      im1 = bm; ic1 = bc; ip1 = bp;
+    }
+    compute(x, 8);
+    // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+    if (r16 < a.cout) {
+      const float b = a.bias ? a.bias[r16] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned row = pos0 + 4 * q + e;
+        if (row < spc) a.out[(size_t)row * a.cout + r16] = act1(acc0[e] + acc1[e] + acc2[e] + acc3[e] + b, a.act, a.slope);
       }
     }
   }
@@ -757,6 +889,8 @@ static int launch_mfma(const ConvArgs& a, int tiles_bound_extra, hipStream_t s) 
   return PCC_OK;
 }
 
+static bool g_wave16_zrun = getenv("PCC_WAVE16_ZRUN") ? atoi(getenv("PCC_WAVE16_ZRUN")) != 0 : true;
+
 template <int CIN>
 static int launch_wave16(const Wave16Args& a, hipStream_t s) {
   const size_t lds = (size_t)a.K * 16 * (CIN + 4) * sizeof(float);
@@ -769,6 +903,18 @@ static int launch_wave16(const Wave16Args& a, hipStream_t s) {
   long long want = pcc_cdiv(tiles, 8);
   want = (want + 7) / 8 * 8;                                     // multiple of 8: one contiguous tile range per XCD
   const unsigned grid = (unsigned)(want < 512 ? want : 512);     // persistent: 2 workgroups (16 waves) per CU re-use the LDS weights
+  // 3x3x3 conv map in canonical row order (k_map_conv: one segment, all 27 offsets, no row list): z-run reuse variant
+  if (g_wave16_zrun && a.K == 27 && a.hdr && !a.rows && a.n_out * 27 < (1ll << 31) &&
+      a.n_in * CIN * 4 <= 0xFFFFFE00ll) {                          // 32-bit buffer offsets
+    static bool attr_z = false;
+    if (!attr_z) {
+      PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_wave16z<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      attr_z = true;
+    }
+    k_conv_wave16z<CIN><<<grid, 512, lds, s>>>(a);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+  }
   k_conv_wave16<CIN><<<grid, 512, lds, s>>>(a);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
@@ -806,7 +952,7 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
   } else if (kind == KIND_WAVE16) {
     Wave16Args a;
     a.feat = feat_in; a.wl = packed_w; a.bias = bias; a.hdr = hdr; a.nbr = nbr; a.rows = rows; a.out = out;
-    a.n_out = n_out; a.K = K; a.cout = cout; a.act = act; a.slope = slope;
+    a.n_out = n_out; a.n_in = n_in; a.K = K; a.cout = cout; a.act = act; a.slope = slope;
     if (cin == 16) PCC_TRY(launch_wave16<16>(a, s));
     else if (cin == 32) PCC_TRY(launch_wave16<32>(a, s));
     else PCC_TRY(launch_wave16<64>(a, s));

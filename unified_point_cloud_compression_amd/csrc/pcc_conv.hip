@@ -34,6 +34,8 @@ struct ConvArgs {
   const int* rows;
   float* out;             // [n_out, cout]
   long long n_out;
+  long long n_in;         // rows of feat (buffer-addressed gathers)
+  long long wp_elems;     // floats in wp
   int cin, cout, cout_pad;
   int cb_log2;            // log2(CB), CB = min(cin, 32)
   int ppo;                // pieces per offset = cin / CB
@@ -43,7 +45,13 @@ struct ConvArgs {
 
 __host__ __device__ inline int bn_for(int cout) { return cout >= 128 ? 128 : (cout > 32 ? 64 : 32); }
 
-template <int WM, int WN, int TM, int TN, int MODE>
+// BUF: feature rows and weight rows are fetched with buffer loads whose offset is out of range for an absent neighbour
+// (reads 0, no memory access): no per-row branch, no zero fill, 32-bit address arithmetic and a fixed number of loads
+// in flight, so the s_waitcnt distances the compiler derives are exact.  Needs feat and wp below 4 GB each.
+static constexpr unsigned BUF_OOB = 0xFFFF0000u;
+static constexpr long long BUF_MAX_BYTES = 0xFFFE0000ll;
+
+template <int WM, int WN, int TM, int TN, int MODE, bool BUF>
 __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -169,30 +177,58 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
     cbi = piece - ai * a.ppo;      // channel block within the offset
     pvalid = ai < nact;
   };
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  if constexpr (BUF) {
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.feat), (short)0,
+                                            (int)(unsigned)((size_t)a.n_in * a.cin * 4), 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), (short)0, (int)(unsigned)((size_t)a.wp_elems * 4),
+                                            0x00020000);
+  }
+  const unsigned cin_bytes = (unsigned)a.cin * 4u;
   auto load_rows = [&](int ai, bool pvalid, int (&rows)[AI]) {
     const int slot = pvalid ? act_list[ai] : 0;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int r = r0 + 32 * i;
-      int v = -1;
-      if (pvalid && r < npos) v = identity ? (pos0 + r) : seg_nbr[(long long)slot * seg_pos_count + r];
-      rows[i] = v;
+      if constexpr (BUF) {         // tail rows repeat the tile's last row (never stored); !pvalid is handled in issue()
+        const int rc = min(r, npos - 1);
+        rows[i] = identity ? (pos0 + rc) : seg_nbr[(long long)slot * seg_pos_count + rc];
+      } else {
+        int v = -1;
+        if (pvalid && r < npos) v = identity ? (pos0 + r) : seg_nbr[(long long)slot * seg_pos_count + r];
+        rows[i] = v;
+      }
     }
   };
   auto issue = [&](int ai, int cbi, bool pvalid, const int (&rows)[AI], float4 (&av)[AI], float4 (&bv)[BI]) {
+    if constexpr (BUF) {
+      const unsigned cb_off = (unsigned)(((cbi << a.cb_log2) + within) * 4);
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rows[i] >= 0)
-        av[i] = *reinterpret_cast<const float4*>(a.feat + (long long)rows[i] * a.cin + (cbi << a.cb_log2) + within);
-    }
-    const long long wbase = pvalid ? ((long long)(act_kid[ai] * a.ppo + cbi) * a.cout_pad) : 0;
+      for (int i = 0; i < AI; ++i) {
+        const unsigned off = (rows[i] >= 0 && pvalid) ? (unsigned)rows[i] * cin_bytes + cb_off : BUF_OOB;
+        av[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+      }
+      const unsigned wbase = pvalid ? (unsigned)((act_kid[ai] * a.ppo + cbi) * a.cout_pad + colblock + r0) : 0u;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pvalid) {
-        const int col = colblock + r0 + 32 * i;
-        bv[i] = *reinterpret_cast<const float4*>(a.wp + ((wbase + col) << a.cb_log2) + within);
+      for (int i = 0; i < BI; ++i) {
+        const unsigned off = pvalid ? (((wbase + 32u * i) << a.cb_log2) + within) * 4u : BUF_OOB;
+        bv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rows[i] >= 0)
+          av[i] = *reinterpret_cast<const float4*>(a.feat + (long long)rows[i] * a.cin + (cbi << a.cb_log2) + within);
+      }
+      const long long wbase = pvalid ? ((long long)(act_kid[ai] * a.ppo + cbi) * a.cout_pad) : 0;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pvalid) {
+          const int col = colblock + r0 + 32 * i;
+          bv[i] = *reinterpret_cast<const float4*>(a.wp + ((wbase + col) << a.cb_log2) + within);
+        }
       }
     }
   };
@@ -240,6 +276,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
         if (ai_n != ai_c) load_rows(ai_n, pv_n, rows_nxt);
       }
     }
+    if constexpr (BUF) __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs, not next to its use
     // LDS -> fragments -> MFMA
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -621,7 +658,6 @@ __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 static constexpr int DPP_SHL1 = 0x101, DPP_SHR1 = 0x111;
-__device__ float g_zero_row[64];                 // zero-initialised: the row every absent neighbour reads
 
 template <int CIN>
 __global__ void __launch_bounds__(512) k_conv_wave16z(Wave16Args a) {
@@ -642,15 +678,12 @@ __global__ void __launch_bounds__(512) k_conv_wave16z(Wave16Args a) {
   const unsigned xcd_lo = (blockIdx.x & 7) * per_xcd;
   const unsigned xcd_hi = min(total_tiles, xcd_lo + per_xcd);
   const float* wl_lane = wl_s + r16 * LD + 4 * q;
-  const char* fbase = reinterpret_cast<const char*>(a.feat) + 16 * q;
-  const char* zrow = reinterpret_cast<const char*>(g_zero_row) + 16 * q;
 
   // One (dx,dy) group of a 16-row tile: the dz=0 rows, and the dz=-+1 rows, each either the neighbouring lane's dz=0
   // row (mask k*) or loaded.  All rows come through buffer loads whose offset is out of range for an absent or
   // not-needed row: those lanes read 0 without touching memory, the number of loads in flight is fixed (exact
   // s_waitcnt distances; conditional loads made the compiler wait for the prefetch itself), and no branch is left.
   struct Grp { float4 c[G], m[G], p[G]; unsigned km, kp; };
-  typedef int v4i __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.feat), (short)0, (int)(unsigned)((size_t)a.n_in * CIN * 4), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
@@ -667,6 +700,7 @@ __global__ void __launch_bounds__(512) k_conv_wave16z(Wave16Args a) {
       const bool mp = ip >= 0 && ip == cp && r16 != 15;
       x.km = mm ? 0xFFFFFFFFu : 0u;
       x.kp = mp ? 0xFFFFFFFFu : 0u;
+      asm volatile("" : "+v"(x.km), "+v"(x.kp));       // opaque: keeps (shifted & k) | loaded as one v_and_or_b32
       const unsigned oc = ic >= 0 ? (unsigned)ic * (CIN * 4) + 16 * q : OOB;
       const unsigned om = (im >= 0 && !mm) ? (unsigned)im * (CIN * 4) + 16 * q : OOB;
       const unsigned op = (ip >= 0 && !mp) ? (unsigned)ip * (CIN * 4) + 16 * q : OOB;
@@ -869,6 +903,8 @@ extern "C" int pcc_prof_collect(double* h_conv_ms, int64_t* h_conv_launches) {
   return PCC_OK;
 }
 
+static bool g_mfma_buf = getenv("PCC_MFMA_BUF") ? atoi(getenv("PCC_MFMA_BUF")) != 0 : true;
+
 template <int MODE>
 static int launch_mfma(const ConvArgs& a, int tiles_bound_extra, hipStream_t s) {
   const int bn = bn_for(a.cout);
@@ -877,14 +913,22 @@ static int launch_mfma(const ConvArgs& a, int tiles_bound_extra, hipStream_t s) 
   auto grid = [&](int bm) { return dim3((unsigned)((tiles(bm) * gy + 7) / 8 * 8)); };   // 1-D, multiple of 8 (XCD ranges)
   // few rows: shrink the row tile until the grid covers the 256 CUs about twice
   const long long want = 512;
+  const bool buf = g_mfma_buf && a.n_in > 0 && a.n_in * a.cin * 4 <= BUF_MAX_BYTES && a.wp_elems > 0 &&
+                   a.wp_elems * 4 <= BUF_MAX_BYTES;
+#define PCC_LAUNCH_MFMA(WM, WN, TM, TN, BMV)                                                     \
+  do {                                                                                           \
+    if (buf) k_conv_mfma<WM, WN, TM, TN, MODE, true><<<grid(BMV), 256, 0, s>>>(a);               \
+    else k_conv_mfma<WM, WN, TM, TN, MODE, false><<<grid(BMV), 256, 0, s>>>(a);                  \
+  } while (0)
   if (bn == 128) {
-    if (tiles(128) * gy >= want) k_conv_mfma<2, 2, 2, 2, MODE><<<grid(128), 256, 0, s>>>(a);
-    else if (tiles(64) * gy >= want) k_conv_mfma<2, 2, 1, 2, MODE><<<grid(64), 256, 0, s>>>(a);
-    else k_conv_mfma<1, 4, 1, 1, MODE><<<grid(32), 256, 0, s>>>(a);
+    if (tiles(128) * gy >= want) PCC_LAUNCH_MFMA(2, 2, 2, 2, 128);
+    else if (tiles(64) * gy >= want) PCC_LAUNCH_MFMA(2, 2, 1, 2, 64);
+    else PCC_LAUNCH_MFMA(1, 4, 1, 1, 32);
   } else if (bn == 64) {
-    if (tiles(128) * gy >= want) k_conv_mfma<2, 2, 2, 1, MODE><<<grid(128), 256, 0, s>>>(a);
-    else k_conv_mfma<2, 2, 1, 1, MODE><<<grid(64), 256, 0, s>>>(a);
-  } else k_conv_mfma<4, 1, 1, 1, MODE><<<grid(128), 256, 0, s>>>(a);
+    if (tiles(128) * gy >= want) PCC_LAUNCH_MFMA(2, 2, 2, 1, 128);
+    else PCC_LAUNCH_MFMA(2, 2, 1, 1, 64);
+  } else PCC_LAUNCH_MFMA(4, 1, 1, 1, 128);
+#undef PCC_LAUNCH_MFMA
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
@@ -947,6 +991,7 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
     ConvArgs a;
     a.feat = feat_in; a.wp = packed_w; a.bias = bias; a.hdr = hdr; a.nbr = nbr; a.rows = rows; a.out = out;
     a.n_out = n_out; a.cin = cin; a.cout = cout; a.cout_pad = cout_pad_for(cout);
+    a.n_in = n_in; a.wp_elems = (long long)K * cin * a.cout_pad;
     a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = act; a.slope = slope;
     PCC_TRY(launch_mfma<MODE_CONV>(a, rows ? PCC_MAP_MAX_SEG : 0, s));
   } else if (kind == KIND_WAVE16) {
@@ -1108,6 +1153,7 @@ extern "C" int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, co
   ConvArgs a;
   a.feat = feat_in; a.wp = packed_w; a.bias = nullptr; a.hdr = nullptr; a.nbr = nullptr; a.rows = nullptr; a.out = T;
   a.n_out = n_in; a.cin = cin; a.cout = K * cout; a.cout_pad = cout_pad_for(K * cout);
+  a.n_in = n_in; a.wp_elems = (long long)cin * a.cout_pad;
   a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
   hipEvent_t e0, e1;
   if (g_prof_on) PCC_TRY(prof_event(&e0, s));
@@ -1188,6 +1234,7 @@ extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin
   ConvArgs a;
   a.feat = feat_in; a.wp = packed_w; a.bias = nullptr; a.hdr = nullptr; a.nbr = nullptr; a.rows = nullptr; a.out = T;
   a.n_out = n_in; a.cin = cin; a.cout = K * cout; a.cout_pad = cout_pad_for(K * cout);
+  a.n_in = n_in; a.wp_elems = (long long)cin * a.cout_pad;
   a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
   hipEvent_t e0, e1;
   if (g_prof_on) PCC_TRY(prof_event(&e0, s));
@@ -1265,6 +1312,7 @@ extern "C" int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* pa
   ConvArgs a;
   a.feat = x; a.wp = packed; a.bias = beta_eff; a.hdr = nullptr; a.nbr = nullptr; a.rows = nullptr; a.out = out;
   a.n_out = n; a.cin = c; a.cout = c; a.cout_pad = cout_pad_for(c);
+  a.n_in = n; a.wp_elems = (long long)c * a.cout_pad;
   a.cb_log2 = cb_log2_for(c); a.ppo = c >> a.cb_log2; a.act = 0; a.slope = 0.f;
   if (inverse) return launch_mfma<MODE_IGDN>(a, 0, s);
   return launch_mfma<MODE_GDN>(a, 0, s);

@@ -114,6 +114,56 @@ __global__ void __launch_bounds__(256) k_map_conv(PccGrid grid, const int64_t* _
   count_pairs(idx >= 0, d_pairs);
 }
 
+// conv through the grid index: thread per (kernel column (kx, ky), o) walks the KS offsets along z.  z is the fastest
+// cell axis, so the KS probes of a thread fall in one or two bitmap words: one key read, one (rarely two) word + rank
+// reads for KS neighbours, instead of a key, a word and a rank per neighbour.
+template <int KS>
+__global__ void __launch_bounds__(256) k_map_conv_z(PccGrid g, const int64_t* __restrict__ out_keys, int64_t n_out,
+                                                    int step, const int* __restrict__ rows, int* __restrict__ nbr,
+                                                    int* __restrict__ d_pairs) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int kxy = blockIdx.y;                                      // kx + KS * ky
+  constexpr int H = (KS & 1) ? (KS - 1) / 2 : 0;
+  int hits = 0;
+  if (o < n_out) {
+    const int64_t key = out_keys[rows ? rows[o] : o];
+    const int b = (int)(key >> 48);
+    const int x = (int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - g.lo[0] + (kxy % KS - H) * step;
+    const int y = (int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - g.lo[1] + (kxy / KS - H) * step;
+    const int z0 = (int)(key & 0xFFFF) - (int)PCC_BIAS - g.lo[2];
+    const int tm = (1 << g.ts_log2) - 1;
+    const int cx = x >> g.ts_log2, cy = y >> g.ts_log2;
+    const bool col_ok = (x | y) >= 0 && b < g.nbatch && !((x | y) & tm) && cx < g.dims[0] && cy < g.dims[1];
+    const long long cell0 = (((long long)b * g.dims[0] + cx) * g.dims[1] + cy) * g.dims[2];
+    long long wi = -1;
+    unsigned long long w = 0;
+    int rk = 0;
+#pragma unroll
+    for (int iz = 0; iz < KS; ++iz) {
+      const int z = z0 + (iz - H) * step;
+      const int cz = z >> g.ts_log2;
+      int idx = -1;
+      if (col_ok && z >= 0 && !(z & tm) && cz < g.dims[2]) {
+        const long long cell = cell0 + cz;
+        if ((cell >> 6) != wi) { wi = cell >> 6; w = g.bits[wi]; rk = g.rank[wi]; }
+        const int bit = (int)(cell & 63);
+        if ((w >> bit) & 1ull) idx = rk + __popcll(w & ((1ull << bit) - 1ull));
+      }
+      nbr[(int64_t)(kxy + KS * KS * iz) * n_out + o] = idx;
+      hits += idx >= 0;
+    }
+  }
+  if (d_pairs) {                                                   // kernel-uniform
+    __shared__ int wc[4];
+    int c = hits;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) d_pairs[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+  }
+}
+
 // Morton (Z-curve) code of the lattice cell of every output row: bits of z, y, x interleaved (z lowest).  Tiles of
 // consecutive positions in this order are compact 3-D blobs, so the 27 (or 125) neighbour gathers of a tile hit a
 // few hundred distinct rows instead of a few thousand, and consecutive tiles share them (L1 / L2 locality).
@@ -281,8 +331,14 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
                             ws_bytes - (size_t)(p - (char*)ws), s));
       morton_rows = rows;
     }
-    k_map_conv<<<gdim, 256, 0, s>>>(grid, in_keys, (int)n_in, out_keys, n_out, kernel_size, step, morton_rows, nbr,
-                                    block_counts);
+    if (grid.bits && (kernel_size == 3 || kernel_size == 5)) {
+      gdim.y = (unsigned)(kernel_size * kernel_size);
+      if (kernel_size == 3) k_map_conv_z<3><<<gdim, 256, 0, s>>>(grid, out_keys, n_out, step, morton_rows, nbr, block_counts);
+      else k_map_conv_z<5><<<gdim, 256, 0, s>>>(grid, out_keys, n_out, step, morton_rows, nbr, block_counts);
+    } else {
+      k_map_conv<<<gdim, 256, 0, s>>>(grid, in_keys, (int)n_in, out_keys, n_out, kernel_size, step, morton_rows, nbr,
+                                      block_counts);
+    }
     PCC_LAUNCH_CHECK();
     if (d_pairs) {
       k_sum_counts<<<1, 1024, 0, s>>>(block_counts, (int64_t)gdim.x * gdim.y, d_pairs);

@@ -309,6 +309,15 @@ int pcc_octree_decode_host(const uint8_t* h_data, int64_t nbytes, int32_t* h_cel
                            int32_t* h_depth);
 
 /* ------------------------------------------------------------------------------------------
+ * 8f-4  nearest-neighbour association of the distortion report (replaces the two Open3D KD-trees and the per-point
+ *       Python loop of PointCloudMetric.__init__, metrics/metric.py:36-43).  Exact, integer coordinates.
+ *       a_xyz [n_a,3] int32 queries (any order; canonical order is fastest); b_xyz [n_b,3] int32 SORTED BY x ascending
+ *       (canonical key order is).  d2[i] = min_j |a_i - b_j|^2, nn[i] = the smallest such j.
+ * ---------------------------------------------------------------------------------------- */
+int pcc_nn_sorted_x(const int32_t* a_xyz, int64_t n_a, const int32_t* b_xyz, int64_t n_b, int64_t* d2, int32_t* nn,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * measurement support: per-launch HIP-event timing of the conv kernel (bench.py roofline)
  * ---------------------------------------------------------------------------------------- */
 int pcc_prof_enable(int32_t on);

@@ -60,8 +60,22 @@ def test_container_roundtrip(tmp_path):
 def test_d1_psnr_formula():
     a = np.array([[0, 0, 0], [10, 0, 0]], float)
     b = np.array([[0, 0, 1], [10, 0, 0], [50, 50, 50]], float)
-    ab, ba, sym = metrics.d1_psnr(a, b, resolution=1023)
+    from oracle import metrics as ometrics
+    ab, ba, sym = ometrics.d1_psnr(a, b, resolution=1023)
     assert abs(ab - 10 * np.log10(1023 ** 2 / ((1 / 3 + 0) / 2))) < 1e-9
     assert sym == min(ab, ba) and ba < ab
-    assert metrics.d1_psnr(a, a)[2] == float("inf")
+    assert ometrics.d1_psnr(a, a)[2] == float("inf")
+    # colour report: identical clouds -> infinite PSNRs; one wrong colour -> the closed-form y MSE
+    rgb = np.array([[0.2, 0.4, 0.6], [1.0, 0.0, 0.5]])
+    pa = np.concatenate([a, rgb], 1)
+    r = ometrics.pointcloud_metrics(pa, pa)
+    assert r["sym_y_psnr"] == float("inf") and r["sym_psnr_hausdorff"] == float("inf")
+    pb = pa.copy()
+    pb[0, 3:] = [0.2, 0.4, 0.2]
+    r = ometrics.pointcloud_metrics(pa, pb)
+    y = lambda c: (0.2126 * np.uint8(c[0] * 255) + 0.7152 * np.uint8(c[1] * 255) + 0.0722 * np.uint8(c[2] * 255)) / 255
+    assert abs(r["AB_y_mse"] - (y(pa[0, 3:]) - y(pb[0, 3:])) ** 2 / 2) < 1e-9
+    # equidistant neighbours: the smallest row in (x,y,z) order is taken
+    d2, nn = ometrics.nearest(np.array([[5, 5, 5]]), np.array([[4, 5, 5], [5, 4, 5], [6, 5, 5], [9, 9, 9]]))
+    assert d2[0] == 1 and nn[0] == 0
     assert metrics.count_bits([[b"ab"], [b"c", [b"de"]]]) == 40

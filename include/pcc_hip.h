@@ -153,6 +153,24 @@ int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* p
                  const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* hdr,
                  const int32_t* nbr, const int32_t* rows, int64_t n_out, float* out, int32_t act,
                  float slope, void* ws, size_t ws_bytes, void* stream);
+/* Pair-list form of the same convolution for maps with mostly empty (offset, row) slots (5x5x5 kernels on surfaces):
+ * the pairs of each offset are compacted and padded to 128-pair tiles, T[p] = feat[in(p)] @ W[k(p)] runs as a gathered
+ * GEMM in which every MFMA row is a real pair, and out[o] = act(bias + sum_k T[pos(k,o)]) is summed in ascending k.
+ * Conv maps only (one segment, nbr[k*n_out + o], no row list).  Same results as pcc_conv_fwd up to fp32 summation order.
+ *   pcc_pair_plan_rank : pos[K*n_out], pstart[K+1], info[3] = {padded pairs, tiles, pairs}      (device arrays)
+ *   pcc_pair_plan_fill : pair_in[padded pairs] (-1 = padding), tile_k[tiles]   -- after the host has read info
+ *   pcc_conv_fwd_pairs : T is scratch of padded_pairs*cout floats */
+int pcc_conv_pairs_supported(int32_t K, int32_t cin, int32_t cout);
+size_t pcc_pair_plan_ws_bytes(int64_t n_out, int32_t K);
+int pcc_pair_plan_rank(const int32_t* nbr, int64_t n_out, int32_t K, int32_t* pos, int32_t* pstart, int64_t* info,
+                       void* ws, size_t ws_bytes, void* stream);
+int pcc_pair_plan_fill(const int32_t* nbr, const int32_t* pos, const int32_t* pstart, int64_t n_out, int32_t K,
+                       int64_t padded_pairs, int32_t* pair_in, int32_t* tile_k, void* stream);
+int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias,
+                       int32_t K, int32_t cout, const int32_t* pair_in, const int32_t* tile_k, const int64_t* d_info,
+                       int64_t padded_pairs, const int32_t* pos, int64_t n_out, float* T, float* out, int32_t act,
+                       float slope, void* stream);
+
 
 /* a3  generative transposed convolution, input stationary (ME.MinkowskiGenerativeConvolutionTranspose forward:
  * model/transforms.py:129,133,137; model/entropy_models.py:186,188).  Every (input row, offset) is one pair, so

@@ -36,6 +36,9 @@ struct ConvArgs {
   long long n_out;
   long long n_in;         // rows of feat (buffer-addressed gathers)
   long long wp_elems;     // floats in wp
+  const int* pair_in = nullptr;   // pair mode (pcc_conv_fwd_pairs): input row of every (padded) pair, -1 = padding
+  const int* tile_k = nullptr;    // pair mode: kernel offset of each 128-pair tile
+  const long long* n_tiles = nullptr;   // pair mode: device count of tiles (the grid is an upper bound)
   int cin, cout, cout_pad;
   int cb_log2;            // log2(CB), CB = min(cin, 32)
   int ppo;                // pieces per offset = cin / CB
@@ -80,8 +83,13 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
   int pos0, npos, k_count, koff_begin;
   long long seg_pos_count;
   const int* seg_nbr = nullptr;
-  bool identity = (a.hdr == nullptr);
-  if (identity) {
+  const bool pair_mode = (a.pair_in != nullptr);
+  bool identity = (a.hdr == nullptr) && !pair_mode;
+  if (pair_mode) {          // one kernel offset per tile, rows = compacted pairs of that offset
+    if (tile_id >= *a.n_tiles) return;
+    pos0 = tile_id * BM; npos = BM; k_count = 1; koff_begin = 0; seg_pos_count = 0;
+    seg_nbr = a.pair_in + pos0;
+  } else if (identity) {
     const long long p0 = (long long)tile_id * BM;
     if (p0 >= a.n_out) return;
     pos0 = (int)p0;
@@ -113,7 +121,9 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
   }
 
   // ---- active offsets of this tile ---------------------------------------------------------
-  if (identity) {
+  if (pair_mode) {
+    if (tid == 0) { act_list[0] = 0; act_kid[0] = (unsigned char)a.tile_k[tile_id]; s_nact = 1; }
+  } else if (identity) {
     if (tid == 0) { act_list[0] = 0; act_kid[0] = 0; s_nact = 1; }
   } else {
     for (int j = w; j < k_count; j += 4) {
@@ -1038,6 +1048,190 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
     PCC_TRY(prof_event(&e1, s));
     ++g_launches;
   }
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Pair-list form of a sparse convolution, for maps where most (offset, output row) slots are empty (5x5x5 kernels on
+// surfaces: 36 of 125).  The output-stationary kernel multiplies whole 128-row tiles per active offset, so its MFMA
+// work scales with K * rows, not with the pairs.  Here the pairs of each offset are compacted (padded to whole
+// 128-pair tiles), T[p] = feat[in(p)] @ W[k(p)] runs as a gathered GEMM with one offset per tile -- every MFMA row is
+// a real pair -- and out[o] = bias + sum_k T[pos(k, o)] is taken in ascending k: deterministic, no atomics.
+// ------------------------------------------------------------------------------------------
+static constexpr int PAIR_BM = 128;
+
+__global__ void k_pair_flags(const int* __restrict__ nbr, long long n, int* __restrict__ f) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) f[e] = nbr[e] >= 0 ? 1 : 0;
+}
+
+// one block: padded start of every offset's pair range; info = {padded pairs, tiles, pairs}
+__global__ void k_pair_starts(const int* __restrict__ g, const int* __restrict__ nbr, long long n_out, int K,
+                              int* __restrict__ pstart /*[K+1]*/, long long* __restrict__ info) {
+  if (threadIdx.x != 0) return;
+  const long long n = n_out * K;
+  const long long total = (long long)g[n - 1] + (nbr[n - 1] >= 0 ? 1 : 0);
+  long long run = 0;
+  for (int k = 0; k < K; ++k) {
+    const long long b = g[(long long)k * n_out];
+    const long long e = (k + 1 < K) ? g[(long long)(k + 1) * n_out] : total;
+    pstart[k] = (int)run;
+    run += (e - b + PAIR_BM - 1) / PAIR_BM * PAIR_BM;
+  }
+  pstart[K] = (int)run;
+  info[0] = run; info[1] = run / PAIR_BM; info[2] = total;
+}
+
+__global__ void k_pair_pos(const int* __restrict__ nbr, const int* __restrict__ g, const int* __restrict__ pstart,
+                           long long n_out, int K, int* __restrict__ pos) {
+  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (o >= n_out) return;
+  const long long e = (long long)k * n_out + o;
+  pos[e] = nbr[e] >= 0 ? pstart[k] + (g[e] - g[(long long)k * n_out]) : -1;
+}
+
+__global__ void k_pair_fill(const int* __restrict__ nbr, const int* __restrict__ pos, long long n,
+                            int* __restrict__ pair_in) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n && pos[e] >= 0) pair_in[pos[e]] = nbr[e];
+}
+
+__global__ void k_pair_tile_k(const int* __restrict__ pstart, int K, long long tiles, int* __restrict__ tile_k) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= tiles) return;
+  const long long p = t * PAIR_BM;
+  int lo = 0, hi = K;                 // last k with pstart[k] <= p
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pstart[mid] <= p) lo = mid; else hi = mid; }
+  tile_k[t] = lo;
+}
+
+extern "C" int pcc_conv_pairs_supported(int32_t K, int32_t cin, int32_t cout) {
+  return (K >= 1 && K <= MAXK && conv_kind(K, cin, cout) == KIND_MFMA && cout % 4 == 0) ? 1 : 0;
+}
+
+extern "C" size_t pcc_pair_plan_ws_bytes(int64_t n_out, int32_t K) {
+  const int64_t n = n_out * K;
+  return 2 * pcc_align_up((size_t)n * 4) + pcc_scan_ws_bytes(n) + 1024;
+}
+
+// phase 1: pos[k][o] (row of pair (k,o) in the padded pair list, -1 = no pair), pstart[K+1], info[3]
+extern "C" int pcc_pair_plan_rank(const int32_t* nbr, int64_t n_out, int32_t K, int32_t* pos, int32_t* pstart,
+                                  int64_t* info, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(nbr && pos && pstart && info && ws && n_out > 0 && K >= 1 && K <= MAXK, "pcc_pair_plan_rank: bad arguments");
+  const int64_t n = n_out * K;
+  PCC_REQUIRE(n + (int64_t)K * PAIR_BM < (1ll << 31), "pcc_pair_plan_rank: too many map slots");
+  if (ws_bytes < pcc_pair_plan_ws_bytes(n_out, K)) { pcc_set_error("pcc_pair_plan_rank: workspace too small"); return PCC_EWS; }
+  char* p = (char*)ws;
+  int* f = (int*)p;  p += pcc_align_up((size_t)n * 4);
+  int* g = (int*)p;  p += pcc_align_up((size_t)n * 4);
+  k_pair_flags<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(nbr, n, f);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(f, g, n, p, ws_bytes - (size_t)(p - (char*)ws), s));
+  k_pair_starts<<<1, 64, 0, s>>>(g, nbr, n_out, K, pstart, (long long*)info);
+  PCC_LAUNCH_CHECK();
+  k_pair_pos<<<dim3((unsigned)pcc_cdiv(n_out, 256), (unsigned)K), 256, 0, s>>>(nbr, g, pstart, n_out, K, pos);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// phase 2 (after the host has read info and sized the arrays): pair_in[padded pairs], tile_k[tiles]
+extern "C" int pcc_pair_plan_fill(const int32_t* nbr, const int32_t* pos, const int32_t* pstart, int64_t n_out, int32_t K,
+                                  int64_t padded_pairs, int32_t* pair_in, int32_t* tile_k, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(nbr && pos && pstart && pair_in && tile_k && padded_pairs % PAIR_BM == 0, "pcc_pair_plan_fill: bad arguments");
+  if (padded_pairs == 0) return PCC_OK;
+  PCC_CHECK_HIP(hipMemsetAsync(pair_in, 0xFF, (size_t)padded_pairs * 4, s));
+  const int64_t n = n_out * K;
+  k_pair_fill<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(nbr, pos, n, pair_in);
+  PCC_LAUNCH_CHECK();
+  const int64_t tiles = padded_pairs / PAIR_BM;
+  k_pair_tile_k<<<(unsigned)pcc_cdiv(tiles, 256), 256, 0, s>>>(pstart, K, tiles, tile_k);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+struct PairReduceArgs {
+  const float* T; const float* bias; const int* pos; float* out; long long n_out; int K, cout, act; float slope; int lpr_log2;
+};
+
+// LPR lanes per output row, 4 channels per lane and pass; pair rows of JB offsets loaded independently
+__global__ void __launch_bounds__(256) k_pair_reduce(PairReduceArgs a) {
+  constexpr int JB = 5;
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << a.lpr_log2;
+  const int rpw = 64 >> a.lpr_log2;
+  const long long o = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> a.lpr_log2);
+  const int cl = lane & (lpr - 1);
+  if (o >= a.n_out) return;
+  const int cvec = a.cout / 4;
+  for (int cv = cl; cv < cvec; cv += lpr) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < a.K; k0 += JB) {
+      int pr[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) pr[u] = (k0 + u < a.K) ? a.pos[(long long)(k0 + u) * a.n_out + o] : -1;
+      float4 x[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) {
+        x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pr[u] >= 0) x[u] = reinterpret_cast<const float4*>(a.T + (long long)pr[u] * a.cout)[cv];
+      }
+#pragma unroll
+      for (int u = 0; u < JB; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+    }
+    if (a.bias) {
+      const float4 b = reinterpret_cast<const float4*>(a.bias)[cv];
+      acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    acc.x = act1(acc.x, a.act, a.slope); acc.y = act1(acc.y, a.act, a.slope);
+    acc.z = act1(acc.z, a.act, a.slope); acc.w = act1(acc.w, a.act, a.slope);
+    reinterpret_cast<float4*>(a.out + o * a.cout)[cv] = acc;
+  }
+}
+
+extern "C" int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                                  const float* bias, int32_t K, int32_t cout, const int32_t* pair_in,
+                                  const int32_t* tile_k, const int64_t* d_info, int64_t padded_pairs,
+                                  const int32_t* pos, int64_t n_out, float* T, float* out, int32_t act, float slope,
+                                  void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out <= 0) return PCC_OK;
+  PCC_REQUIRE(feat_in && packed_w && pair_in && tile_k && d_info && pos && T && out, "pcc_conv_fwd_pairs: NULL array");
+  PCC_REQUIRE(conv_kind(K, cin, cout) == KIND_MFMA && cout % 4 == 0, "pcc_conv_fwd_pairs: shape cin=%d cout=%d not on the MFMA path", cin, cout);
+  PCC_REQUIRE(padded_pairs % PAIR_BM == 0 && padded_pairs < (1ll << 31), "pcc_conv_fwd_pairs: bad pair count");
+  PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd_pairs: bad activation");
+  if (padded_pairs > 0) {
+    ConvArgs a;
+    a.feat = feat_in; a.wp = packed_w; a.bias = nullptr; a.hdr = nullptr; a.nbr = nullptr; a.rows = nullptr; a.out = T;
+    a.n_out = padded_pairs; a.cin = cin; a.cout = cout; a.cout_pad = cout_pad_for(cout);
+    a.n_in = n_in; a.wp_elems = (long long)K * cin * a.cout_pad;
+    a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
+    a.pair_in = pair_in; a.tile_k = tile_k; a.n_tiles = (const long long*)d_info + 1;
+    hipEvent_t e0, e1;
+    if (g_prof_on) PCC_TRY(prof_event(&e0, s));
+    const int bn = bn_for(cout);
+    const long long gy = a.cout_pad / bn;
+    const dim3 grid((unsigned)((padded_pairs / PAIR_BM * gy + 7) / 8 * 8));
+    const bool buf = g_mfma_buf && n_in * cin * 4 <= BUF_MAX_BYTES && a.wp_elems * 4 <= BUF_MAX_BYTES;
+    if (bn == 128) { if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    else if (bn == 64) { if (buf) k_conv_mfma<2, 2, 2, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    else { if (buf) k_conv_mfma<4, 1, 1, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<4, 1, 1, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    PCC_LAUNCH_CHECK();
+    if (g_prof_on) {
+      PCC_TRY(prof_event(&e1, s));
+      ++g_launches;
+    }
+  }
+  PairReduceArgs r;
+  r.T = T; r.bias = bias; r.pos = pos; r.out = out; r.n_out = n_out; r.K = K; r.cout = cout; r.act = act; r.slope = slope;
+  int l = 0;
+  while ((1 << l) < cout / 4 && l < 6) ++l;
+  r.lpr_log2 = l;
+  const int64_t waves = pcc_cdiv(n_out, 64 >> l);
+  k_pair_reduce<<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(r);
+  PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
 

@@ -84,6 +84,12 @@ SIGNATURES = {
     "pcc_octree_max_bytes": (_i64, [_i64, _i32]),
     "pcc_octree_encode_host": (C.c_int, [_p, _i64, _i32, _p, _i64, C.POINTER(_i64)]),
     "pcc_octree_decode_host": (C.c_int, [_p, _i64, _p, _i64, C.POINTER(_i64), C.POINTER(_i32)]),
+    "pcc_conv_pairs_supported": (C.c_int, [_i32, _i32, _i32]),
+    "pcc_pair_plan_ws_bytes": (_sz, [_i64, _i32]),
+    "pcc_pair_plan_rank": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _sz, _p]),
+    "pcc_pair_plan_fill": (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p]),
+    "pcc_conv_fwd_pairs": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32,
+                                     C.c_float, _p]),
     "pcc_nn_sorted_x": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p]),
     "pcc_prof_enable": (C.c_int, [_i32]),
     "pcc_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64)]),

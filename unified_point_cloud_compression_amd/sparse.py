@@ -51,6 +51,31 @@ class KernelMap:
             self._pairs = int(self.d_pairs.item()) if self.d_pairs is not None else -1
         return self._pairs
 
+    def pair_plan(self):
+        """Compacted pair lists of a conv map (pcc_conv_fwd_pairs), built on first use; None when the map is too dense
+        for the pair form to pay (or is not a plain conv map)."""
+        if not hasattr(self, "_plan"):
+            self._plan = None
+            if self.rows is None and not self.transposed and self.n_out > 0 and self.K * self.n_out + self.K * 128 < (1 << 31):
+                dev = self.hdr.device
+                lib = L.load()
+                pos = torch.empty(self.K * self.n_out, dtype=torch.int32, device=dev)
+                pstart = torch.empty(self.K + 1, dtype=torch.int32, device=dev)
+                info = torch.zeros(3, dtype=torch.int64, device=dev)
+                ws = L.workspace(lib.pcc_pair_plan_ws_bytes(self.n_out, self.K), dev)
+                L.call("pcc_pair_plan_rank", L.ptr(self.nbr), self.n_out, self.K, L.ptr(pos), L.ptr(pstart), L.ptr(info),
+                       L.ptr(ws), ws.numel(), L.stream())
+                padded, _, pairs = (int(v) for v in info.tolist())
+                if self._pairs is None:
+                    self._pairs = pairs
+                if pairs <= PAIR_MAX_DENSITY * self.K * self.n_out:
+                    pair_in = torch.empty(max(padded, 1), dtype=torch.int32, device=dev)
+                    tile_k = torch.empty(max(padded // 128, 1), dtype=torch.int32, device=dev)
+                    L.call("pcc_pair_plan_fill", L.ptr(self.nbr), L.ptr(pos), L.ptr(pstart), self.n_out, self.K, padded,
+                           L.ptr(pair_in), L.ptr(tile_k), L.stream())
+                    self._plan = (pos, pair_in, tile_k, info, padded)
+        return self._plan
+
     def dense(self):
         """[K, n_out] int32 table with -1 holes (tests)."""
         out = torch.empty((self.K, self.n_out), dtype=torch.int32, device=self.hdr.device)
@@ -60,6 +85,9 @@ class KernelMap:
         return out
 
 
+PAIR_MIN_K = 64          # pair-list convolution: kernels with at least this many offsets ...
+PAIR_MAX_DENSITY = 0.5   # ... whose map holds at most this fraction of the K * n_out slots ...
+PAIR_MIN_CIN = 64        # ... and enough input channels to pay for writing and re-reading T (cin/4 FLOP per byte)
 COUNT_PAIRS = False   # bench.py switches this on for its FLOP accounting pass
 MORTON_MIN_ROWS = 1 << 62    # Z-curve visiting order of conv maps: measured no gain on MI355X (round 1), off by default
 USE_CSR = True        # generative expansion also emits the transposed map as CSR pair lists (False: class map + lookup)
@@ -310,6 +338,15 @@ def conv_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NON
     if n_out == 0:
         return out
     b = bias.detach().reshape(-1).contiguous() if bias is not None else None
+    if kmap is not None and K >= PAIR_MIN_K and cin >= PAIR_MIN_CIN and L.load().pcc_conv_pairs_supported(K, cin, cout):
+        plan = kmap.pair_plan()
+        if plan is not None:           # sparse map: gathered GEMM over the compacted pairs, then ordered reduce
+            pos, pair_in, tile_k, info, padded = plan
+            T = L.workspace(max(padded, 1) * cout * 4, feats.device)
+            L.call("pcc_conv_fwd_pairs", L.ptr(feats), feats.shape[0], cin, L.ptr(packed_w), L.ptr(b), K, cout,
+                   L.ptr(pair_in), L.ptr(tile_k), L.ptr(info), padded, L.ptr(pos), n_out, L.ptr(T), L.ptr(out), act,
+                   float(slope), L.stream())
+            return out
     ws = L.workspace(L.load().pcc_conv_ws_bytes(feats.shape[0], K, cin, cout), feats.device)
     L.call("pcc_conv_fwd", L.ptr(feats), feats.shape[0], cin, L.ptr(packed_w), L.ptr(b), K, cout,
            L.ptr(kmap.hdr) if kmap is not None else None, L.ptr(kmap.nbr) if kmap is not None else None,

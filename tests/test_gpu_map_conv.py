@@ -106,6 +106,48 @@ def test_conv_strided_k5(cin, cout, ks, stride):
     assert_close(n(got), want, what="strided conv")
 
 
+@pytest.mark.parametrize("cin,cout,stride,bias,act", [(128, 128, 2, True, 1), (64, 64, 1, False, 0), (192, 256, 1, True, 2),
+                                                       (128, 32, 2, False, 0)])
+def test_conv_pair_list_form(cin, cout, stride, bias, act):
+    """5x5x5 convolution on a sparse set through the pair-list form (compacted per-offset pair tiles + ordered reduce)
+    and through the output-stationary kernel: both against the oracle, and the plan's bookkeeping against the map."""
+    from unified_point_cloud_compression_amd import sparse as S
+    keys = cloud_keys(21, 30, 0.03, 1, batch=2)
+    cs = _cs(keys, 1, 2)
+    out = cs if stride == 1 else cs.stride(stride)
+    rng = np.random.default_rng(15)
+    f = rng.standard_normal((len(keys), cin)).astype(np.float32)
+    W = (rng.standard_normal((125, cin, cout)) / np.sqrt(cin * 10)).astype(np.float32)
+    b = rng.standard_normal((1, cout)).astype(np.float32) if bias else None
+    m = cs.kernel_map(out, 5)
+    plan = m.pair_plan()
+    assert plan is not None, "map expected to be sparse enough for the pair form"
+    pos, pair_in, tile_k, info, padded = plan
+    dense = n(m.dense())
+    padded_i, tiles, pairs = (int(v) for v in n(info))
+    assert pairs == int((dense >= 0).sum()) and padded_i == padded == tiles * 128
+    pos_h, pin_h, tk_h = n(pos).reshape(125, out.n), n(pair_in), n(tile_k)
+    assert np.array_equal(pos_h >= 0, dense >= 0)
+    assert np.array_equal(pin_h[pos_h[dense >= 0]], dense[dense >= 0])          # pair row -> input row
+    assert (pin_h >= 0).sum() == pairs                                            # everything else is padding
+    kk = np.repeat(np.arange(125), out.n).reshape(125, out.n)
+    assert np.array_equal(tk_h[pos_h[dense >= 0] // 128], kk[dense >= 0])        # one offset per 128-pair tile
+    pk = S.PackedConv().get(torch.nn.Parameter(t(W)))
+    bt = t(b) if bias else None
+    got_pairs = S.conv_forward(t(f), pk, bt, 125, cin, cout, m, out.n, act=act, slope=0.2)
+    old = S.PAIR_MIN_K
+    S.PAIR_MIN_K = 1 << 30
+    try:
+        got_os = S.conv_forward(t(f), pk, bt, 125, cin, cout, m, out.n, act=act, slope=0.2)
+    finally:
+        S.PAIR_MIN_K = old
+    out_keys = keys if stride == 1 else co.stride_keys(keys, stride)
+    want = ops.conv(f, W, b, co.kernel_map(keys, out_keys, 5, 1))
+    want = {0: lambda v: v, 1: ops.relu, 2: lambda v: ops.leaky_relu(v, 0.2)}[act](want)
+    assert_close(n(got_pairs), want, what="pair-list conv")
+    assert_close(n(got_os), want, what="output-stationary conv")
+
+
 @pytest.mark.parametrize("cin,cout,ks", [(128, 128, 5), (128, 32, 5), (192, 192, 2), (16, 4, 5), (8, 16, 2)])
 def test_generative_transpose_features(cin, cout, ks):
     from unified_point_cloud_compression_amd import sparse as S

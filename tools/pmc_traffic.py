@@ -12,6 +12,7 @@ import csv
 import glob
 import json
 import os
+import re
 import subprocess
 import sys
 
@@ -37,7 +38,7 @@ def parse(out, dst):
         tot, launches = 0.0, 0
         for r in csv.DictReader(open(files[0])):
             name = r["Kernel_Name"]
-            conv = "k_conv_wave16" in name or ("k_conv_mfma<" in name and ", 0>(" in name)   # MODE_CONV instances only
+            conv = "k_conv_wave16" in name or re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>", name)   # MODE_CONV only
             if r["Counter_Name"] == ctr and conv:
                 tot += float(r["Counter_Value"])
                 launches += 1

@@ -224,6 +224,10 @@ __global__ void __launch_bounds__(RS_T) k_rs_scatter(const KT* __restrict__ keys
   constexpr int NWR = NW * RS_I;                // 32 wave-rounds, in element order
   __shared__ unsigned short wcount[NWR][256];   // 16 KB
   __shared__ int gbase[256];
+  __shared__ int dstart[256];
+  __shared__ int wtot[NW];
+  __shared__ KT skey[RS_B];
+  __shared__ int spay[PAYLOAD ? RS_B : 1];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int i = tid; i < NWR * 256 / 2; i += RS_T) ((unsigned*)wcount)[i] = 0u;
   gbase[tid] = offs[(int64_t)tid * nblocks + blockIdx.x];
@@ -250,8 +254,8 @@ __global__ void __launch_bounds__(RS_T) k_rs_scatter(const KT* __restrict__ keys
     if (valid && rank[r] == 0) wcount[r * NW + w][d] = (unsigned short)__popcll(peers);
   }
   __syncthreads();
+  int run = 0;
   {  // per digit: exclusive prefix over the 32 wave-rounds
-    int run = 0;
 #pragma unroll 4
     for (int i = 0; i < NWR; ++i) {
       const int c = wcount[i][tid];
@@ -259,15 +263,44 @@ __global__ void __launch_bounds__(RS_T) k_rs_scatter(const KT* __restrict__ keys
       run += c;
     }
   }
+  // first position of every digit inside the block (exclusive scan of the 256 digit totals)
+  {
+    int v = run;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const int t = __shfl_up(v, dd, 64);
+      if (lane >= dd) v += t;
+    }
+    if (lane == 63) wtot[w] = v;
+    __syncthreads();
+    int add = 0;
+    for (int i = 0; i < w; ++i) add += wtot[i];
+    dstart[tid] = v - run + add;
+  }
   __syncthreads();
+  // stage the block's elements in LDS in digit order, then write them out: neighbouring threads hold neighbouring
+  // elements of one digit run, so the global stores are contiguous runs instead of 2048 scattered words
 #pragma unroll
   for (int r = 0; r < RS_I; ++r) {
     const int64_t e = base + r * RS_T + tid;
     if (e < n) {
       const int d = (int)((key[r] >> shift) & 0xFF);
-      const int64_t pos = (int64_t)gbase[d] + wcount[r * NW + w][d] + rank[r];
-      keys_out[pos] = key[r];
-      if (PAYLOAD) pay_out[pos] = pay_in ? pay_in[e] : (int)e;
+      const int lp = dstart[d] + wcount[r * NW + w][d] + rank[r];
+      skey[lp] = key[r];
+      if (PAYLOAD) spay[lp] = pay_in ? pay_in[e] : (int)e;
+    }
+  }
+  __syncthreads();
+  const int nv = (int)min((int64_t)RS_B, n - base);
+#pragma unroll
+  for (int r = 0; r < RS_I; ++r) {
+    const int j = r * RS_T + tid;
+    if (j < nv) {
+      const KT k = skey[j];
+      const int d = (int)((k >> shift) & 0xFF);
+      const int64_t pos = (int64_t)gbase[d] + (j - dstart[d]);
+      keys_out[pos] = k;
+      if (PAYLOAD) pay_out[pos] = spay[j];
     }
   }
 }

@@ -202,6 +202,46 @@ def test_gdn(c, inverse):
     assert_close(n(got), ops.gdn(x, beta, gamma, inverse), what="gdn")
 
 
+def test_weight_offset_order_hook():
+    """`sparse.WEIGHT_OFFSET_ORDER = "z_fastest"` re-indexes checkpoint weights while packing (the SURVEY A.3 hedge):
+    a module fed the z-fastest enumeration of the same kernel gives the same output, in inference and under autograd."""
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    from unified_point_cloud_compression_amd import sparse as S
+    keys = cloud_keys(3, 14, 0.2, 1)
+    C = co.unpack_keys(keys)
+    rng = np.random.default_rng(2)
+    f = rng.standard_normal((len(keys), 32)).astype(np.float32)
+    conv = ME.MinkowskiConvolution(32, 64, kernel_size=3, stride=1, bias=False, dimension=3).to(dev())
+    x = ME.SparseTensor(features=t(f), coordinates=t(C.astype(np.int32)), device=dev())
+    with torch.no_grad():
+        ref = conv(x).F.clone()
+    idx = np.arange(27)
+    ix, iy, iz = idx % 3, (idx // 3) % 3, idx // 9
+    zf = iz + 3 * iy + 9 * ix                      # position of native offset idx in a z-fastest enumeration
+    w_native = conv.kernel.detach().clone()
+    w_zf = torch.empty_like(w_native)
+    w_zf[t(zf).long()] = w_native
+    try:
+        S.WEIGHT_OFFSET_ORDER = "z_fastest"
+        with torch.no_grad():
+            conv.kernel.copy_(w_zf)
+            got = conv(x).F.clone()
+        assert torch.equal(got, ref)
+        xg = ME.SparseTensor(features=t(f).requires_grad_(True), coordinates=t(C.astype(np.int32)), device=dev())
+        out = conv(xg).F
+        assert torch.allclose(out, ref, atol=1e-5)
+        out.square().sum().backward()
+        g_zf = conv.kernel.grad.clone()
+    finally:
+        S.WEIGHT_OFFSET_ORDER = "x_fastest"
+    conv.kernel.grad = None
+    with torch.no_grad():
+        conv.kernel.copy_(w_native)
+    xg = ME.SparseTensor(features=t(f).requires_grad_(True), coordinates=t(C.astype(np.int32)), device=dev())
+    conv(xg).F.square().sum().backward()
+    assert torch.allclose(g_zf[t(zf).long()], conv.kernel.grad, atol=1e-4, rtol=1e-4)
+
+
 def test_unsupported_shape_fails_loudly():
     from unified_point_cloud_compression_amd import sparse as S, lib as L
     with pytest.raises(L.PccError):

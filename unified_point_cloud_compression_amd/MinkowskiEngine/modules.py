@@ -2,7 +2,7 @@
 
 Constructor signatures, parameter names and shapes follow MinkowskiEngine 0.5.x so the reference's
 `state_dict`s load: `kernel` is [K, Cin, Cout] ([Cin, Cout] when K == 1), `bias` is [1, Cout]
-(SURVEY A.4).  Forward passes call libpcc_hip; inference only in this round (no autograd).
+(SURVEY A.4).  Forward passes call libpcc_hip; under autograd they go through `autograd.SparseConvFn`.
 """
 import math
 
@@ -67,8 +67,10 @@ class _ConvBase(nn.Module):
         feats = x._canonical_features()
         if torch.is_grad_enabled() and (feats.requires_grad or self.kernel.requires_grad):
             from ..autograd import SparseConvFn            # training path (BASELINE config 4)
-            return SparseConvFn.apply(feats, self.kernel, self.bias, self, x._cset, out_set, kmap, act, slope)
-        packed = self._packed.get(self.kernel)
+            perm = S.weight_offset_perm(self.kernel_volume, self.kernel.device)
+            kernel = self.kernel if perm is None else self.kernel[perm]
+            return SparseConvFn.apply(feats, kernel, self.bias, self, x._cset, out_set, kmap, act, slope)
+        packed = self._packed.get(self.kernel, state_dict_order=True)
         if isinstance(kmap, tuple):          # CSR pair lists from the fused coordinate expansion
             return S.convt_forward_csr(x._canonical_features(), packed, self.bias, self.kernel_volume,
                                        self.in_channels, self.out_channels, kmap, out_set.n, act, slope)

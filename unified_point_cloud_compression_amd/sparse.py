@@ -305,6 +305,24 @@ def coordset_from_coords(coords, tensor_stride):
 # ------------------------------------------------------------------------------------------------
 # functional operators on canonical-order features
 # ------------------------------------------------------------------------------------------------
+WEIGHT_OFFSET_ORDER = "x_fastest"   # enumeration of the K kernel offsets in `kernel[K, Cin, Cout]` of a state_dict
+
+
+def weight_offset_perm(K, device):
+    """SURVEY A.3 could not re-verify MinkowskiEngine's kernel-offset enumeration offline (x fastest is assumed:
+    kidx = ix + k*iy + k*k*iz).  Should a checkpoint turn out to enumerate z fastest, set
+    `sparse.WEIGHT_OFFSET_ORDER = "z_fastest"`: weights are then re-indexed while packing (and through autograd's
+    index op in training); kernel maps, kernels and bitstreams are unaffected.  Returns None for the native order."""
+    if WEIGHT_OFFSET_ORDER == "x_fastest" or K == 1:
+        return None
+    if WEIGHT_OFFSET_ORDER != "z_fastest":
+        raise L.PccError(f"unknown WEIGHT_OFFSET_ORDER {WEIGHT_OFFSET_ORDER!r}")
+    ks = round(K ** (1.0 / 3.0))
+    idx = torch.arange(K, device=device)
+    ix, iy, iz = idx % ks, (idx // ks) % ks, idx // (ks * ks)
+    return iz + ks * iy + ks * ks * ix
+
+
 class PackedConv:
     """Packed copy of a conv weight, refreshed when the parameter changes.  `transposed` selects the flattened
     [cin, K*cout] layout of the input-stationary generative transposed convolution."""
@@ -314,11 +332,16 @@ class PackedConv:
         self.packed = None
         self.transposed = transposed
 
-    def get(self, kernel):
+    def get(self, kernel, state_dict_order=False):
+        """state_dict_order: `kernel` is a module parameter as stored in a checkpoint (see WEIGHT_OFFSET_ORDER);
+        otherwise its K axis already is in the native offset order."""
         w = kernel.detach()
-        tag = (w.data_ptr(), kernel._version, tuple(w.shape), str(w.device))
+        tag = (w.data_ptr(), kernel._version, tuple(w.shape), str(w.device), WEIGHT_OFFSET_ORDER if state_dict_order else "")
         if tag != self.tag:
             w3 = w if w.dim() == 3 else w.unsqueeze(0)
+            perm = weight_offset_perm(w3.shape[0], w3.device) if state_dict_order else None
+            if perm is not None:
+                w3 = w3[perm]
             w3 = w3.to(torch.float32).contiguous()
             K, cin, cout = w3.shape
             pre = "pcc_convt" if self.transposed else "pcc_conv"

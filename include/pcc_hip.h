@@ -133,6 +133,12 @@ int64_t pcc_grid_words(const int32_t* h_grid);
 size_t pcc_grid_ws_bytes(int64_t words);
 int pcc_grid_build(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits /*[words]*/,
                    int32_t* rank /*[words]*/, void* ws, size_t ws_bytes, void* stream);
+/* a2-i through the bitmap: strided set = occupancy of the coarse cells.  keys = the FINE canonical set; h_grid = the
+ * COARSE lattice (pitch h_grid[6] = new tensor stride, origin a multiple of it).  Marks, ranks and reads the set back
+ * out in bitmap (= canonical) order: out_keys (capacity n), *d_count, plus the coarse set's grid index in bits / rank.
+ * Same result as pcc_coords_stride without the sort; ws of pcc_grid_ws_bytes(words). */
+int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits, int32_t* rank,
+                           int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes, void* stream);
 /* dense [K][n_out] view of any map (testing / inspection): -1 where no pair */
 int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows, int64_t n_out,
                      int32_t K, int32_t* dense, void* stream);

@@ -74,9 +74,11 @@ def test_empty_inputs():
     assert x._cset.expand(2, 1).n == 0
 
 
+@pytest.mark.parametrize("by_grid", [True, False], ids=["bitmap", "sort"])
 @pytest.mark.parametrize("seed,size,p,ts", [(0, 40, 0.1, 1), (1, 24, 0.3, 2), (2, 64, 0.02, 4)])
-def test_stride_matches_oracle(seed, size, p, ts):
+def test_stride_matches_oracle(seed, size, p, ts, by_grid, monkeypatch):
     S, L = _S()
+    monkeypatch.setattr(S, "STRIDE_BY_GRID", by_grid)
     keys = cloud_keys(seed, size, p, ts, batch=2)
     C = co.unpack_keys(keys)
     C[:, 1:] -= 3 * ts                                 # some negative coordinates
@@ -90,6 +92,10 @@ def test_stride_matches_oracle(seed, size, p, ts):
         assert np.array_equal(n(got.keys)[:got.n], want)
         cs2 = got.stride(2 * m)                         # chained (down_conv twice, model/model.py:228-229)
         assert np.array_equal(n(cs2.keys)[:cs2.n], co.stride_keys(want, 2 * m))
+        if by_grid:                                     # the grid index that came with the set == one built from its keys
+            bits, rank, h = got.grid()
+            fresh = S.CoordSet(got.keys[:got.n].clone(), got.n, m, got.bounds).grid()
+            assert torch.equal(bits, fresh[0]) and torch.equal(rank, fresh[1]) and list(h) == list(fresh[2])
 
 
 @pytest.mark.parametrize("use_csr", [True, False], ids=["csr", "sort64"])

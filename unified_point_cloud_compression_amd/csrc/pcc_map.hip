@@ -459,6 +459,76 @@ extern "C" int pcc_grid_build(const int64_t* keys, int64_t n, const int32_t* h_g
   return PCC_OK;
 }
 
+// ---- strided coordinate set straight from the occupancy bitmap --------------------------------------------
+// unique(floor(c/m)*m) needs no sort: mark the coarse cell of every fine row (atomicOr; fine order is not coarse cell
+// order), rank the words, and read the set back out of the bitmap -- bitmap order IS canonical key order.  The coarse
+// set's grid index (bits + rank) falls out for free.  A handful of launches where the sort took ~35.
+__global__ void k_grid_bits_any(const int64_t* __restrict__ keys, int64_t n, int lo0, int lo1, int lo2, int d0, int d1,
+                                int d2, int tsl, unsigned long long* __restrict__ bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long c = grid_cell(keys[i], lo0, lo1, lo2, d0, d1, d2, tsl);
+  // neighbours in fine order often share the coarse cell (z pairs): only the first of a run issues the atomic
+  if (i > 0 && grid_cell(keys[i - 1], lo0, lo1, lo2, d0, d1, d2, tsl) == c) return;
+  atomicOr(&bits[c >> 6], 1ull << (c & 63));
+}
+
+__global__ void k_grid_enumerate(const unsigned long long* __restrict__ bits, const int* __restrict__ rank,
+                                 int64_t words, int lo0, int lo1, int lo2, int d0, int d1, int d2, int tsl,
+                                 int64_t* __restrict__ keys, int64_t* __restrict__ count) {
+  const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (wi >= words) return;
+  unsigned long long w = bits[wi];
+  int r = rank[wi];
+  if (wi == words - 1) *count = (int64_t)r + __popcll(w);
+  while (w) {
+    const int bit = __ffsll((long long)w) - 1;
+    w &= w - 1;
+    long long cell = wi * 64 + bit;
+    const int cz = (int)(cell % d2); cell /= d2;
+    const int cy = (int)(cell % d1); cell /= d1;
+    const int cx = (int)(cell % d0);
+    const int b = (int)(cell / d0);
+    const int64_t x = (int64_t)(lo0 + (cx << tsl)) + PCC_BIAS, y = (int64_t)(lo1 + (cy << tsl)) + PCC_BIAS,
+                  z = (int64_t)(lo2 + (cz << tsl)) + PCC_BIAS;
+    keys[r++] = ((int64_t)b << 48) | (x << 32) | (y << 16) | z;
+  }
+}
+
+// keys: the FINE set (canonical); h_grid: lattice of the COARSE set (lo multiples of the coarse pitch h_grid[6]).
+// Outputs: bits/rank = grid index of the coarse set, out_keys (capacity n) = its canonical keys, *d_count = its size.
+extern "C" int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits,
+                                      int32_t* rank, int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes,
+                                      void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(h_grid && bits && rank && out_keys && d_count, "pcc_coords_stride_grid: NULL array");
+  const int64_t words = pcc_grid_words(h_grid);
+  PCC_REQUIRE(words >= 1 && words < (1ll << 31), "pcc_coords_stride_grid: lattice too large (%lld words)", (long long)words);
+  const int P = h_grid[6];
+  PCC_REQUIRE(P >= 1 && (P & (P - 1)) == 0, "pcc_coords_stride_grid: pitch must be a power of two");
+  PCC_REQUIRE(h_grid[0] % P == 0 && h_grid[1] % P == 0 && h_grid[2] % P == 0,
+              "pcc_coords_stride_grid: lattice origin must be a multiple of the pitch %d", P);
+  if (ws_bytes < pcc_grid_ws_bytes(words)) {
+    pcc_set_error("pcc_coords_stride_grid: workspace too small");
+    return PCC_EWS;
+  }
+  PCC_CHECK_HIP(hipMemsetAsync(bits, 0, (size_t)words * 8, s));
+  if (n > 0) {
+    PCC_REQUIRE(keys, "pcc_coords_stride_grid: keys is NULL");
+    k_grid_bits_any<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(keys, n, h_grid[0], h_grid[1], h_grid[2], h_grid[3],
+                                                              h_grid[4], h_grid[5], ilog2(P), (unsigned long long*)bits);
+    PCC_LAUNCH_CHECK();
+  }
+  k_grid_popc<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>((const unsigned long long*)bits, words, rank);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(rank, rank, words, ws, ws_bytes, s));
+  k_grid_enumerate<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>((const unsigned long long*)bits, rank, words, h_grid[0],
+                                                                 h_grid[1], h_grid[2], h_grid[3], h_grid[4], h_grid[5],
+                                                                 ilog2(P), out_keys, d_count);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
 // dense [K][n_out] view (tests / inspection)
 __global__ void k_map_dense(const int* __restrict__ hdr, const int* __restrict__ nbr, const int* __restrict__ rows,
                             int64_t n_out, int* __restrict__ dense) {

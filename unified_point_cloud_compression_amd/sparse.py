@@ -91,6 +91,7 @@ PAIR_MIN_CIN = 64        # ... and enough input channels to pay for writing and 
 COUNT_PAIRS = False   # bench.py switches this on for its FLOP accounting pass
 MORTON_MIN_ROWS = 1 << 62    # Z-curve visiting order of conv maps: measured no gain on MI355X (round 1), off by default
 USE_CSR = True        # generative expansion also emits the transposed map as CSR pair lists (False: class map + lookup)
+STRIDE_BY_GRID = True  # strided sets read out of the coarse occupancy bitmap (False: mask + radix sort + unique)
 USE_GRID = True       # neighbour lookup through the bitmap+rank grid index (False: binary search; tests run both)
 GRID_MAX_BYTES = 8 << 30
 
@@ -148,15 +149,30 @@ class CoordSet:
         key = ("stride", new_stride)
         if key not in self._derived:
             dev = self.device
-            out = torch.empty(max(self.n, 1), dtype=torch.int64, device=dev)
+            lib = L.load()
+            nb = self.bounds.strided(new_stride)
+            dims = [(nb.hi[i] - nb.lo[i]) // new_stride + 1 for i in range(3)]
+            h = (C.c_int32 * 8)(nb.lo[0], nb.lo[1], nb.lo[2], dims[0], dims[1], dims[2], new_stride, nb.bmax + 1)
+            words = lib.pcc_grid_words(h)
             cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-            nb = L.load().pcc_stride_ws_bytes(self.n)
-            ws = L.workspace(nb, dev)
+            out = torch.empty(max(self.n, 1), dtype=torch.int64, device=dev)
+            if USE_GRID and STRIDE_BY_GRID and self.n > 0 and words < (1 << 31) and words * 12 <= GRID_MAX_BYTES:
+                # through the occupancy bitmap of the coarse lattice: no sort, and the coarse set's grid index for free
+                bits = torch.empty(words, dtype=torch.int64, device=dev)
+                rank = torch.empty(words, dtype=torch.int32, device=dev)
+                ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
+                L.call("pcc_coords_stride_grid", L.ptr(self.keys), self.n, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
+                       L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+                n = int(cnt.item())
+                cs = CoordSet(out[:n].clone() if n < self.n // 2 else out, n, new_stride, nb)
+                cs._grid = (bits, rank, h)
+                self._derived[key] = cs
+                return cs
+            ws = L.workspace(lib.pcc_stride_ws_bytes(self.n), dev)
             L.call("pcc_coords_stride", L.ptr(self.keys), self.n, new_stride, self.bounds.bit_mask(), L.ptr(out),
                    L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
             n = int(cnt.item())
-            self._derived[key] = CoordSet(out[:n].clone() if n < self.n // 2 else out, n, new_stride,
-                                          self.bounds.strided(new_stride))
+            self._derived[key] = CoordSet(out[:n].clone() if n < self.n // 2 else out, n, new_stride, nb)
         return self._derived[key]
 
     def expand(self, ksize, ts_out):

@@ -139,6 +139,18 @@ int pcc_grid_build(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64
  * Same result as pcc_coords_stride without the sort; ws of pcc_grid_ws_bytes(words). */
 int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits, int32_t* rank,
                            int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes, void* stream);
+/* a3-i through the bitmaps: generative expansion without sorting the n*K candidates.
+ *   pcc_coords_expand_grid     : marks the output lattice h_out (pitch ts_out), ranks it and reads the canonical output
+ *                                keys back out; bits / rank = grid index of the output set; *d_count = n_out.
+ *   pcc_coords_expand_grid_csr : (n_out known) CSR pair lists of the transposed map by probing the INPUT set's grid at
+ *                                c - off_k in ascending input row: first[n_out+1], pair_ids[n_in*K] (pair = i*K + k),
+ *                                identical to pcc_coords_expand_csr's. */
+int pcc_coords_expand_grid(const int64_t* keys, int64_t n, int32_t kernel_size, const int32_t* h_out, uint64_t* bits,
+                           int32_t* rank, int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes, void* stream);
+size_t pcc_expand_grid_csr_ws_bytes(int64_t n_out);
+int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
+                               const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in, int64_t n_in,
+                               int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes, void* stream);
 /* dense [K][n_out] view of any map (testing / inspection): -1 where no pair */
 int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows, int64_t n_out,
                      int32_t K, int32_t* dense, void* stream);

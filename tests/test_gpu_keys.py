@@ -98,11 +98,14 @@ def test_stride_matches_oracle(seed, size, p, ts, by_grid, monkeypatch):
             assert torch.equal(bits, fresh[0]) and torch.equal(rank, fresh[1]) and list(h) == list(fresh[2])
 
 
-@pytest.mark.parametrize("use_csr", [True, False], ids=["csr", "sort64"])
+@pytest.mark.parametrize("mode", ["bitmap", "sort32", "sort64"])
 @pytest.mark.parametrize("ks,ts_in", [(5, 2), (2, 2), (2, 32), (5, 8), (3, 2)])
-def test_expand_matches_oracle(ks, ts_in, use_csr, monkeypatch):
+def test_expand_matches_oracle(ks, ts_in, mode, monkeypatch):
+    """The three expansion paths (bitmap marking + grid probing / 32-bit cell sort with pair ids / 64-bit key sort)."""
     S, L = _S()
+    use_csr = mode != "sort64"
     monkeypatch.setattr(S, "USE_CSR", use_csr)
+    monkeypatch.setattr(S, "EXPAND_BY_GRID", mode == "bitmap")
     keys = cloud_keys(7, 20, 0.08, ts_in, batch=2)       # includes coordinates at 0 -> negative outputs for k5
     C = co.unpack_keys(keys)
     cs = S.CoordSet(t(keys), len(keys), ts_in, S.Bounds(1, C[:, 1:].min(0), C[:, 1:].max(0)))
@@ -123,3 +126,7 @@ def test_expand_matches_oracle(ks, ts_in, use_csr, monkeypatch):
             ks_valid = np.nonzero(nbr[:, o] >= 0)[0]
             want_ids = np.sort(nbr[ks_valid, o].astype(np.int64) * K + ks_valid)
             assert np.array_equal(lst, want_ids), o
+    if mode == "bitmap":     # the grid index that came with the output set == one built from its keys
+        bits, rank, h = got.grid()
+        fresh = S.CoordSet(got.keys[:got.n].clone(), got.n, got.ts, got.bounds).grid()
+        assert torch.equal(bits, fresh[0]) and torch.equal(rank, fresh[1]) and list(h) == list(fresh[2])

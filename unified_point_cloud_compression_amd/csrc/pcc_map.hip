@@ -529,6 +529,156 @@ extern "C" int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int3
   return PCC_OK;
 }
 
+// ---- generative expansion through the bitmaps ----------------------------------------------------------------
+// out = union_k (in + off_k * ts_out), plus the transposed map as CSR pair lists, without sorting the n*K candidates:
+//   mark   : thread (input row, kernel column kx,ky) ORs its ks z-consecutive cells into the output bitmap (<= 2 atomics)
+//   rank   : popcount + scan; enumerate the set bits -> canonical output keys (and the output set's grid index)
+//   csr    : thread per output row probes the INPUT grid at c - off_k for the offsets whose parity fits, x then y then z
+//            descending, i.e. in ascending input row: exactly the pair-id order a stable sort by cell would give.
+//            One pass counts, a scan gives first[], a second pass writes pair ids i*K + k.
+template <int KS>
+__global__ void __launch_bounds__(256) k_expand_mark(const int64_t* __restrict__ keys, int64_t n, int ts_out, int lo0,
+                                                     int lo1, int lo2, int d0, int d1, int d2, int tsl,
+                                                     unsigned long long* __restrict__ bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int H = (KS & 1) ? (KS - 1) / 2 : 0;
+  const int kxy = blockIdx.y;
+  const int64_t key = keys[i];
+  const int b = (int)(key >> 48);
+  const int cx = ((int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - lo0 + (kxy % KS - H) * ts_out) >> tsl;
+  const int cy = ((int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - lo1 + (kxy / KS - H) * ts_out) >> tsl;
+  const int cz = ((int)(key & 0xFFFF) - (int)PCC_BIAS - lo2 - H * ts_out) >> tsl;
+  const long long cell = (((long long)b * d0 + cx) * d1 + cy) * d2 + cz;     // KS consecutive cells along z
+  const int bit = (int)(cell & 63);
+  const unsigned long long m = (1ull << KS) - 1ull;
+  atomicOr(&bits[cell >> 6], m << bit);
+  if (bit + KS > 64) atomicOr(&bits[(cell >> 6) + 1], m >> (64 - bit));
+}
+
+struct ExpandCsrArgs {
+  const int64_t* out_keys; long long n_out;
+  PccGrid in;                 // grid index of the input set
+  int ts_out; int K;
+  int* first;                 // FILL=false: first[o] = pairs of row o;  FILL=true: exclusive prefix (read)
+  int* pair_ids;
+};
+
+template <int KS, bool FILL>
+__global__ void __launch_bounds__(256) k_expand_csr(ExpandCsrArgs a) {
+  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.n_out) return;
+  constexpr int H = (KS & 1) ? (KS - 1) / 2 : 0;
+  const int64_t key = a.out_keys[o];
+  const int b = (int)(key >> 48);
+  const int c[3] = {(int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - a.in.lo[0],
+                    (int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - a.in.lo[1],
+                    (int)(key & 0xFFFF) - (int)PCC_BIAS - a.in.lo[2]};
+  const int tm = (1 << a.in.ts_log2) - 1;
+  // per axis: the offsets whose source lies on the input lattice, offset index descending = source cell ascending
+  int cell_ax[3][KS], idx_ax[3][KS], cnt_ax[3];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    int m = 0;
+#pragma unroll
+    for (int ia = KS - 1; ia >= 0; --ia) {
+      const int rel = c[ax] - (ia - H) * a.ts_out;
+      const int cc = rel >> a.in.ts_log2;
+      if (rel >= 0 && !(rel & tm) && cc < a.in.dims[ax]) { cell_ax[ax][m] = cc; idx_ax[ax][m] = ia; ++m; }
+    }
+    cnt_ax[ax] = m;
+  }
+  int total = 0;
+  int wpos = FILL ? a.first[o] : 0;
+  if (b < a.in.nbatch) {
+    long long wi = -1;
+    unsigned long long w = 0;
+    int rk = 0;
+    for (int jx = 0; jx < cnt_ax[0]; ++jx)
+      for (int jy = 0; jy < cnt_ax[1]; ++jy) {
+        const long long row = (((long long)b * a.in.dims[0] + cell_ax[0][jx]) * a.in.dims[1] + cell_ax[1][jy]) * a.in.dims[2];
+        for (int jz = 0; jz < cnt_ax[2]; ++jz) {
+          const long long cell = row + cell_ax[2][jz];
+          if ((cell >> 6) != wi) { wi = cell >> 6; w = a.in.bits[wi]; if (FILL) rk = a.in.rank[wi]; }
+          const int bit = (int)(cell & 63);
+          if ((w >> bit) & 1ull) {
+            if (FILL) {
+              const int i = rk + __popcll(w & ((1ull << bit) - 1ull));
+              a.pair_ids[wpos++] = i * a.K + idx_ax[0][jx] + KS * idx_ax[1][jy] + KS * KS * idx_ax[2][jz];
+            } else ++total;
+          }
+        }
+      }
+  }
+  if (!FILL) a.first[o] = total;
+}
+
+__global__ void k_set_int(int* p, int v) { *p = v; }
+
+// phase 1: output set + its grid index.  h_out: output lattice (pitch ts_out).  out_keys capacity >= min(n*K, cells).
+extern "C" int pcc_coords_expand_grid(const int64_t* keys, int64_t n, int32_t kernel_size, const int32_t* h_out,
+                                      uint64_t* bits, int32_t* rank, int64_t* out_keys, int64_t* d_count, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(keys && h_out && bits && rank && out_keys && d_count && n > 0, "pcc_coords_expand_grid: bad arguments");
+  PCC_REQUIRE(kernel_size == 2 || kernel_size == 3 || kernel_size == 5, "pcc_coords_expand_grid: kernel_size %d unsupported", kernel_size);
+  const int64_t words = pcc_grid_words(h_out);
+  PCC_REQUIRE(words >= 1 && words < (1ll << 31), "pcc_coords_expand_grid: lattice too large (%lld words)", (long long)words);
+  const int ts_out = h_out[6];
+  PCC_REQUIRE(ts_out >= 1 && (ts_out & (ts_out - 1)) == 0, "pcc_coords_expand_grid: pitch must be a power of two");
+  if (ws_bytes < pcc_grid_ws_bytes(words)) { pcc_set_error("pcc_coords_expand_grid: workspace too small"); return PCC_EWS; }
+  PCC_CHECK_HIP(hipMemsetAsync(bits, 0, (size_t)words * 8, s));
+  const dim3 g((unsigned)pcc_cdiv(n, 256), (unsigned)(kernel_size * kernel_size));
+  unsigned long long* b = (unsigned long long*)bits;
+  const int tsl = ilog2(ts_out);
+  if (kernel_size == 2) k_expand_mark<2><<<g, 256, 0, s>>>(keys, n, ts_out, h_out[0], h_out[1], h_out[2], h_out[3], h_out[4], h_out[5], tsl, b);
+  else if (kernel_size == 3) k_expand_mark<3><<<g, 256, 0, s>>>(keys, n, ts_out, h_out[0], h_out[1], h_out[2], h_out[3], h_out[4], h_out[5], tsl, b);
+  else k_expand_mark<5><<<g, 256, 0, s>>>(keys, n, ts_out, h_out[0], h_out[1], h_out[2], h_out[3], h_out[4], h_out[5], tsl, b);
+  PCC_LAUNCH_CHECK();
+  k_grid_popc<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, words, rank);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(rank, rank, words, ws, ws_bytes, s));
+  k_grid_enumerate<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, rank, words, h_out[0], h_out[1], h_out[2], h_out[3],
+                                                                 h_out[4], h_out[5], tsl, out_keys, d_count);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" size_t pcc_expand_grid_csr_ws_bytes(int64_t n_out) { return pcc_scan_ws_bytes(n_out) + 256; }
+
+// phase 2 (n_out known to the host): CSR pair lists of the transposed map: first[n_out+1], pair_ids[n_in*K]
+extern "C" int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
+                                          const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in,
+                                          int64_t n_in, int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes,
+                                          void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(out_keys && in_bits && in_rank && h_in && first && pair_ids && n_out > 0, "pcc_coords_expand_grid_csr: bad arguments");
+  PCC_REQUIRE(kernel_size == 2 || kernel_size == 3 || kernel_size == 5, "pcc_coords_expand_grid_csr: kernel_size %d unsupported", kernel_size);
+  const int K = kernel_size * kernel_size * kernel_size;
+  PCC_REQUIRE(n_in * K < (1ll << 31), "pcc_coords_expand_grid_csr: too many pairs");
+  if (ws_bytes < pcc_expand_grid_csr_ws_bytes(n_out)) { pcc_set_error("pcc_coords_expand_grid_csr: workspace too small"); return PCC_EWS; }
+  ExpandCsrArgs a;
+  a.out_keys = out_keys; a.n_out = n_out; a.ts_out = ts_out; a.K = K; a.first = first; a.pair_ids = pair_ids;
+  a.in.bits = (const unsigned long long*)in_bits; a.in.rank = in_rank;
+  for (int i = 0; i < 3; ++i) { a.in.lo[i] = h_in[i]; a.in.dims[i] = h_in[3 + i]; }
+  a.in.ts_log2 = ilog2(h_in[6]); a.in.nbatch = h_in[7];
+  const unsigned g = (unsigned)pcc_cdiv(n_out, 256);
+#define PCC_EXPAND_CSR(FILL)                                                        \
+  do {                                                                              \
+    if (kernel_size == 2) k_expand_csr<2, FILL><<<g, 256, 0, s>>>(a);               \
+    else if (kernel_size == 3) k_expand_csr<3, FILL><<<g, 256, 0, s>>>(a);          \
+    else k_expand_csr<5, FILL><<<g, 256, 0, s>>>(a);                                \
+    PCC_LAUNCH_CHECK();                                                             \
+  } while (0)
+  PCC_EXPAND_CSR(false);
+  PCC_TRY(pcc_scan_exclusive_i32(first, first, n_out, ws, ws_bytes, s));
+  k_set_int<<<1, 1, 0, s>>>(first + n_out, (int)(n_in * K));
+  PCC_LAUNCH_CHECK();
+  PCC_EXPAND_CSR(true);
+#undef PCC_EXPAND_CSR
+  return PCC_OK;
+}
+
 // dense [K][n_out] view (tests / inspection)
 __global__ void k_map_dense(const int* __restrict__ hdr, const int* __restrict__ nbr, const int* __restrict__ rows,
                             int64_t n_out, int* __restrict__ dense) {

@@ -46,6 +46,9 @@ SIGNATURES = {
     "pcc_grid_ws_bytes": (_sz, [_i64]),
     "pcc_grid_build": (C.c_int, [_p, _i64, C.POINTER(_i32), _p, _p, _p, _sz, _p]),
     "pcc_coords_stride_grid": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pcc_coords_expand_grid": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pcc_expand_grid_csr_ws_bytes": (_sz, [_i64]),
+    "pcc_coords_expand_grid_csr": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
     "pcc_map_to_dense": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),

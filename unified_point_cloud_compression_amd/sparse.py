@@ -91,6 +91,7 @@ PAIR_MIN_CIN = 64        # ... and enough input channels to pay for writing and 
 COUNT_PAIRS = False   # bench.py switches this on for its FLOP accounting pass
 MORTON_MIN_ROWS = 1 << 62    # Z-curve visiting order of conv maps: measured no gain on MI355X (round 1), off by default
 USE_CSR = True        # generative expansion also emits the transposed map as CSR pair lists (False: class map + lookup)
+EXPAND_BY_GRID = True  # generative expansion through the bitmaps (False: 32-bit cell radix sort with pair ids as payload)
 STRIDE_BY_GRID = True  # strided sets read out of the coarse occupancy bitmap (False: mask + radix sort + unique)
 USE_GRID = True       # neighbour lookup through the bitmap+rank grid index (False: binary search; tests run both)
 GRID_MAX_BYTES = 8 << 30
@@ -185,8 +186,33 @@ class CoordSet:
             ob = self.bounds.expanded(ksize, ts_out)
             dims = [(ob.hi[i] - ob.lo[i]) // ts_out + 1 for i in range(3)]
             cells = (ob.bmax + 1) * dims[0] * dims[1] * dims[2]
+            h = (C.c_int32 * 8)(ob.lo[0], ob.lo[1], ob.lo[2], dims[0], dims[1], dims[2], ts_out, ob.bmax + 1)
+            words = (cells + 63) // 64
+            g_in = self.grid() if (USE_CSR and USE_GRID and EXPAND_BY_GRID and self.n > 0 and ksize in (2, 3, 5) and
+                                   words < (1 << 31) and words * 12 <= GRID_MAX_BYTES and self.n * K < (1 << 31)) else None
+            if g_in:
+                # mark the output bitmap, read the set back out, then build the pair lists by probing this set's grid
+                lib = L.load()
+                m = self.n * K
+                bits = torch.empty(words, dtype=torch.int64, device=dev)
+                rank = torch.empty(words, dtype=torch.int32, device=dev)
+                out = torch.empty(min(m, cells), dtype=torch.int64, device=dev)
+                cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+                ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
+                L.call("pcc_coords_expand_grid", L.ptr(self.keys), self.n, ksize, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
+                       L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+                n = int(cnt.item())
+                first = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                pair_ids = torch.empty(m, dtype=torch.int32, device=dev)
+                ws = L.workspace(lib.pcc_expand_grid_csr_ws_bytes(n), dev)
+                L.call("pcc_coords_expand_grid_csr", L.ptr(out), n, ksize, ts_out, L.ptr(g_in[0]), L.ptr(g_in[1]), g_in[2],
+                       self.n, L.ptr(first), L.ptr(pair_ids), L.ptr(ws), ws.numel(), L.stream())
+                cs = CoordSet(out[:n].clone() if n < out.numel() // 2 else out, n, ts_out, ob)
+                cs._grid = (bits, rank, h)
+                self._derived[key] = cs
+                self._derived[("csr", ksize, ts_out)] = (first, pair_ids)
+                return cs
             if USE_CSR and self.n > 0 and cells <= 0xFFFFFFFF and self.n * K < (1 << 31):
-                h = (C.c_int32 * 8)(ob.lo[0], ob.lo[1], ob.lo[2], dims[0], dims[1], dims[2], ts_out, ob.bmax + 1)
                 m = self.n * K
                 out = torch.empty(m, dtype=torch.int64, device=dev)
                 pair_ids = torch.empty(m, dtype=torch.int32, device=dev)

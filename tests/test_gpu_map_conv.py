@@ -242,6 +242,23 @@ def test_weight_offset_order_hook():
     assert torch.allclose(g_zf[t(zf).long()], conv.kernel.grad, atol=1e-4, rtol=1e-4)
 
 
+def test_fallback_kernels_in_subprocess():
+    """The kernels behind the size limits of the fast paths (pointer-addressed MFMA gathers for feature arrays over
+    4 GB, the generic wave16 kernel, sort-based coordinate sets) are selected by load-time switches: run the feature
+    tests of this file once more in a child process with the fast paths off."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("PCC_TEST_CHILD"):
+        pytest.skip("already the child")
+    env = dict(os.environ, PCC_TEST_CHILD="1", PCC_MFMA_BUF="0", PCC_WAVE16_ZRUN="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_map_conv.py", "-x", "-q", "-k",
+                        "features or strided or pair_list or gdn or row_tails"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 def test_unsupported_shape_fails_loudly():
     from unified_point_cloud_compression_amd import sparse as S, lib as L
     with pytest.raises(L.PccError):

@@ -85,6 +85,49 @@ def test_compress_decompress_matches_oracle_and_golden(seed):
     assert abs(bits - float(gold["bits"])) / float(gold["bits"]) < 5e-3
 
 
+@pytest.mark.parametrize("bits", [6, 7, 8])
+def test_r2_architecture_parity_small_surface(bits):
+    """The full-width R2 architecture (128 / 192 channels: MFMA kernels, pair-list 5x5x5 convolutions, the z-run
+    32->16 kernel, thin heads) end to end against the oracle on a small synthetic surface."""
+    from unified_point_cloud_compression_amd import synth
+    cfg = codec.R2_CONFIG
+    P = codec.random_params(cfg, 0, gain=3.0)
+    model = _model(cfg, P)
+    pc = synth.surface_cloud(0, bits)
+    q = np.array([[0.5, 0.5]], dtype=np.float32)
+    streams, shapes, ks, coords, qs = model.compress(t(pc), t(q), block_size=1024)
+    blocks = codec.compress(P, cfg, pc, q)
+    assert len(streams) == len(blocks) == 1 and ks[0] == blocks[0]["k"]
+    y_keys = n(coords[0]._pcc_cset.keys)[:coords[0].shape[0]]
+    assert np.array_equal(y_keys, blocks[0]["y_keys"])
+    y_sym, z_sym = n(streams[0][0]), n(streams[0][1])
+    _sym_close(y_sym, blocks[0]["y_symbols"], "y symbols")
+    _sym_close(z_sym, blocks[0]["z_symbols"], "z symbols")
+    trace_g, trace_o = {}, {}
+    rec = n(model.decompress(coordinates=coords, strings=streams, shape=shapes, k=ks, q_vals=qs, trace=trace_g))
+    blk = dict(y_keys=y_keys, y_symbols=y_sym, z_symbols=z_sym, k=ks[0], q=q)
+    rec_o = codec.decompress(P, cfg, [blk], trace=trace_o)
+    same_sets = True
+    for lvl in range(3):
+        if not same_sets:
+            break               # a flipped near-tie at one level changes the sets of the next: nothing left to compare
+        assert np.array_equal(n(trace_g[f"keys_{lvl}"]), trace_o[f"keys_{lvl}"]), f"generative coords level {lvl}"
+        assert_close(n(trace_g[f"feats_{lvl}"]), trace_o[f"feats_{lvl}"], what=f"features level {lvl}")
+        assert_close(n(trace_g[f"logit_{lvl}"]), trace_o[f"logit_{lvl}"], atol=2e-4, what=f"logits level {lvl}")
+        gl = n(trace_g[f"logit_{lvl}"])[:, 0]
+        mg = n(trace_g[f"mask_{lvl}"])
+        assert np.array_equal(mg, ops.topk_mask(gl, ks[0][lvl]))               # exact for the GPU's own logits
+        mo = trace_o[f"mask_{lvl}"]
+        flips = int((mg != mo).sum())
+        if flips:               # only rows whose logit sits within float noise of the k-th may differ
+            kth = np.sort(gl)[::-1][ks[0][lvl][0] - 1]
+            assert flips <= 4 and np.all(np.abs(gl[mg != mo] - kth) < 2e-4), (lvl, flips)
+            same_sets = False
+    if same_sets:
+        assert rec.shape == rec_o.shape and np.array_equal(rec[:, :3], rec_o[:, :3])
+    assert rec.shape[0] == pc.shape[0]
+
+
 def test_multi_block_partition_matches_oracle():
     from unified_point_cloud_compression_amd import synth
     cfg = codec.small_config()

@@ -139,6 +139,13 @@ int pcc_grid_build(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64
  * Same result as pcc_coords_stride without the sort; ws of pcc_grid_ws_bytes(words). */
 int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits, int32_t* rank,
                            int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes, void* stream);
+/* a1 through the bitmap: canonical order and first-wins de-duplication of USER-ordered keys without a sort.
+ * bits / rank = the set's grid index, out_keys (capacity n) = canonical keys, first_user[canonical position] = smallest
+ * user row with that coordinate, d_count[0] = number of distinct coordinates, d_count[1] != 0 when some key is off the
+ * lattice (results invalid: use pcc_sort_keys + pcc_unique_sorted).  h_grid must cover all keys. */
+int pcc_keys_canonicalize_grid(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits, int32_t* rank,
+                               int64_t* out_keys, int32_t* first_user, int64_t* d_count, void* ws, size_t ws_bytes,
+                               void* stream);
 /* a3-i through the bitmaps: generative expansion without sorting the n*K candidates.
  *   pcc_coords_expand_grid     : marks the output lattice h_out (pitch ts_out), ranks it and reads the canonical output
  *                                keys back out; bits / rank = grid index of the output set; *d_count = n_out.

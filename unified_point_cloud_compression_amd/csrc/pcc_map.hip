@@ -529,6 +529,66 @@ extern "C" int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int3
   return PCC_OK;
 }
 
+// ---- canonical order of user-ordered rows through the bitmap (ME.SparseTensor construction, a1) ------------------
+__global__ void k_grid_bits_each(const int64_t* __restrict__ keys, int64_t n, int lo0, int lo1, int lo2, int d0, int d1,
+                                 int d2, int tsl, unsigned long long* __restrict__ bits, int64_t* __restrict__ off_lattice) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t key = keys[i];
+  const int x = (int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - lo0, y = (int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - lo1,
+            z = (int)(key & 0xFFFF) - (int)PCC_BIAS - lo2;
+  if ((x | y | z) & ((1 << tsl) - 1)) { *off_lattice = 1; return; }      // not a multiple of the pitch: caller falls back
+  const long long c = grid_cell(key, lo0, lo1, lo2, d0, d1, d2, tsl);
+  atomicOr(&bits[c >> 6], 1ull << (c & 63));
+}
+
+// canonical position of every user row; the smallest user row of a cell wins (first duplicate kept)
+__global__ void k_grid_first_user(const int64_t* __restrict__ keys, int64_t n, int lo0, int lo1, int lo2, int d0, int d1,
+                                  int d2, int tsl, const unsigned long long* __restrict__ bits,
+                                  const int* __restrict__ rank, int* __restrict__ first_user) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long c = grid_cell(keys[i], lo0, lo1, lo2, d0, d1, d2, tsl);
+  const unsigned long long w = bits[c >> 6];
+  const int r = rank[c >> 6] + __popcll(w & ((1ull << (c & 63)) - 1ull));
+  atomicMin(&first_user[r], (int)i);
+}
+
+// keys in USER order (any order, duplicates allowed).  Outputs: the set's grid index (bits, rank), its canonical keys
+// (capacity n), first_user[canonical position] = smallest user row holding that coordinate, d_count[0] = unique rows,
+// d_count[1] != 0: some key is not on the lattice (not a multiple of the pitch) -- results invalid, use the sort path.
+extern "C" int pcc_keys_canonicalize_grid(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits,
+                                          int32_t* rank, int64_t* out_keys, int32_t* first_user, int64_t* d_count,
+                                          void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(keys && h_grid && bits && rank && out_keys && first_user && d_count && n > 0 && n < (1ll << 31),
+              "pcc_keys_canonicalize_grid: bad arguments");
+  const int64_t words = pcc_grid_words(h_grid);
+  PCC_REQUIRE(words >= 1 && words < (1ll << 31), "pcc_keys_canonicalize_grid: lattice too large (%lld words)", (long long)words);
+  const int P = h_grid[6];
+  PCC_REQUIRE(P >= 1 && (P & (P - 1)) == 0, "pcc_keys_canonicalize_grid: pitch must be a power of two");
+  if (ws_bytes < pcc_grid_ws_bytes(words)) { pcc_set_error("pcc_keys_canonicalize_grid: workspace too small"); return PCC_EWS; }
+  const int tsl = ilog2(P);
+  unsigned long long* b = (unsigned long long*)bits;
+  PCC_CHECK_HIP(hipMemsetAsync(bits, 0, (size_t)words * 8, s));
+  PCC_CHECK_HIP(hipMemsetAsync(first_user, 0x7F, (size_t)n * 4, s));
+  PCC_CHECK_HIP(hipMemsetAsync(d_count, 0, 2 * sizeof(int64_t), s));
+  const unsigned g = (unsigned)pcc_cdiv(n, 256);
+  k_grid_bits_each<<<g, 256, 0, s>>>(keys, n, h_grid[0], h_grid[1], h_grid[2], h_grid[3], h_grid[4], h_grid[5], tsl, b,
+                                     d_count + 1);
+  PCC_LAUNCH_CHECK();
+  k_grid_popc<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, words, rank);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(rank, rank, words, ws, ws_bytes, s));
+  k_grid_first_user<<<g, 256, 0, s>>>(keys, n, h_grid[0], h_grid[1], h_grid[2], h_grid[3], h_grid[4], h_grid[5], tsl, b,
+                                      rank, first_user);
+  PCC_LAUNCH_CHECK();
+  k_grid_enumerate<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, rank, words, h_grid[0], h_grid[1], h_grid[2],
+                                                                 h_grid[3], h_grid[4], h_grid[5], tsl, out_keys, d_count);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
 // ---- generative expansion through the bitmaps ----------------------------------------------------------------
 // out = union_k (in + off_k * ts_out), plus the transposed map as CSR pair lists, without sorting the n*K candidates:
 //   mark   : thread (input row, kernel column kx,ky) ORs its ks z-consecutive cells into the output bitmap (<= 2 atomics)

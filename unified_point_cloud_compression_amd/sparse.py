@@ -91,6 +91,7 @@ PAIR_MIN_CIN = 64        # ... and enough input channels to pay for writing and 
 COUNT_PAIRS = False   # bench.py switches this on for its FLOP accounting pass
 MORTON_MIN_ROWS = 1 << 62    # Z-curve visiting order of conv maps: measured no gain on MI355X (round 1), off by default
 USE_CSR = True        # generative expansion also emits the transposed map as CSR pair lists (False: class map + lookup)
+CANON_BY_GRID = True   # canonical order of user rows through the bitmap (False: radix sort + unique)
 EXPAND_BY_GRID = True  # generative expansion through the bitmaps (False: 32-bit cell radix sort with pair ids as payload)
 STRIDE_BY_GRID = True  # strided sets read out of the coarse occupancy bitmap (False: mask + radix sort + unique)
 USE_GRID = True       # neighbour lookup through the bitmap+rank grid index (False: binary search; tests run both)
@@ -322,6 +323,31 @@ def coordset_from_coords(coords, tensor_stride):
         return CoordSet(keys, n, tensor_stride, b), None, None
     dev = coords.device
     lib = L.load()
+    dims = [(b.hi[i] - b.lo[i]) // tensor_stride + 1 for i in range(3)]
+    h = (C.c_int32 * 8)(b.lo[0], b.lo[1], b.lo[2], dims[0], dims[1], dims[2], tensor_stride, b.bmax + 1)
+    words = lib.pcc_grid_words(h)
+    on_lattice = all(v % tensor_stride == 0 for v in b.lo)      # rows of a stride-ts tensor sit on multiples of ts
+    if USE_GRID and CANON_BY_GRID and on_lattice and words < (1 << 31) and words * 12 <= GRID_MAX_BYTES:
+        # through the occupancy bitmap: canonical keys, first-wins row per coordinate and the grid index, no sort
+        bits = torch.empty(words, dtype=torch.int64, device=dev)
+        rank = torch.empty(words, dtype=torch.int32, device=dev)
+        ukeys = torch.empty(n, dtype=torch.int64, device=dev)
+        first_user = torch.empty(n, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
+        L.call("pcc_keys_canonicalize_grid", L.ptr(keys), n, h, L.ptr(bits), L.ptr(rank), L.ptr(ukeys), L.ptr(first_user),
+               L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+        nu, off_lattice = (int(v) for v in cnt.tolist())
+        if not off_lattice:
+            cs = CoordSet(ukeys[:nu].clone() if nu < n else ukeys, nu, tensor_stride, b)
+            cs._grid = (bits, rank, h)
+            first_user = first_user[:nu].long()
+            if nu == n:
+                return cs, first_user, None
+            keep, inv = torch.sort(first_user)            # surviving user rows, original order
+            rank_u = torch.empty_like(inv)
+            rank_u[inv] = torch.arange(nu, device=dev)
+            return cs, rank_u, keep
     skeys = torch.empty(n, dtype=torch.int64, device=dev)
     perm = torch.empty(n, dtype=torch.int32, device=dev)
     ws = L.workspace(lib.pcc_sort_ws_bytes(n), dev)

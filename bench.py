@@ -81,9 +81,9 @@ def account_flops(model, pc, q):
         calls.append((kmap, K, cin, cout, n_out, feats.shape[0]))     # pairs = n_in*K: the dense GEMM does exactly the algorithmic FLOPs
         return orig_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act, slope)
 
-    def spy_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
-        calls.append((feats.shape[0] * K, K, cin, cout, n_out, feats.shape[0]))        # every (input row, offset) is one pair
-        return orig_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope)
+    def spy_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01, **kw):
+        calls.append((int(csr[0][n_out].item()), K, cin, cout, n_out, feats.shape[0]))  # pairs of the map (full expansion: n_in*K)
+        return orig_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope, **kw)
 
     S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr = True, spy, spy_t, spy_c
     try:

@@ -154,6 +154,10 @@ int pcc_keys_canonicalize_grid(const int64_t* keys, int64_t n, const int32_t* h_
  *                                identical to pcc_coords_expand_csr's. */
 int pcc_coords_expand_grid(const int64_t* keys, int64_t n, int32_t kernel_size, const int32_t* h_out, uint64_t* bits,
                            int32_t* rank, int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes, void* stream);
+/* conv-form map (one segment, nbr[k*n_out + o] = input row or -1) from CSR pair lists: evaluates a transposed conv on a
+ * subset of its output rows with pcc_conv_fwd / pcc_conv_fwd_pairs.  hdr: PCC_MAP_HDR_INTS ints, nbr: K*n_out ints. */
+int pcc_map_from_csr(const int32_t* first, const int32_t* pair_ids, int64_t n_out, int32_t kernel_size, int32_t* hdr,
+                     int32_t* nbr, void* stream);
 size_t pcc_expand_grid_csr_ws_bytes(int64_t n_out);
 int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
                                const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in, int64_t n_in,
@@ -213,7 +217,8 @@ int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* 
 int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                       const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* first,
                       const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
-                      void* stream);
+                      const int32_t* ex_nbr /*nullable [ex_K][n_out]*/, int32_t ex_K,
+                      const float* ex_bias /*[ex_K][cout]*/, void* stream);
 
 /* a5  fused GDN / IGDN (GDN1 form), MinkowskiGDN.forward model/blocks.py:26-57:
  *   norm = beta + |x| @ gamma^T ; out = x / norm (inverse=0) or x * norm (inverse=1)

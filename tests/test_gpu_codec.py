@@ -128,6 +128,41 @@ def test_r2_architecture_parity_small_surface(bits):
     assert rec.shape[0] == pc.shape[0]
 
 
+@pytest.mark.parametrize("which", ["small", "r2"])
+def test_fused_up_predict_matches_layerwise(which):
+    """Inference evaluates an up-sampling block and its occupancy head as one composite 7x7x7 generative convolution
+    (and the up-sampled features only for the kept rows): same logits up to float noise, same occupancy decisions, same
+    reconstruction as the layer-by-layer path, and as the oracle."""
+    from unified_point_cloud_compression_amd import synth
+    from unified_point_cloud_compression_amd.model.transforms import SparseSynthesisTransform as G
+    from unified_point_cloud_compression_amd.MinkowskiEngine.sparse_tensor import SparseTensor
+    if which == "small":
+        cfg, pc, gain = codec.small_config(), synth.random_block(4, 40, 0.08), 4.0
+    else:
+        cfg, pc, gain = codec.R2_CONFIG, synth.surface_cloud(0, 7), 3.0
+    P = codec.random_params(cfg, 3, gain=gain)
+    model = _model(cfg, P)
+    q = np.array([[0.5, 0.5]], dtype=np.float32)
+    streams, shapes, ks, coords, qs = model.compress(t(pc), t(q), block_size=1024)
+    old_fuse, old_min = G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS
+    try:
+        G.FUSE_MIN_HEAD_CHANNELS = 8                # fuse every level the shapes allow, also the narrow last head
+        G.FUSE_UP_PREDICT = True
+        rec_f = n(model.decompress(coordinates=coords, strings=streams, shape=shapes, k=ks, q_vals=qs))
+        G.FUSE_UP_PREDICT = False
+        rec_u = n(model.decompress(coordinates=coords, strings=streams, shape=shapes, k=ks, q_vals=qs))
+    finally:
+        G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS = old_fuse, old_min
+    assert rec_f.shape == rec_u.shape == (pc.shape[0], 6)
+    assert np.array_equal(rec_f[:, :3], rec_u[:, :3])                             # same occupancy decisions
+    lv_f, lv_u = np.rint(rec_f[:, 3:] * 255).astype(int), np.rint(rec_u[:, 3:] * 255).astype(int)
+    assert np.abs(lv_f - lv_u).max() <= 1 and (lv_f != lv_u).mean() < 5e-3
+    y_keys = n(coords[0]._pcc_cset.keys)[:coords[0].shape[0]]
+    blk = dict(y_keys=y_keys, y_symbols=n(streams[0][0]), z_symbols=n(streams[0][1]), k=ks[0], q=q)
+    rec_o = codec.decompress(P, cfg, [blk])
+    assert np.array_equal(rec_f[:, :3], rec_o[:, :3])
+
+
 def test_multi_block_partition_matches_oracle():
     from unified_point_cloud_compression_amd import synth
     cfg = codec.small_config()

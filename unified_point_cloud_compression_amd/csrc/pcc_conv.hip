@@ -22,6 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr int LDS_LD = 36;   // floats per LDS tile row: 32 + 4 pad
 static constexpr int MAXK = 128;    // kernel offsets per segment (K <= 125)
+static constexpr int MAXK_T = 512;  // offsets of the input-stationary transposed conv (a flat GEMM: 7^3 composites fit)
 
 enum { MODE_CONV = 0, MODE_GDN = 1, MODE_IGDN = 2 };
 
@@ -1269,7 +1270,7 @@ extern "C" int64_t pcc_convt_packed_elems(int32_t K, int32_t cin, int32_t cout) 
 extern "C" int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
                                       void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  PCC_REQUIRE(W && packed && K >= 1 && K <= MAXK && cin >= 1 && cout >= 1, "pcc_convt_pack_weights: bad arguments");
+  PCC_REQUIRE(W && packed && K >= 1 && K <= MAXK_T && cin >= 1 && cout >= 1, "pcc_convt_pack_weights: bad arguments");
   PCC_REQUIRE(mfma_ok(cin, K * cout), "pcc_convt: unsupported shape cin=%d (needs 4, 8, 16 or a multiple of 32)", cin);
   const int64_t total = pcc_convt_packed_elems(K, cin, cout);
   k_pack_convt<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(W, K, cin, cout, K * cout, cout_pad_for(K * cout),
@@ -1376,6 +1377,7 @@ extern "C" int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, co
 struct GatherCsrArgs {
   const float* T; const float* bias; const int* first; const int* pair_ids;
   float* out; long long n_out; int cout, act; float slope; int lpr_log2;
+  const int* ex_nbr; const float* ex_bias; int ex_K;      // optional: + sum over the existing neighbours k of ex_bias[k]
 };
 
 template <int VEC>
@@ -1406,6 +1408,10 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
 #pragma unroll
       for (int u = 0; u < JB; ++u) thin_acc(acc, x[u]);     // fixed order: pair id ascending
     }
+    if (a.ex_nbr) {              // neighbour k of this row exists -> its constant contribution (fused affine layers)
+      for (int k = 0; k < a.ex_K; ++k)
+        if (a.ex_nbr[(long long)k * a.n_out + o] >= 0) thin_acc(acc, reinterpret_cast<const VT*>(a.ex_bias + (long long)k * a.cout)[cv]);
+    }
     VT b;
     thin_zero(b);
     if (a.bias) b = reinterpret_cast<const VT*>(a.bias)[cv];
@@ -1418,11 +1424,12 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
 extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                                  const float* bias, int32_t K, int32_t cout, const int32_t* first,
                                  const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
-                                 void* stream) {
+                                 const int32_t* ex_nbr, int32_t ex_K, const float* ex_bias, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0 || n_in <= 0) return PCC_OK;
   PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && out, "pcc_convt_fwd_csr: NULL array");
-  PCC_REQUIRE(K >= 1 && K <= MAXK && mfma_ok(cin, K * cout), "pcc_convt_fwd_csr: unsupported shape K=%d cin=%d cout=%d", K, cin, cout);
+  PCC_REQUIRE(K >= 1 && K <= MAXK_T && mfma_ok(cin, K * cout), "pcc_convt_fwd_csr: unsupported shape K=%d cin=%d cout=%d", K, cin, cout);
+  PCC_REQUIRE(!ex_nbr || (ex_bias && ex_K >= 1), "pcc_convt_fwd_csr: ex_nbr needs ex_bias and ex_K");
   PCC_REQUIRE(act >= 0 && act <= 2, "pcc_convt_fwd_csr: bad activation");
   PCC_REQUIRE(n_in * K < (1ll << 31) && n_out < (1ll << 31), "pcc_convt_fwd_csr: too many rows");
   ConvArgs a;
@@ -1439,7 +1446,7 @@ extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin
   }
   GatherCsrArgs g;
   g.T = T; g.bias = bias; g.first = first; g.pair_ids = pair_ids; g.out = out; g.n_out = n_out; g.cout = cout;
-  g.act = act; g.slope = slope;
+  g.act = act; g.slope = slope; g.ex_nbr = ex_nbr; g.ex_bias = ex_bias; g.ex_K = ex_K;
   const int vec = (cout % 4 == 0) ? 4 : 1;
   int l = 0;
   while ((1 << l) < cout / vec && l < 6) ++l;

@@ -704,7 +704,7 @@ extern "C" int pcc_coords_expand_grid(const int64_t* keys, int64_t n, int32_t ke
   return PCC_OK;
 }
 
-extern "C" size_t pcc_expand_grid_csr_ws_bytes(int64_t n_out) { return pcc_scan_ws_bytes(n_out) + 256; }
+extern "C" size_t pcc_expand_grid_csr_ws_bytes(int64_t n_out) { return pcc_scan_ws_bytes(n_out + 1) + 256; }
 
 // phase 2 (n_out known to the host): CSR pair lists of the transposed map: first[n_out+1], pair_ids[n_in*K]
 extern "C" int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
@@ -713,7 +713,8 @@ extern "C" int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out
                                           void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(out_keys && in_bits && in_rank && h_in && first && pair_ids && n_out > 0, "pcc_coords_expand_grid_csr: bad arguments");
-  PCC_REQUIRE(kernel_size == 2 || kernel_size == 3 || kernel_size == 5, "pcc_coords_expand_grid_csr: kernel_size %d unsupported", kernel_size);
+  PCC_REQUIRE(kernel_size == 2 || kernel_size == 3 || kernel_size == 5 || kernel_size == 7,
+              "pcc_coords_expand_grid_csr: kernel_size %d unsupported", kernel_size);
   const int K = kernel_size * kernel_size * kernel_size;
   PCC_REQUIRE(n_in * K < (1ll << 31), "pcc_coords_expand_grid_csr: too many pairs");
   if (ws_bytes < pcc_expand_grid_csr_ws_bytes(n_out)) { pcc_set_error("pcc_coords_expand_grid_csr: workspace too small"); return PCC_EWS; }
@@ -727,15 +728,49 @@ extern "C" int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out
   do {                                                                              \
     if (kernel_size == 2) k_expand_csr<2, FILL><<<g, 256, 0, s>>>(a);               \
     else if (kernel_size == 3) k_expand_csr<3, FILL><<<g, 256, 0, s>>>(a);          \
-    else k_expand_csr<5, FILL><<<g, 256, 0, s>>>(a);                                \
+    else if (kernel_size == 5) k_expand_csr<5, FILL><<<g, 256, 0, s>>>(a);          \
+    else k_expand_csr<7, FILL><<<g, 256, 0, s>>>(a);                                \
     PCC_LAUNCH_CHECK();                                                             \
   } while (0)
   PCC_EXPAND_CSR(false);
-  PCC_TRY(pcc_scan_exclusive_i32(first, first, n_out, ws, ws_bytes, s));
-  k_set_int<<<1, 1, 0, s>>>(first + n_out, (int)(n_in * K));
+  // out_keys need not be the full expansion (any subset of rows, or a wider kernel restricted to a given set), so the
+  // pair total is whatever the counts add up to: scan n_out + 1 entries
+  k_set_int<<<1, 1, 0, s>>>(first + n_out, 0);
   PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(first, first, n_out + 1, ws, ws_bytes, s));
   PCC_EXPAND_CSR(true);
 #undef PCC_EXPAND_CSR
+  return PCC_OK;
+}
+
+// conv-form kernel map (one segment, nbr[k][o] = input row or -1) from CSR pair lists: lets the pair-list convolution
+// evaluate a transposed conv on a SUBSET of its output rows (the rows that survive pruning) without the dense T
+__global__ void k_csr_to_nbr(const int* __restrict__ first, const int* __restrict__ pair_ids, long long n_out, int K,
+                             int* __restrict__ nbr) {
+  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  for (int t = first[o]; t < first[o + 1]; ++t) {
+    const int pid = pair_ids[t];
+    const int i = pid / K, k = pid - i * K;
+    nbr[(long long)k * n_out + o] = i;
+  }
+}
+
+extern "C" int pcc_map_from_csr(const int32_t* first, const int32_t* pair_ids, int64_t n_out, int32_t kernel_size,
+                                int32_t* hdr, int32_t* nbr, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(first && pair_ids && hdr && nbr && n_out > 0, "pcc_map_from_csr: bad arguments");
+  const int K = kernel_size * kernel_size * kernel_size;
+  PCC_REQUIRE(K >= 1 && K <= 192 && (int64_t)K * n_out < (1ll << 31), "pcc_map_from_csr: K=%d unsupported", K);
+  SegPlan plan;
+  memset(&plan, 0, sizeof(plan));
+  plan.K = K; plan.nseg = 1; plan.listed = 0; plan.k_count[0] = K; plan.koff_begin[0] = 0;
+  plan_order(plan, kernel_size);
+  k_write_hdr<<<1, 1, 0, s>>>(plan, nullptr, 0, n_out, hdr);
+  PCC_LAUNCH_CHECK();
+  PCC_CHECK_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)K * n_out * sizeof(int), s));
+  k_csr_to_nbr<<<(unsigned)pcc_cdiv(n_out, 256), 256, 0, s>>>(first, pair_ids, n_out, K, nbr);
+  PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
 

@@ -5,7 +5,12 @@ Module structure, attribute names and Sequential indices equal the reference's (
   * fuse ReLU into the first occupancy-head convolution's epilogue,
   * select the top-k rows with a radix select on the device and compact directly, instead of
     torch.topk + int64 flattening + torch.isin + MinkowskiPruning (`model/transforms.py:228-282`),
-  * obtain z / training target coordinates with the coordinate-only stride operator.
+  * obtain z / training target coordinates with the coordinate-only stride operator,
+  * (inference) evaluate an up-sampling block together with its occupancy head: the generative transposed convolution
+    and the head's first convolution are both affine, so head_conv(genT(x)) is ONE generative convolution from the
+    parents with the composite 7x7x7 kernel M[d] = sum_{off_k - off_j = d} W_k V_j -- 5-6x fewer FLOPs than convolving
+    all ~40 candidates per parent with the 128-channel up-sampled features; the up-sampled features themselves are then
+    computed only for the rows the top-k keeps (`SparseSynthesisTransform.FUSE_UP_PREDICT`).
 """
 import torch
 import torch.nn as nn
@@ -135,14 +140,82 @@ class SparseSynthesisTransform(nn.Module):
         keys, feats, n = S.prune(cs.keys, cs.n, f, mask, n_keep)
         return SparseTensor._from_canonical(S.CoordSet(keys, n, cs.ts, cs.bounds), feats)
 
+    # ---- up-sampling block + occupancy head as one composite generative convolution (inference) ------------
+    FUSE_UP_PREDICT = True
+    FUSE_MIN_HEAD_CHANNELS = 32      # narrower heads (predict_3: 32 -> 16) gain nothing: the per-pair buffer dominates
+
+    def _fused_weights(self, gen, c0):
+        """(packed composite kernel [343, Cin, Ch], neighbour-existence bias [27, Ch]) of head_conv0(genT(.)), cached per
+        parameter version.  Offsets: genT writes parent + off_k, the head reads row + off_j, so parent -> row
+        displacement is off_k - off_j, index (ix - jx + 2) per axis in the 7-wide composite."""
+        tag = tuple((p.data_ptr(), p._version) for p in (gen.kernel, gen.bias, c0.kernel)) + (S.WEIGHT_OFFSET_ORDER,)
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        hit = cache.get(id(gen))
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                W, V = gen.kernel.detach().double(), c0.kernel.detach().double()
+                pw, pv = S.weight_offset_perm(125, W.device), S.weight_offset_perm(27, V.device)
+                W = W if pw is None else W[pw]
+                V = V if pv is None else V[pv]
+                cin, cm, ch = W.shape[1], W.shape[2], V.shape[2]
+                W5, V3 = W.view(5, 5, 5, cin, cm), V.view(3, 3, 3, cm, ch)          # [z][y][x] (x fastest)
+                M = torch.zeros((7, 7, 7, cin, ch), dtype=torch.float64, device=W.device)
+                for jz in range(3):
+                    for jy in range(3):
+                        for jx in range(3):
+                            M[2 - jz:7 - jz, 2 - jy:7 - jy, 2 - jx:7 - jx] += W5 @ V3[jz, jy, jx]
+                Mf = torch.nn.Parameter(M.view(343, cin, ch).float(), requires_grad=False)
+                packed = S.PackedConv(transposed=True).get(Mf)
+                cb = (gen.bias.detach().double().reshape(1, cm) @ V.reshape(27 * cm, ch).view(27, cm, ch)).reshape(27, ch)
+                cache[id(gen)] = hit = (tag, packed, cb.float().contiguous())
+        return hit[1], hit[2]
+
+    def _can_fuse(self, up, head, x):
+        gen, c0, c2 = up[-1], head[0], head[2]
+        return (self.FUSE_UP_PREDICT and not torch.is_grad_enabled() and S.USE_GRID and S.USE_CSR and S.EXPAND_BY_GRID
+                and isinstance(gen, ME.MinkowskiGenerativeConvolutionTranspose) and gen.kernel_size == 5
+                and gen.stride == 2 and gen.bias is not None and c0.kernel_size == 3 and c0.stride == 1
+                and c0.out_channels >= self.FUSE_MIN_HEAD_CHANNELS and c0.out_channels % 4 == 0
+                and x._cset.n > 0 and x._cset.n * 343 < (1 << 31) and x._cset.grid() is not None)
+
+    def _up_predict_fused(self, up, head, x, k_lvl):
+        """Returns (x pruned to the top-k rows, prediction over all candidate rows, mask)."""
+        for m in list(up)[:-1]:
+            x = m(x)
+        gen, c0, c2 = up[-1], head[0], head[2]
+        cs_in = x._cset
+        ts_out = cs_in.ts // 2
+        feats = x._canonical_features()
+        out_set = cs_in.expand(5, ts_out, want_csr=False)
+        kmap3 = out_set.kernel_map(out_set, 3)
+        packedM, cb = self._fused_weights(gen, c0)
+        csr7 = cs_in.csr_for(out_set.keys, out_set.n, 7, ts_out)
+        h = S.convt_forward_csr(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, out_set.n,
+                                act=L.ACT_RELU, ex_map=kmap3, ex_bias=cb)
+        logit = c2._apply_conv(SparseTensor._from_canonical(out_set, h), out_set, kmap3)
+        pred = SparseTensor._from_canonical(out_set, logit)
+        mask, n_keep = self._topk_prediction(pred, k_lvl)
+        keys, _, n = S.prune(out_set.keys, out_set.n, None, mask, n_keep)
+        kept = S.CoordSet(keys, n, ts_out, out_set.bounds)
+        # the up-sampled features, for the kept rows only: transposed conv restricted to them, in pair-list form
+        m5 = S.map_from_csr(cs_in.csr_for(kept.keys, n, 5, ts_out), cs_in.n, n, 5)
+        if "_packed_conv" not in gen.__dict__:
+            gen.__dict__["_packed_conv"] = S.PackedConv(transposed=False)
+        xk = S.conv_forward(feats, gen._packed_conv.get(gen.kernel, state_dict_order=True), gen.bias, 125,
+                            gen.in_channels, gen.out_channels, m5, n)
+        return SparseTensor._from_canonical(kept, xk), pred, mask
+
     def forward(self, y, coords=None, k=None, trace=None):
         """y (stride 8) -> x (stride 1) features at the k-selected voxels (`model/transforms.py:170-225`)."""
-        x = self.up_1(y)
         predictions = []
-        for lvl, (up, head) in enumerate(((None, self.predict_1), (self.up_2, self.predict_2),
+        x = y
+        for lvl, (up, head) in enumerate(((self.up_1, self.predict_1), (self.up_2, self.predict_2),
                                           (self.up_3, self.predict_3))):
-            if up is not None:
-                x = up(x)
+            if coords is None and trace is None and self._can_fuse(up, head, x if lvl else y):
+                x, pred, _ = self._up_predict_fused(up, head, x, k[lvl])
+                predictions.append(pred)
+                continue
+            x = up(x)
             pred = self._predict(head, x)
             mask, n_keep = self._topk_prediction(pred, k[lvl])
             if trace is not None:

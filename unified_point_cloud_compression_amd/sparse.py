@@ -177,10 +177,29 @@ class CoordSet:
             self._derived[key] = CoordSet(out[:n].clone() if n < self.n // 2 else out, n, new_stride, nb)
         return self._derived[key]
 
-    def expand(self, ksize, ts_out):
-        """Output set of a generative transposed conv (a3-i): unique{c + off_k*ts_out}.  When the output lattice has
-        at most 2^32 cells the same sort also yields the transposed map in CSR form (`csr_map`)."""
+    def csr_for(self, out_keys, n_out, ksize, ts_out):
+        """CSR pair lists (first[n_out+1], pair_ids) of the transposed conv from this set onto the GIVEN output rows
+        (any canonical subset of the lattice at pitch ts_out), built by probing this set's grid index."""
+        g = self.grid()
+        if not g:
+            raise L.PccError("csr_for needs the grid index of the input set")
+        dev = self.device
+        K = ksize ** 3
+        first = torch.empty(n_out + 1, dtype=torch.int32, device=dev)
+        pair_ids = torch.empty(max(self.n * K, 1), dtype=torch.int32, device=dev)
+        ws = L.workspace(L.load().pcc_expand_grid_csr_ws_bytes(n_out), dev)
+        L.call("pcc_coords_expand_grid_csr", L.ptr(out_keys), n_out, ksize, ts_out, L.ptr(g[0]), L.ptr(g[1]), g[2],
+               self.n, L.ptr(first), L.ptr(pair_ids), L.ptr(ws), ws.numel(), L.stream())
+        return first, pair_ids
+
+    def expand(self, ksize, ts_out, want_csr=True):
+        """Output set of a generative transposed conv (a3-i): unique{c + off_k*ts_out}, plus (want_csr) the transposed
+        map in CSR form (`csr_map`)."""
         key = ("expand", ksize, ts_out)
+        if key in self._derived and want_csr and USE_CSR and ("csr", ksize, ts_out) not in self._derived \
+                and self._derived[key]._grid and self.grid():
+            cs = self._derived[key]                       # the set was built without its pair lists: add them
+            self._derived[("csr", ksize, ts_out)] = self.csr_for(cs.keys, cs.n, ksize, ts_out)
         if key not in self._derived:
             dev = self.device
             K = ksize ** 3
@@ -203,15 +222,11 @@ class CoordSet:
                 L.call("pcc_coords_expand_grid", L.ptr(self.keys), self.n, ksize, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
                        L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
                 n = int(cnt.item())
-                first = torch.empty(n + 1, dtype=torch.int32, device=dev)
-                pair_ids = torch.empty(m, dtype=torch.int32, device=dev)
-                ws = L.workspace(lib.pcc_expand_grid_csr_ws_bytes(n), dev)
-                L.call("pcc_coords_expand_grid_csr", L.ptr(out), n, ksize, ts_out, L.ptr(g_in[0]), L.ptr(g_in[1]), g_in[2],
-                       self.n, L.ptr(first), L.ptr(pair_ids), L.ptr(ws), ws.numel(), L.stream())
                 cs = CoordSet(out[:n].clone() if n < out.numel() // 2 else out, n, ts_out, ob)
                 cs._grid = (bits, rank, h)
                 self._derived[key] = cs
-                self._derived[("csr", ksize, ts_out)] = (first, pair_ids)
+                if want_csr:
+                    self._derived[("csr", ksize, ts_out)] = self.csr_for(cs.keys, n, ksize, ts_out)
                 return cs
             if USE_CSR and self.n > 0 and cells <= 0xFFFFFFFF and self.n * K < (1 << 31):
                 m = self.n * K
@@ -460,8 +475,11 @@ def convt_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NO
     return out
 
 
-def convt_forward_csr(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT_NONE, slope=0.01):
-    """Generative transposed conv (a3) with the CSR pair lists produced by the coordinate expansion."""
+def convt_forward_csr(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT_NONE, slope=0.01, ex_map=None,
+                      ex_bias=None):
+    """Generative transposed conv (a3) with the CSR pair lists produced by the coordinate expansion.
+    ex_map / ex_bias: a conv map of the output set and a [K2, cout] table; row o additionally receives ex_bias[k] for
+    every neighbour k it has (the constant part of two fused affine layers)."""
     feats = feats.contiguous()
     n_in = feats.shape[0]
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
@@ -470,9 +488,27 @@ def convt_forward_csr(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT
     first, pair_ids = csr
     T = torch.empty(n_in * K * cout, dtype=torch.float32, device=feats.device)
     b = bias.detach().reshape(-1).contiguous() if bias is not None else None
+    eb = ex_bias.detach().to(torch.float32).contiguous() if ex_map is not None else None
     L.call("pcc_convt_fwd_csr", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first),
-           L.ptr(pair_ids), n_out, L.ptr(T), L.ptr(out), act, float(slope), L.stream())
+           L.ptr(pair_ids), n_out, L.ptr(T), L.ptr(out), act, float(slope),
+           L.ptr(ex_map.nbr) if ex_map is not None else None, ex_map.K if ex_map is not None else 0, L.ptr(eb), L.stream())
     return out
+
+
+def map_from_csr(csr, n_in, n_out, ksize):
+    """Conv-form KernelMap (nbr[k][o] = input row) of a transposed conv restricted to `n_out` output rows, from their
+    CSR pair lists: conv_forward then evaluates it (pair-list form when sparse) without the dense per-pair buffer."""
+    first, pair_ids = csr
+    dev = first.device
+    K = ksize ** 3
+    m = KernelMap()
+    m.n_in, m.n_out, m.K, m.ksize, m.transposed = n_in, n_out, K, ksize, False
+    m._pairs, m.d_pairs, m.rows = None, None, None
+    m.hdr = torch.empty(L.MAP_HDR_INTS, dtype=torch.int32, device=dev)
+    m.nbr = torch.empty(max(K * n_out, 1), dtype=torch.int32, device=dev)
+    if n_out:
+        L.call("pcc_map_from_csr", L.ptr(first), L.ptr(pair_ids), n_out, ksize, L.ptr(m.hdr), L.ptr(m.nbr), L.stream())
+    return m
 
 
 def conv_wgrad(feats_in, grad_out, K, cin, cout, kmap):

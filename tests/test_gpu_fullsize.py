@@ -59,7 +59,15 @@ def test_fullsize_roundtrip_properties(frame):
     streams2, *_ = model.compress(pc, q, block_size=1024)
     assert torch.equal(streams2[0][0], y_sym) and torch.equal(streams2[0][1], z_sym)
     rec2 = model.decompress(coordinates=coords, strings=streams, shape=shapes, k=ks, q_vals=qs)
-    assert torch.equal(rec, rec2)
+    rec3 = model.decompress(coordinates=coords, strings=streams, shape=shapes, k=ks, q_vals=qs)
+    assert torch.equal(rec2, rec3)
+    # `rec` came through the layer-by-layer path (trace), rec2 through the composite up+head convolution: the same
+    # function up to fp32 rounding, so only candidates whose logit sits within float noise of the k-th may swap
+    from unified_point_cloud_compression_amd import metrics
+    assert rec2.shape == rec.shape
+    d2, _ = metrics.nearest(rec2[:, :3].int(), metrics._canonical(rec[:, :3])[0])
+    moved = int((d2 > 0).sum().item())
+    assert moved <= max(50, n0 // 2000), f"{moved} of {n0} decoded voxels differ between the two evaluation orders"
 
 
 def test_fullsize_generative_map_is_complete(frame):

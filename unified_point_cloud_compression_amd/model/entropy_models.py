@@ -129,6 +129,19 @@ class MeanScaleHyperprior(CompressionModel):
         return scale.to(torch.float32).contiguous(), rescale.to(torch.float32).contiguous()
 
     def _gaussian_params(self, z_hat, y_cset):
+        if not torch.is_grad_enabled() and S.USE_GRID:
+            # the last h_s layer is only ever read at y's coordinates (`features_at_coordinates`, a6): evaluate the
+            # 3x3x3 convolution for those rows alone (13 k of the 56 k octree children) instead of everywhere + gather
+            x = self._conv_act(self.h_s[0], z_hat, L.ACT_LEAKY)
+            x = self._conv_act(self.h_s[2], x, L.ACT_LEAKY)
+            last, cs = self.h_s[4], x._cset
+            if last.kernel_size == 3 and last.stride == 1 and cs.ts == y_cset.ts and y_cset.n > 0:
+                kmap = cs.kernel_map(y_cset, 3)
+                f = last._apply_conv(x, y_cset, kmap)
+                centre = kmap.nbr[13 * y_cset.n:14 * y_cset.n]        # offset (0,0,0): is the row itself in the set?
+                return torch.where((centre >= 0).unsqueeze(1), f, f.new_zeros(1))      # absent coordinate -> zeros
+            g = self._conv_act(last, x, L.ACT_NONE)
+            return S.lookup_gather(g._cset, g._canonical_features(), y_cset.keys, y_cset.n)
         g = self.hyper_synthesis(z_hat)
         gf = g._canonical_features()
         if torch.is_grad_enabled() and gf.requires_grad:       # training: differentiable row gather

@@ -85,12 +85,19 @@ def account_flops(model, pc, q):
         calls.append((int(csr[0][n_out].item()), K, cin, cout, n_out, feats.shape[0]))  # pairs of the map (full expansion: n_in*K)
         return orig_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope, **kw)
 
-    S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr = True, spy, spy_t, spy_c
+    orig_r = S.convt_forward_rows
+
+    def spy_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
+        calls.append((int(csr[0][n_out].item()), K, cin, cout, n_out, feats.shape[0]))
+        return orig_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope)
+
+    S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr, S.convt_forward_rows = True, spy, spy_t, spy_c, spy_r
     try:
         step(model, pc, q)
         torch.cuda.synchronize()
     finally:
-        S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr = False, orig, orig_t, orig_c
+        S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr, S.convt_forward_rows = (
+            False, orig, orig_t, orig_c, orig_r)
     flops, launches, pairs_total, alg_bytes = 0.0, 0, 0, 0.0
     for kmap, K, cin, cout, n_out, n_in in calls:
         if not mfma_shape(cin, cout):

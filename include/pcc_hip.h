@@ -154,6 +154,15 @@ int pcc_keys_canonicalize_grid(const int64_t* keys, int64_t n, const int32_t* h_
  *                                identical to pcc_coords_expand_csr's. */
 int pcc_coords_expand_grid(const int64_t* keys, int64_t n, int32_t kernel_size, const int32_t* h_out, uint64_t* bits,
                            int32_t* rank, int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes, void* stream);
+/* Transposed convolution on a SUBSET of its output rows (the rows kept by the top-k pruning), straight from their CSR
+ * pair lists (pcc_coords_expand_grid_csr on those rows): pairs bucketed by offset, gathered pair GEMM, sum in CSR order.
+ * packed_w: pcc_conv_pack_weights layout.  pairs = host value of first[n_out].  T: pcc_convt_rows_t_elems floats. */
+size_t pcc_convt_rows_int_ws_bytes(int64_t pairs, int32_t K);
+int64_t pcc_convt_rows_t_elems(int64_t pairs, int32_t K, int32_t cout);
+int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias,
+                       int32_t K, int32_t cout, const int32_t* first, const int32_t* pair_ids, int64_t n_out,
+                       int64_t pairs, float* T, float* out, int32_t act, float slope, void* int_ws, size_t int_ws_bytes,
+                       void* stream);
 /* conv-form map (one segment, nbr[k*n_out + o] = input row or -1) from CSR pair lists: evaluates a transposed conv on a
  * subset of its output rows with pcc_conv_fwd / pcc_conv_fwd_pairs.  hdr: PCC_MAP_HDR_INTS ints, nbr: K*n_out ints. */
 int pcc_map_from_csr(const int32_t* first, const int32_t* pair_ids, int64_t n_out, int32_t kernel_size, int32_t* hdr,

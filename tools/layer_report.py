@@ -52,7 +52,19 @@ def spy_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01, **
     return out
 
 
-S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr = True, spy, spy_t, spy_c
+orig_r = S.convt_forward_rows
+
+
+def spy_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = orig_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope)
+    e1.record()
+    calls.append((int(csr[0][n_out].item()), -K, cin, cout, feats.shape[0], n_out, e0, e1))
+    return out
+
+
+S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr, S.convt_forward_rows = True, spy, spy_t, spy_c, spy_r
 bench.step(model, pc, q)
 torch.cuda.synchronize()
 tot_ms = tot_fl = 0

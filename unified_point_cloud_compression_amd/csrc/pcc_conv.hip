@@ -1237,6 +1237,187 @@ extern "C" int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t ci
 }
 
 // ------------------------------------------------------------------------------------------
+// Transposed convolution on a SUBSET of its output rows (the rows that survive the top-k pruning), straight from their
+// CSR pair lists: the P pairs are bucketed by kernel offset (LDS counting sort; the position inside a bucket does not
+// matter, every T row depends on its own pair only), T[p] = feat[in(p)] @ W[k(p)] runs as the gathered pair GEMM, and
+// out[o] = act(bias + sum over the row's CSR entries of T[slot(entry)]) is summed in CSR order.  Work ~ P, where the
+// dense input-stationary form computes all n_in*K products and the slot-map form touches K*n_out slots.
+// ------------------------------------------------------------------------------------------
+static constexpr int CK_T = 256, CK_I = 8, CK_B = CK_T * CK_I;
+
+__global__ void __launch_bounds__(CK_T) k_csr_khist(const int* __restrict__ pair_ids, const int* __restrict__ d_P, int K,
+                                                    int nb, int* __restrict__ hist) {
+  __shared__ int h[MAXK];
+  for (int i = threadIdx.x; i < K; i += CK_T) h[i] = 0;
+  __syncthreads();
+  const int P = *d_P;
+  const long long base = (long long)blockIdx.x * CK_B;
+#pragma unroll
+  for (int r = 0; r < CK_I; ++r) {
+    const long long t = base + r * CK_T + threadIdx.x;
+    if (t < P) atomicAdd(&h[pair_ids[t] % K], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K; i += CK_T) hist[(long long)i * nb + blockIdx.x] = h[i];
+}
+
+__global__ void k_csr_kstarts(const int* __restrict__ off, const int* __restrict__ d_P, int K, int nb,
+                              int* __restrict__ pstart, long long* __restrict__ info) {
+  if (threadIdx.x != 0) return;
+  const long long total = *d_P;
+  long long run = 0;
+  for (int k = 0; k < K; ++k) {
+    const long long b = off[(long long)k * nb];
+    const long long e = (k + 1 < K) ? off[(long long)(k + 1) * nb] : total;
+    pstart[k] = (int)run;
+    run += (e - b + PAIR_BM - 1) / PAIR_BM * PAIR_BM;
+  }
+  pstart[K] = (int)run;
+  info[0] = run; info[1] = run / PAIR_BM; info[2] = total;
+}
+
+__global__ void __launch_bounds__(CK_T) k_csr_kscatter(const int* __restrict__ pair_ids, const int* __restrict__ d_P, int K,
+                                                       int nb, const int* __restrict__ off, const int* __restrict__ pstart,
+                                                       int* __restrict__ pair_in, int* __restrict__ slot) {
+  __shared__ int cur[MAXK];
+  for (int i = threadIdx.x; i < K; i += CK_T)
+    cur[i] = pstart[i] + off[(long long)i * nb + blockIdx.x] - off[(long long)i * nb];
+  __syncthreads();
+  const int P = *d_P;
+  const long long base = (long long)blockIdx.x * CK_B;
+#pragma unroll
+  for (int r = 0; r < CK_I; ++r) {
+    const long long t = base + r * CK_T + threadIdx.x;
+    if (t < P) {
+      const int pid = pair_ids[t];
+      const int i = pid / K, k = pid - i * K;
+      const int pos = atomicAdd(&cur[k], 1);
+      pair_in[pos] = i;
+      slot[t] = pos;
+    }
+  }
+}
+
+struct CsrReduceArgs {
+  const float* T; const float* bias; const int* first; const int* slot; float* out; long long n_out;
+  int cout, act; float slope; int lpr_log2;
+};
+
+__global__ void __launch_bounds__(256) k_csr_reduce(CsrReduceArgs a) {
+  constexpr int JB = 4;
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << a.lpr_log2;
+  const int rpw = 64 >> a.lpr_log2;
+  const long long o = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> a.lpr_log2);
+  const int cl = lane & (lpr - 1);
+  if (o >= a.n_out) return;
+  const int cvec = a.cout / 4;
+  const int t0 = a.first[o], t1 = a.first[o + 1];
+  for (int cv = cl; cv < cvec; cv += lpr) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = t0; t < t1; t += JB) {
+      int sl[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) sl[u] = (t + u < t1) ? a.slot[t + u] : -1;
+      float4 x[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) {
+        x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sl[u] >= 0) x[u] = reinterpret_cast<const float4*>(a.T + (long long)sl[u] * a.cout)[cv];
+      }
+#pragma unroll
+      for (int u = 0; u < JB; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+    }
+    if (a.bias) {
+      const float4 b = reinterpret_cast<const float4*>(a.bias)[cv];
+      acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    acc.x = act1(acc.x, a.act, a.slope); acc.y = act1(acc.y, a.act, a.slope);
+    acc.z = act1(acc.z, a.act, a.slope); acc.w = act1(acc.w, a.act, a.slope);
+    reinterpret_cast<float4*>(a.out + o * a.cout)[cv] = acc;
+  }
+}
+
+// pairs: host value of first[n_out] (the number of CSR entries).  Scratch: int_ws and T sized by the two queries.
+extern "C" size_t pcc_convt_rows_int_ws_bytes(int64_t pairs, int32_t K) {
+  const int64_t nb = pcc_cdiv(pairs > 0 ? pairs : 1, CK_B);
+  const int64_t padded = pairs + (int64_t)K * PAIR_BM;
+  return pcc_align_up((size_t)K * nb * 4) + pcc_align_up((size_t)padded * 4) + pcc_align_up((size_t)(pairs + 1) * 4) +
+         pcc_align_up((size_t)(padded / PAIR_BM + 1) * 4) + pcc_align_up((size_t)(K + 1) * 4) + 64 +
+         pcc_scan_ws_bytes((int64_t)K * nb) + 1024;
+}
+extern "C" int64_t pcc_convt_rows_t_elems(int64_t pairs, int32_t K, int32_t cout) {
+  return (pairs + (int64_t)K * PAIR_BM) * cout;
+}
+
+extern "C" int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                                  const float* bias, int32_t K, int32_t cout, const int32_t* first,
+                                  const int32_t* pair_ids, int64_t n_out, int64_t pairs, float* T, float* out,
+                                  int32_t act, float slope, void* int_ws, size_t int_ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out <= 0) return PCC_OK;
+  PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && out && int_ws, "pcc_convt_fwd_rows: NULL array");
+  PCC_REQUIRE(K >= 1 && K <= MAXK && conv_kind(K, cin, cout) == KIND_MFMA && cout % 4 == 0,
+              "pcc_convt_fwd_rows: shape K=%d cin=%d cout=%d not on the MFMA path", K, cin, cout);
+  PCC_REQUIRE(pairs >= 0 && pairs + (int64_t)K * PAIR_BM < (1ll << 31) && act >= 0 && act <= 2, "pcc_convt_fwd_rows: bad arguments");
+  if (int_ws_bytes < pcc_convt_rows_int_ws_bytes(pairs, K)) { pcc_set_error("pcc_convt_fwd_rows: workspace too small"); return PCC_EWS; }
+  const int64_t nb = pcc_cdiv(pairs > 0 ? pairs : 1, CK_B);
+  const int64_t padded_cap = pairs + (int64_t)K * PAIR_BM;
+  char* p = (char*)int_ws;
+  int* hist = (int*)p;        p += pcc_align_up((size_t)K * nb * 4);
+  int* pair_in = (int*)p;     p += pcc_align_up((size_t)padded_cap * 4);
+  int* slot = (int*)p;        p += pcc_align_up((size_t)(pairs + 1) * 4);
+  int* tile_k = (int*)p;      p += pcc_align_up((size_t)(padded_cap / PAIR_BM + 1) * 4);
+  int* pstart = (int*)p;      p += pcc_align_up((size_t)(K + 1) * 4);
+  long long* info = (long long*)p;  p += 64;
+  void* scan_ws = p;
+  const size_t scan_bytes = int_ws_bytes - (size_t)(p - (char*)int_ws);
+  const int* d_P = first + n_out;
+  k_csr_khist<<<(unsigned)nb, CK_T, 0, s>>>(pair_ids, d_P, K, (int)nb, hist);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(hist, hist, (int64_t)K * nb, scan_ws, scan_bytes, s));
+  k_csr_kstarts<<<1, 64, 0, s>>>(hist, d_P, K, (int)nb, pstart, info);
+  PCC_LAUNCH_CHECK();
+  PCC_CHECK_HIP(hipMemsetAsync(pair_in, 0xFF, (size_t)padded_cap * 4, s));
+  k_csr_kscatter<<<(unsigned)nb, CK_T, 0, s>>>(pair_ids, d_P, K, (int)nb, hist, pstart, pair_in, slot);
+  PCC_LAUNCH_CHECK();
+  const int64_t tiles_cap = padded_cap / PAIR_BM;
+  k_pair_tile_k<<<(unsigned)pcc_cdiv(tiles_cap, 256), 256, 0, s>>>(pstart, K, tiles_cap, tile_k);
+  PCC_LAUNCH_CHECK();
+  {
+    ConvArgs a;
+    a.feat = feat_in; a.wp = packed_w; a.bias = nullptr; a.hdr = nullptr; a.nbr = nullptr; a.rows = nullptr; a.out = T;
+    a.n_out = padded_cap; a.cin = cin; a.cout = cout; a.cout_pad = cout_pad_for(cout);
+    a.n_in = n_in; a.wp_elems = (long long)K * cin * a.cout_pad;
+    a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
+    a.pair_in = pair_in; a.tile_k = tile_k; a.n_tiles = info + 1;
+    hipEvent_t e0, e1;
+    if (g_prof_on) PCC_TRY(prof_event(&e0, s));
+    const int bn = bn_for(cout);
+    const long long gy = a.cout_pad / bn;
+    const dim3 grid((unsigned)((tiles_cap * gy + 7) / 8 * 8));
+    const bool buf = g_mfma_buf && n_in * cin * 4 <= BUF_MAX_BYTES && a.wp_elems * 4 <= BUF_MAX_BYTES;
+    if (bn == 128) { if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    else if (bn == 64) { if (buf) k_conv_mfma<2, 2, 2, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    else { if (buf) k_conv_mfma<4, 1, 1, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<4, 1, 1, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    PCC_LAUNCH_CHECK();
+    if (g_prof_on) {
+      PCC_TRY(prof_event(&e1, s));
+      ++g_launches;
+    }
+  }
+  CsrReduceArgs r;
+  r.T = T; r.bias = bias; r.first = first; r.slot = slot; r.out = out; r.n_out = n_out; r.cout = cout; r.act = act; r.slope = slope;
+  int l = 0;
+  while ((1 << l) < cout / 4 && l < 6) ++l;
+  r.lpr_log2 = l;
+  const int64_t waves = pcc_cdiv(n_out, 64 >> l);
+  k_csr_reduce<<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(r);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Generative transposed convolution, input stationary.
 //   Every (input row i, kernel offset k) is exactly one pair of the map, so the products
 //   T[i][k][:] = feat[i] @ W[k] form ONE dense GEMM  [n_in, cin] x [cin, K*cout]  with no gather and no padding

@@ -60,6 +60,10 @@ SIGNATURES = {
     "pcc_convt_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _f32, _p]),
     "pcc_convt_fwd_csr": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p, _i32, _p,
                                     _p]),
+    "pcc_convt_rows_int_ws_bytes": (_sz, [_i64, _i32]),
+    "pcc_convt_rows_t_elems": (_i64, [_i64, _i32, _i32]),
+    "pcc_convt_fwd_rows": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _i64, _p, _p, _i32, _f32, _p, _sz,
+                                     _p]),
     "pcc_map_from_csr": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "pcc_conv_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "pcc_conv_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),

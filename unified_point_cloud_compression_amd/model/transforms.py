@@ -198,11 +198,15 @@ class SparseSynthesisTransform(nn.Module):
         keys, _, n = S.prune(out_set.keys, out_set.n, None, mask, n_keep)
         kept = S.CoordSet(keys, n, ts_out, out_set.bounds)
         # the up-sampled features, for the kept rows only: transposed conv restricted to them, in pair-list form
-        m5 = S.map_from_csr(cs_in.csr_for(kept.keys, n, 5, ts_out), cs_in.n, n, 5)
         if "_packed_conv" not in gen.__dict__:
             gen.__dict__["_packed_conv"] = S.PackedConv(transposed=False)
-        xk = S.conv_forward(feats, gen._packed_conv.get(gen.kernel, state_dict_order=True), gen.bias, 125,
-                            gen.in_channels, gen.out_channels, m5, n)
+        packed = gen._packed_conv.get(gen.kernel, state_dict_order=True)
+        csr5 = cs_in.csr_for(kept.keys, n, 5, ts_out)
+        if L.load().pcc_conv_pairs_supported(125, gen.in_channels, gen.out_channels):
+            xk = S.convt_forward_rows(feats, packed, gen.bias, 125, gen.in_channels, gen.out_channels, csr5, n)
+        else:       # narrow shapes: slot map of the kept rows + the generic convolution
+            xk = S.conv_forward(feats, packed, gen.bias, 125, gen.in_channels, gen.out_channels,
+                                S.map_from_csr(csr5, cs_in.n, n, 5), n)
         return SparseTensor._from_canonical(kept, xk), pred, mask
 
     def forward(self, y, coords=None, k=None, trace=None):

@@ -495,6 +495,23 @@ def convt_forward_csr(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT
     return out
 
 
+def convt_forward_rows(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT_NONE, slope=0.01):
+    """Transposed conv evaluated for the `n_out` output rows whose CSR pair lists are given (work ~ their pairs)."""
+    feats = feats.contiguous()
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    if n_out == 0:
+        return out
+    first, pair_ids = csr
+    lib = L.load()
+    pairs = int(first[n_out].item())
+    T = torch.empty(max(lib.pcc_convt_rows_t_elems(pairs, K, cout), 1), dtype=torch.float32, device=feats.device)
+    ws = L.workspace(lib.pcc_convt_rows_int_ws_bytes(pairs, K), feats.device)
+    b = bias.detach().reshape(-1).contiguous() if bias is not None else None
+    L.call("pcc_convt_fwd_rows", L.ptr(feats), feats.shape[0], cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first),
+           L.ptr(pair_ids), n_out, pairs, L.ptr(T), L.ptr(out), act, float(slope), L.ptr(ws), ws.numel(), L.stream())
+    return out
+
+
 def map_from_csr(csr, n_in, n_out, ksize):
     """Conv-form KernelMap (nbr[k][o] = input row) of a transposed conv restricted to `n_out` output rows, from their
     CSR pair lists: conv_forward then evaluates it (pair-list form when sparse) without the dense per-pair buffer."""

@@ -163,6 +163,30 @@ def test_fused_up_predict_matches_layerwise(which):
     assert np.array_equal(rec_f[:, :3], rec_o[:, :3])
 
 
+def test_fused_path_edge_counts():
+    """k = 0 at a level (nothing kept) and k larger than the candidate set (everything kept) through the composite
+    up+head path: same result as the layer-wise path."""
+    from unified_point_cloud_compression_amd import synth
+    from unified_point_cloud_compression_amd.model.transforms import SparseSynthesisTransform as G
+    cfg = codec.small_config()
+    model = _model(cfg, codec.random_params(cfg, 2, gain=4.0))
+    pc = synth.random_block(2, 24, 0.1)
+    q = np.array([[0.5, 0.5]], dtype=np.float32)
+    streams, shapes, ks, coords, qs = model.compress(t(pc), t(q), block_size=1024)
+    old_fuse, old_min = G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS
+    try:
+        G.FUSE_MIN_HEAD_CHANNELS = 8
+        for k_alt in ([[10 ** 9], [10 ** 9], ks[0][2]], [ks[0][0], [0], [0]]):
+            out = {}
+            for fuse in (True, False):
+                G.FUSE_UP_PREDICT = fuse
+                out[fuse] = n(model.decompress(coordinates=coords, strings=streams, shape=shapes, k=[k_alt], q_vals=qs))
+            assert out[True].shape == out[False].shape
+            assert np.array_equal(out[True][:, :3], out[False][:, :3])
+    finally:
+        G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS = old_fuse, old_min
+
+
 def test_multi_block_partition_matches_oracle():
     from unified_point_cloud_compression_amd import synth
     cfg = codec.small_config()

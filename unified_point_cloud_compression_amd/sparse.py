@@ -185,6 +185,8 @@ class CoordSet:
             raise L.PccError("csr_for needs the grid index of the input set")
         dev = self.device
         K = ksize ** 3
+        if n_out == 0:
+            return torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev)
         first = torch.empty(n_out + 1, dtype=torch.int32, device=dev)
         pair_ids = torch.empty(max(self.n * K, 1), dtype=torch.int32, device=dev)
         ws = L.workspace(L.load().pcc_expand_grid_csr_ws_bytes(n_out), dev)

@@ -1067,17 +1067,22 @@ __global__ void k_pair_flags(const int* __restrict__ nbr, long long n, int* __re
 }
 
 // one block: padded start of every offset's pair range; info = {padded pairs, tiles, pairs}
-__global__ void k_pair_starts(const int* __restrict__ g, const int* __restrict__ nbr, long long n_out, int K,
-                              int* __restrict__ pstart /*[K+1]*/, long long* __restrict__ info) {
-  if (threadIdx.x != 0) return;
+__global__ void __launch_bounds__(128) k_pair_starts(const int* __restrict__ g, const int* __restrict__ nbr, long long n_out, int K,
+                                                     int* __restrict__ pstart /*[K+1]*/, long long* __restrict__ info) {
+  __shared__ long long cnt[MAXK];
   const long long n = n_out * K;
   const long long total = (long long)g[n - 1] + (nbr[n - 1] >= 0 ? 1 : 0);
-  long long run = 0;
-  for (int k = 0; k < K; ++k) {
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {         // the 2K boundary reads in parallel, then a short serial prefix
     const long long b = g[(long long)k * n_out];
     const long long e = (k + 1 < K) ? g[(long long)(k + 1) * n_out] : total;
+    cnt[k] = e - b;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  long long run = 0;
+  for (int k = 0; k < K; ++k) {
     pstart[k] = (int)run;
-    run += (e - b + PAIR_BM - 1) / PAIR_BM * PAIR_BM;
+    run += (cnt[k] + PAIR_BM - 1) / PAIR_BM * PAIR_BM;
   }
   pstart[K] = (int)run;
   info[0] = run; info[1] = run / PAIR_BM; info[2] = total;
@@ -1130,7 +1135,7 @@ extern "C" int pcc_pair_plan_rank(const int32_t* nbr, int64_t n_out, int32_t K, 
   k_pair_flags<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(nbr, n, f);
   PCC_LAUNCH_CHECK();
   PCC_TRY(pcc_scan_exclusive_i32(f, g, n, p, ws_bytes - (size_t)(p - (char*)ws), s));
-  k_pair_starts<<<1, 64, 0, s>>>(g, nbr, n_out, K, pstart, (long long*)info);
+  k_pair_starts<<<1, 128, 0, s>>>(g, nbr, n_out, K, pstart, (long long*)info);
   PCC_LAUNCH_CHECK();
   k_pair_pos<<<dim3((unsigned)pcc_cdiv(n_out, 256), (unsigned)K), 256, 0, s>>>(nbr, g, pstart, n_out, K, pos);
   PCC_LAUNCH_CHECK();
@@ -1261,16 +1266,21 @@ __global__ void __launch_bounds__(CK_T) k_csr_khist(const int* __restrict__ pair
   for (int i = threadIdx.x; i < K; i += CK_T) hist[(long long)i * nb + blockIdx.x] = h[i];
 }
 
-__global__ void k_csr_kstarts(const int* __restrict__ off, const int* __restrict__ d_P, int K, int nb,
-                              int* __restrict__ pstart, long long* __restrict__ info) {
-  if (threadIdx.x != 0) return;
+__global__ void __launch_bounds__(128) k_csr_kstarts(const int* __restrict__ off, const int* __restrict__ d_P, int K, int nb,
+                                                     int* __restrict__ pstart, long long* __restrict__ info) {
+  __shared__ long long cnt[MAXK];
   const long long total = *d_P;
-  long long run = 0;
-  for (int k = 0; k < K; ++k) {
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
     const long long b = off[(long long)k * nb];
     const long long e = (k + 1 < K) ? off[(long long)(k + 1) * nb] : total;
+    cnt[k] = e - b;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  long long run = 0;
+  for (int k = 0; k < K; ++k) {
     pstart[k] = (int)run;
-    run += (e - b + PAIR_BM - 1) / PAIR_BM * PAIR_BM;
+    run += (cnt[k] + PAIR_BM - 1) / PAIR_BM * PAIR_BM;
   }
   pstart[K] = (int)run;
   info[0] = run; info[1] = run / PAIR_BM; info[2] = total;
@@ -1376,7 +1386,7 @@ extern "C" int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t ci
   k_csr_khist<<<(unsigned)nb, CK_T, 0, s>>>(pair_ids, d_P, K, (int)nb, hist);
   PCC_LAUNCH_CHECK();
   PCC_TRY(pcc_scan_exclusive_i32(hist, hist, (int64_t)K * nb, scan_ws, scan_bytes, s));
-  k_csr_kstarts<<<1, 64, 0, s>>>(hist, d_P, K, (int)nb, pstart, info);
+  k_csr_kstarts<<<1, 128, 0, s>>>(hist, d_P, K, (int)nb, pstart, info);
   PCC_LAUNCH_CHECK();
   PCC_CHECK_HIP(hipMemsetAsync(pair_in, 0xFF, (size_t)padded_cap * 4, s));
   k_csr_kscatter<<<(unsigned)nb, CK_T, 0, s>>>(pair_ids, d_P, K, (int)nb, hist, pstart, pair_in, slot);

@@ -1574,7 +1574,7 @@ struct GatherCsrArgs {
 template <int VEC>
 __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
   typedef typename ThinVec<VEC>::T VT;
-  constexpr int JB = 4;
+  constexpr int JB = 8;
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << a.lpr_log2;
   const int rpw = 64 >> a.lpr_log2;

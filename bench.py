@@ -174,12 +174,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.time()
     t_enc = 0.0
+    step_marks = []
     for _ in range(args.steps):
         te = time.time()
         out = model.compress(pc, q, block_size=1024)
         torch.cuda.synchronize()
         t_enc += time.time() - te
         rec = model.decompress(coordinates=out[3], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
+        step_marks.append(time.time())          # host time only (no sync): the next compress starts with a size read
     torch.cuda.synchronize()
     barrier()
     dt = time.time() - t0
@@ -234,6 +236,7 @@ def main():
                                    f"1 block; entropy coder in the timed region: {args.coder}",
                        "bpp_y_z_strings": bpp, "ms_per_step_without_entropy_coder": hot_ms,
                        "frames_per_step": world, "encode_ms": recs[0][2] * 1e3, "decode_ms": recs[0][3] * 1e3,
+                       "step_ms_rank0": [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_marks[:-1], step_marks)],
                        "device": arch, "cus": cu},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None, "traffic": pmc_traffic(),

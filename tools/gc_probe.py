@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Are a step's coordinate sets / maps freed by reference counting, or only by the cyclic collector?"""
+import gc, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from unified_point_cloud_compression_amd import synth, sparse as S
+dev = torch.device("cuda:0")
+model = bench.build_model(dev)
+pc = torch.from_numpy(synth.surface_cloud(0, 9)).to(dev)
+q = torch.tensor([[0.5, 0.5]], device=dev)
+gc.collect()
+gc.disable()
+for i in range(4):
+    bench.step(model, pc, q)
+    torch.cuda.synchronize()
+    alive = sum(isinstance(o, S.CoordSet) for o in gc.get_objects())
+    print(f"step {i}: live CoordSet objects {alive}, allocated {torch.cuda.memory_allocated() / 2**20:.0f} MiB", flush=True)
+print("collected by gc.collect():", gc.collect(), "-> live CoordSets", sum(isinstance(o, S.CoordSet) for o in gc.get_objects()),
+      f"allocated {torch.cuda.memory_allocated() / 2**20:.0f} MiB")
+bench.step(model, pc, q)
+torch.cuda.synchronize()
+for o in gc.get_objects():
+    if isinstance(o, S.CoordSet):
+        refs = [r for r in gc.get_referrers(o) if not isinstance(r, type(sys._getframe()))]
+        desc = []
+        for r in refs:
+            if isinstance(r, dict):
+                owners = [type(x).__name__ for x in gc.get_referrers(r) if not isinstance(x, (list, dict, type(sys._getframe())))]
+                desc.append("dict of " + ",".join(owners[:3]) + " keys=" + ",".join(str(k)[:25] for k in list(r)[:4]))
+            else:
+                desc.append(type(r).__name__)
+        print(f"CoordSet ts={o.ts} n={o.n}: {desc}")

@@ -7,6 +7,9 @@ coordinate manager.
 """
 import ctypes as C
 
+import itertools
+import weakref
+
 import torch
 
 from . import lib as L
@@ -98,6 +101,9 @@ USE_GRID = True       # neighbour lookup through the bitmap+rank grid index (Fal
 GRID_MAX_BYTES = 8 << 30
 
 
+_SET_SERIAL = itertools.count()
+
+
 class CoordSet:
     """Canonical coordinate set at one tensor stride."""
 
@@ -110,21 +116,25 @@ class CoordSet:
         self._derived = {}
         self._maps = {}
         self._grid = None
+        self.uid = next(_SET_SERIAL)
 
     @property
     def device(self):
         return self.keys.device
 
     def coords(self):
-        """int32 [n,4] (b,x,y,z) view, cached; tagged so SparseTensor(coordinates=x.C) re-wraps in O(1)."""
-        if self._C is None:
+        """int32 [n,4] (b,x,y,z) view, tagged so SparseTensor(coordinates=x.C) re-wraps in O(1).  The tensor refers to
+        this set strongly, the set remembers the tensor only weakly: a strong reference both ways is a cycle that only
+        the cyclic collector frees, and a step's maps (GBs) would then outlive the step by several steps."""
+        c = self._C() if self._C is not None else None
+        if c is None:
             c = torch.empty((self.n, 4), dtype=torch.int32, device=self.device)
             if self.n:
                 L.call("pcc_keys_unpack", L.ptr(self.keys), self.n, L.ptr(c), L.stream())
             c._pcc_cset = self
             c._pcc_perm = None
-            self._C = c
-        return self._C
+            self._C = weakref.ref(c)
+        return c
 
     def grid(self):
         """Occupancy bitmap + rank over the bounding lattice (the lookup structure of every map whose input is this
@@ -267,7 +277,7 @@ class CoordSet:
         if morton is None:
             morton = (not transposed) and ksize > 1 and out_set.n >= MORTON_MIN_ROWS
         morton = bool(morton) and not transposed
-        key = (id(out_set), ksize, bool(transposed), up_stride, morton, step)
+        key = (out_set.uid, ksize, bool(transposed), up_stride, morton, step)
         m = self._maps.get(key)
         if m is not None:
             return m
@@ -291,8 +301,8 @@ class CoordSet:
                L.ptr(g[0]) if g else None, L.ptr(g[1]) if g else None, g[2] if g else None,
                L.ptr(ws), ws.numel(), L.stream())
         self._maps[key] = m
-        # keep the output set alive as long as the map is cached (id() is the cache key)
-        self._derived.setdefault(("map_out", id(out_set)), out_set)
+        # (the cache key is the output set's serial number, not id(): nothing has to keep the output set alive, and a
+        #  reference from here would close cycles such as y -> stride -> z -> expand -> children -> map onto y)
         return m
 
 

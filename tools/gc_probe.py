@@ -18,16 +18,3 @@ for i in range(4):
     print(f"step {i}: live CoordSet objects {alive}, allocated {torch.cuda.memory_allocated() / 2**20:.0f} MiB", flush=True)
 print("collected by gc.collect():", gc.collect(), "-> live CoordSets", sum(isinstance(o, S.CoordSet) for o in gc.get_objects()),
       f"allocated {torch.cuda.memory_allocated() / 2**20:.0f} MiB")
-bench.step(model, pc, q)
-torch.cuda.synchronize()
-for o in gc.get_objects():
-    if isinstance(o, S.CoordSet):
-        refs = [r for r in gc.get_referrers(o) if not isinstance(r, type(sys._getframe()))]
-        desc = []
-        for r in refs:
-            if isinstance(r, dict):
-                owners = [type(x).__name__ for x in gc.get_referrers(r) if not isinstance(x, (list, dict, type(sys._getframe())))]
-                desc.append("dict of " + ",".join(owners[:3]) + " keys=" + ",".join(str(k)[:25] for k in list(r)[:4]))
-            else:
-                desc.append(type(r).__name__)
-        print(f"CoordSet ts={o.ts} n={o.n}: {desc}")

@@ -556,16 +556,34 @@ __global__ void __launch_bounds__(256) k_rans_decode_lds(const unsigned* __restr
   unsigned long long x = (unsigned long long)data[off] | ((unsigned long long)data[off + 1] << 32);
   unsigned nw = data[min(pos, lim)];
   int j = 0;
-  for (; j < cfast; j += GB) {                         // wave-uniform trip count, no per-symbol predicates
-    int ci[GB];
-    unsigned a[GB];
+  // wave-uniform trip count, no per-symbol predicates.  The table rows of the NEXT batch are fetched while this batch is
+  // decoded (two batches per trip, the buffers swapping roles: a copy would tie the decode to the loads just issued).
+  auto addr = [&](int jj) { return lane_base + (unsigned)(jj >> g.gl) * (unsigned)g.channels + (unsigned)(jj & gm); };
+  auto fetch = [&](int j0, int (&ci)[GB]) {
 #pragma unroll
     for (int u = 0; u < GB; ++u) {
-      a[u] = lane_base + (unsigned)((j + u) >> g.gl) * (unsigned)g.channels + (unsigned)((j + u) & gm);
-      ci[u] = HAS_IDX ? idx[a[u]] : ch0 + ((j + u) & gm);
+      const int jj = min(j0 + u, cfast - 1);            // past the end: re-read the last row (unused)
+      ci[u] = HAS_IDX ? idx[addr(jj)] : ch0 + (jj & gm);
     }
+  };
+  auto run = [&](int j0, const int (&ci)[GB]) {
 #pragma unroll
-    for (int u = 0; u < GB; ++u) out[a[u]] = dec_one(ci[u], x, nw, pos, data, lim, d);
+    for (int u = 0; u < GB; ++u) out[addr(j0 + u)] = dec_one(ci[u], x, nw, pos, data, lim, d);
+  };
+  if (cfast > 0) {
+    int ca[GB], cb[GB];
+    fetch(0, ca);
+    for (; j + 2 * GB <= cfast; j += 2 * GB) {
+      fetch(j + GB, cb);
+      __builtin_amdgcn_sched_barrier(0);
+      run(j, ca);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(j + 2 * GB, ca);
+      __builtin_amdgcn_sched_barrier(0);
+      run(j + GB, cb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (j < cfast) { run(j, ca); j += GB; }              // odd number of batches
   }
   const int cmax = g.R << g.gl;
   for (; j < cmax; ++j) {

@@ -425,21 +425,31 @@ __global__ void __launch_bounds__(64) k_rans_encode(const RansEncSym* __restrict
       enc_one(x, ptr, e, pre_r, o);
     }
   }
-  // full batches, wave-uniform trip count
-  RansEncSym ea[GB], eb[GB];
+  // full batches, wave-uniform trip count; two batches per trip with the buffers swapping roles (no register copy that
+  // would make the coder wait for the entries just requested)
+  auto fetch = [&](int base, RansEncSym (&e)[GB]) {      // entries base-1 ... base-GB (clamped at the stream start)
+#pragma unroll
+    for (int u = 0; u < GB; ++u) e[u] = pre_e[(size_t)max(base - 1 - u, 0) * ns + s];
+  };
+  auto run = [&](int base, const RansEncSym (&e)[GB]) {
+#pragma unroll
+    for (int u = 0; u < GB; ++u) enc_one(x, ptr, e[u], pre_r, (size_t)(base - 1 - u) * ns + s);
+  };
   if (cfast > 0) {
-#pragma unroll
-    for (int u = 0; u < GB; ++u) ea[u] = pre_e[(size_t)(cfast - 1 - u) * ns + s];
-  }
-  for (int base = cfast; base > 0; base -= GB) {
-    if (base > GB) {
-#pragma unroll
-      for (int u = 0; u < GB; ++u) eb[u] = pre_e[(size_t)(base - GB - 1 - u) * ns + s];
+    RansEncSym ea[GB], eb[GB];
+    int base = cfast;
+    fetch(base, ea);
+    for (; base >= 2 * GB; base -= 2 * GB) {
+      fetch(base - GB, eb);
+      __builtin_amdgcn_sched_barrier(0);
+      run(base, ea);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(base - 2 * GB, ea);
+      __builtin_amdgcn_sched_barrier(0);
+      run(base - GB, eb);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int u = 0; u < GB; ++u) enc_one(x, ptr, ea[u], pre_r, (size_t)(base - 1 - u) * ns + s);
-#pragma unroll
-    for (int u = 0; u < GB; ++u) ea[u] = eb[u];
+    if (base > 0) run(base, ea);                          // odd number of batches
   }
   ptr -= 2;
   ptr[0] = (unsigned)x;

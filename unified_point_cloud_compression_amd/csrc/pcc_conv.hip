@@ -311,6 +311,30 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
   }
 
   // ---- epilogue: bias, activation (or GDN), store -------------------------------------------
+  // Full tiles written to consecutive rows take a branch-free path: one base pointer per lane, the activation chosen
+  // once per tile.  (The general loop below costs ~50 instructions per element -- row-list lookups, tail checks and
+  // the activation switch for each of the 64 values a lane holds -- which is as much as the whole MFMA phase of a
+  // 128-deep GEMM tile.)
+  if (MODE == MODE_CONV && !a.rows && npos == BM) {
+    float* const lane_out = a.out + (size_t)(pos0 + wm * TM * 32 + 4 * half) * a.cout + colblock + wn * TN * 32 + r31;
+    auto store_tile = [&](auto actf) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = colblock + (wn * TN + j) * 32 + r31;
+        if (col >= a.cout) continue;
+        const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            lane_out[(size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * a.cout + j * 32] = actf(acc[i][j][e] + b);
+      }
+    };
+    if (a.act == PCC_ACT_RELU) store_tile([](float v) { return fmaxf(v, 0.f); });
+    else if (a.act == PCC_ACT_LEAKY) { const float sl = a.slope; store_tile([sl](float v) { return v >= 0.f ? v : v * sl; }); }
+    else store_tile([](float v) { return v; });
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = colblock + (wn * TN + j) * 32 + r31;

@@ -315,8 +315,10 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
   // once per tile.  (The general loop below costs ~50 instructions per element -- row-list lookups, tail checks and
   // the activation switch for each of the 64 values a lane holds -- which is as much as the whole MFMA phase of a
   // 128-deep GEMM tile.)
-  if (MODE == MODE_CONV && !a.rows && npos == BM) {
-    float* const lane_out = a.out + (size_t)(pos0 + wm * TM * 32 + 4 * half) * a.cout + colblock + wn * TN * 32 + r31;
+  if (!a.rows && npos == BM) {
+    const size_t lane_off = (size_t)(pos0 + wm * TM * 32 + 4 * half) * a.cout + colblock + wn * TN * 32 + r31;
+    float* const lane_out = a.out + lane_off;
+    const float* const lane_x = a.feat + lane_off;             // GDN / IGDN: cin == cout, same element of the input
     auto store_tile = [&](auto actf) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -326,13 +328,17 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            lane_out[(size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * a.cout + j * 32] = actf(acc[i][j][e] + b);
+          for (int e = 0; e < 16; ++e) {
+            const size_t o = (size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * a.cout + j * 32;
+            lane_out[o] = actf(acc[i][j][e] + b, o);
+          }
       }
     };
-    if (a.act == PCC_ACT_RELU) store_tile([](float v) { return fmaxf(v, 0.f); });
-    else if (a.act == PCC_ACT_LEAKY) { const float sl = a.slope; store_tile([sl](float v) { return v >= 0.f ? v : v * sl; }); }
-    else store_tile([](float v) { return v; });
+    if (MODE == MODE_GDN) store_tile([&](float v, size_t o) { return lane_x[o] / v; });
+    else if (MODE == MODE_IGDN) store_tile([&](float v, size_t o) { return lane_x[o] * v; });
+    else if (a.act == PCC_ACT_RELU) store_tile([](float v, size_t) { return fmaxf(v, 0.f); });
+    else if (a.act == PCC_ACT_LEAKY) { const float sl = a.slope; store_tile([sl](float v, size_t) { return v >= 0.f ? v : v * sl; }); }
+    else store_tile([](float v, size_t) { return v; });
     return;
   }
 #pragma unroll

@@ -29,7 +29,7 @@ def gather_records(records, device, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     mine = torch.tensor(records, dtype=torch.float64, device=device).reshape(-1, len(RECORD_FIELDS))
     if world == 1:
-        return mine.cpu().tolist()
+        return sorted(mine.cpu().tolist(), key=lambda r: r[0])
     n_local = torch.tensor([mine.shape[0]], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)

@@ -30,7 +30,9 @@ R2_CONFIG = {
 }
 
 
-def build_model(device, seed=0, gain=3.0, coder="pcc_streams"):
+def init_model(seed=0, gain=3.0, coder="pcc_streams"):
+    """The benchmark's model on the CPU: R2 architecture, torch-seeded default init, conv kernels scaled by `gain`
+    (tests/golden/make_fullsize.py hands exactly these parameters to the oracle)."""
     import copy
     from unified_point_cloud_compression_amd.model import UnifiedModel
     from unified_point_cloud_compression_amd.MinkowskiEngine.modules import _ConvBase
@@ -42,7 +44,11 @@ def build_model(device, seed=0, gain=3.0, coder="pcc_streams"):
         for m in model.modules():
             if isinstance(m, _ConvBase):
                 m.kernel.mul_(gain)
-    model = model.to(device).eval()
+    return model
+
+
+def build_model(device, seed=0, gain=3.0, coder="pcc_streams"):
+    model = init_model(seed, gain, coder).to(device).eval()
     model.update()
     return model
 
@@ -53,14 +59,35 @@ def step(model, pc, q):
     return out, rec
 
 
+def csrc_sha():
+    """SHA-256 over the kernel sources (csrc/*.hip, *.h, include/pcc_hip.h): identifies the code a PMC measurement
+    belongs to (`.git` does not travel to the GPU box, so a content hash stands in for the commit)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pk = os.path.join(ROOT, "unified_point_cloud_compression_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(pk, "*.hip")) + glob.glob(os.path.join(pk, "*.h")) +
+                    [os.path.join(ROOT, "include", "pcc_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_FILE = os.path.join("profiles", "pmc_traffic.json")
+
+
 def pmc_traffic():
     """HBM bytes per MFMA-conv launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE and
-    WRITE_SIZE in separate passes, KiB units, gfx950 FETCH x2 correction).  None when no measurement is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    WRITE_SIZE in separate passes, KiB units, gfx950 FETCH x2 correction), with the hash of the kernel sources it was
+    collected on.  (None, reason) when no measurement is committed or when it belongs to other kernel code."""
     try:
-        return float(json.load(open(path))["hbm_bytes_per_launch"])
+        rec = json.load(open(os.path.join(ROOT, PMC_FILE)))
     except Exception:
-        return None
+        return None, "no PMC measurement committed"
+    now = csrc_sha()
+    if rec.get("csrc_sha") != now:
+        return None, f"stale: measured on csrc {rec.get('csrc_sha')}, running csrc {now} (re-run tools/pmc_traffic.py)"
+    return float(rec["hbm_bytes_per_launch"]), f"rocprofv3 PMC passes of `{rec.get('command')}` on csrc {now}, {PMC_FILE}"
 
 
 def mfma_shape(cin, cout):
@@ -111,23 +138,69 @@ def account_flops(model, pc, q):
     return flops, launches, pairs_total, alg_bytes
 
 
-def cpu_baseline(bits=8, threads=None):
-    """The oracle (numpy restatement, 'port') timed on this host's cores on a bounded sample of the same workload:
-    the same synthetic surface at 2^bits resolution, same R2 architecture, encode + decode."""
+def cpu_baseline(threads=None):
+    """The oracle (numpy restatement, 'port'; MinkowskiEngine cannot run here) timed on this host's cores on bounded
+    samples of the same workload: the same synthetic surface at vox8 (1 warm-up, median of 3) and once at vox9, same
+    R2 architecture and weights recipe, encode + decode, harness of BASELINE.md section 3.  `value` is the vox9 figure
+    (closest to the benchmark's frame that fits the time bound); the full vox10 frame takes the oracle ~150 s on the
+    build container's 8 cores (5.2 k points/s, tests/golden/make_fullsize.py), see DESIGN.md section 5."""
     from oracle import codec
     from unified_point_cloud_compression_amd import synth
-    threads = threads or os.cpu_count() or 1
+    threads = threads or min(os.cpu_count() or 1, 16)           # the GPU box's CPU share for one GPU
     torch.set_num_threads(threads)
-    pc = synth.surface_cloud(0, bits)
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=threads)
+    except Exception:
+        limit = None
     P = codec.random_params(codec.R2_CONFIG, 0, gain=3.0)
     q = np.array([[0.5, 0.5]], dtype=np.float32)
-    t0 = time.time()
-    blocks = codec.compress(P, codec.R2_CONFIG, pc, q, threads=threads)
-    codec.decompress(P, codec.R2_CONFIG, blocks, threads=threads)
-    dt = time.time() - t0
-    return {"value": pc.shape[0] / dt, "unit": "points/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (numpy restatement; MinkowskiEngine unavailable) encode+decode of the same synthetic surface "
-                      f"at vox{bits} ({pc.shape[0]} points), R2 architecture, {dt:.1f} s"}
+
+    def once(pc):
+        t0 = time.time()
+        blocks = codec.compress(P, codec.R2_CONFIG, pc, q, threads=threads)
+        codec.decompress(P, codec.R2_CONFIG, blocks, threads=threads)
+        return time.time() - t0
+
+    pc8, pc9 = synth.surface_cloud(0, 8), synth.surface_cloud(0, 9)
+    once(pc8)
+    t8 = sorted(once(pc8) for _ in range(3))[1]
+    t9 = once(pc9)
+    if limit is not None:
+        limit.restore_original_limits()
+    return {"value": pc9.shape[0] / t9, "unit": "points/s", "cores": threads, "kind": "port",
+            "points_per_s_vox8": pc8.shape[0] / t8,
+            "sample": f"oracle (numpy restatement; MinkowskiEngine unavailable) encode+decode of the same synthetic surface, "
+                      f"R2 architecture: vox9 ({pc9.shape[0]} points) one run {t9:.1f} s -> value; vox8 ({pc8.shape[0]} points) "
+                      f"1 warm-up + median of 3 = {t8:.1f} s"}
+
+
+def oracle_figures(bits):
+    """Rate / distortion of the ORACLE on this exact frame and these weights (tests/golden/full_config2_vox10.npz,
+    produced in the build container by tests/golden/make_fullsize.py): printed beside the build's own figures."""
+    if bits != 10:
+        return None
+    try:
+        fx = np.load(os.path.join(ROOT, "tests", "golden", "full_config2_vox10.npz"))
+        n = int(fx["n_points"])
+        return {"bpp_likelihood": (float(fx["bits_y"]) + float(fx["bits_z"])) / n, "d1_psnr_sym": float(fx["d1_sym"]),
+                "d1_psnr_AB": float(fx["d1_AB"]), "d1_psnr_BA": float(fx["d1_BA"]), "n_points": n}
+    except Exception:
+        return None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run as a CHILD process,
+    before this process touches the GPU (never exec / re-exec after HIP init), and leave with its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -141,6 +214,8 @@ def main():
                     help="entropy coder inside the timed region (default: per-channel GPU rANS)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,7 +294,20 @@ def main():
         return sum(count_bits(x) if isinstance(x, list) else len(x) * 8 for x in strings)
     bpp = (count_bits(out[0]) / n_points) if args.coder != "symbols" else None
 
+    # rate / distortion of the coded frame (un-timed): -sum log2 p / N (`loss.py:77-79`) and the D1 report of
+    # `metrics/metric.py:113-118,74` on the GPU, next to the oracle's figures for the same frame and weights
+    rd = None
     if rank == 0:
+        from unified_point_cloud_compression_amd import metrics
+        y, _ = model.g_a(model.block_input(pc))
+        y_lik, z_lik = model.entropy_model.likelihoods(y, q)
+        bits_lik = float(-torch.log2(y_lik.double()).sum().item() - torch.log2(z_lik.double()).sum().item())
+        m = metrics.pointcloud_metrics(pc, rec, (1 << args.bits) - 1)
+        rd = {"bpp_likelihood": bits_lik / n_points, "d1_psnr_sym": m["sym_psnr_mse"], "d1_psnr_AB": m["AB_psnr_mse"],
+              "d1_psnr_BA": m["BA_psnr_mse"], "y_psnr_sym": m["sym_y_psnr"], "oracle": oracle_figures(args.bits)}
+
+    if rank == 0:
+        traffic, traffic_note = pmc_traffic()
         ms_step = dt_max / args.steps * 1e3
         # conv launches: only MFMA-shaped ones are event-timed inside the library
         ach = (flops_step * args.steps / (conv_ms.value * 1e-3) / 1e12) if conv_ms.value > 0 else None
@@ -234,13 +322,14 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: one synthetic longdress-like vox{args.bits} frame per GPU "
                                    f"({n_points} points on rank 0), R2 architecture, random-init weights, q=[[0.5,0.5]], "
                                    f"1 block; entropy coder in the timed region: {args.coder}",
-                       "bpp_y_z_strings": bpp, "ms_per_step_without_entropy_coder": hot_ms,
+                       "bpp_y_z_strings": bpp, "bpp_likelihood": rd["bpp_likelihood"], "d1_psnr": rd["d1_psnr_sym"],
+                       "rate_distortion": rd, "ms_per_step_without_entropy_coder": hot_ms,
                        "frames_per_step": world, "encode_ms": recs[0][2] * 1e3, "decode_ms": recs[0][3] * 1e3,
                        "step_ms_rank0": [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_marks[:-1], step_marks)],
                        "device": arch, "cus": cu},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None, "traffic": pmc_traffic(),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                         "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
                          "alg_bytes_per_launch": (alg_bytes_step / launches_step) if launches_step else None,
                          "kernel": "k_conv_mfma (pcc_conv_fwd)", "flop_per_step": flops_step,
                          "pairs_per_step": pairs_step, "launches_per_step": launches_step,

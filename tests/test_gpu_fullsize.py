@@ -112,23 +112,34 @@ def _roundtrip(model, pc, q, block_size):
 
 
 def test_rd_sweep_shapes_and_weights():
-    """BASELINE config 3 (R1-R4 = four separately trained models of one architecture, four sequences): different
-    synthetic surfaces x different weight seeds; every run must satisfy the codec invariants."""
+    """BASELINE config 3 at its stated size (R1-R4 = four separately trained models of one architecture x four
+    sequences): four synthetic vox10 surfaces (0.79-1.05 M voxels) x four weight seeds; every one of the 16 runs must
+    satisfy the codec invariants and be bit-reproducible.  One cell (surface 3 x weights 2) is additionally compared
+    with the oracle in tests/test_gpu_fullsize_oracle.py."""
     import bench
     from unified_point_cloud_compression_amd import synth
     dev = torch.device("cuda:0")
     q = torch.tensor([[0.5, 0.5]], device=dev)
-    for wseed in (1, 2):
+    clouds = [torch.from_numpy(synth.surface_cloud(s, 10, sc)).to(dev) for s, sc in ((3, 1.1), (4, 1.0), (5, 1.05), (6, 1.15))]
+    assert all(750_000 < c.shape[0] < 1_100_000 for c in clouds)
+    for wseed in (1, 2, 3, 4):
         model = bench.build_model(dev, seed=wseed, coder="pcc_streams")
-        for sseed, scale in ((3, 1.0), (4, 0.8)):
-            pc = torch.from_numpy(synth.surface_cloud(sseed, 9, scale)).to(dev)
+        for pc in clouds:
             out, rec = _roundtrip(model, pc, q, 1024)
             assert rec.shape == (pc.shape[0], 6)
-            assert out[2][0][2] == [pc.shape[0]]
+            k = out[2][0]
+            assert k[2] == [pc.shape[0]] and k[0][0] < k[1][0] < k[2][0]
             (ys,), (zs,) = out[0][0]
             assert len(ys) > 0 and len(zs) > 0
+            keys = S_keys(rec)
+            assert bool((keys[1:] > keys[:-1]).all().item())                  # decoded voxels unique and canonical
             out2, rec2 = _roundtrip(model, pc, q, 1024)
             assert out2[0][0][0][0] == ys and torch.equal(rec, rec2)          # bit-identical strings and reconstruction
+
+
+def S_keys(rec):
+    c = rec[:, :3].to(torch.int64) + (1 << 15)
+    return (c[:, 0] << 32) | (c[:, 1] << 16) | c[:, 2]
 
 
 def test_vox11_multiblock_frame():

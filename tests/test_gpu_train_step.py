@@ -58,7 +58,7 @@ def test_train_step_matches_torch_reference(mode, offsets):
     # ---- build under test
     mcfg = copy.deepcopy(cfg)
     model = load_params(UnifiedModel(mcfg), Pn).to(dev()).train()
-    model.entropy_model.noise_fn = lambda tag, like: t(noise_y if tag == "y" else noise_z)
+    model.entropy_model.noise_fn = lambda tag, like: t(noise_y if tag.startswith("y") else noise_z)
     x = ME.SparseTensor(coordinates=t(C), features=t(rgb))
     out = model(x, t(q), t(Lam))
     total, parts = Loss(copy.deepcopy(LOSS_CFG))(x, out)

@@ -6,7 +6,9 @@ gather-heavy kernels, whose 16-byte row pieces are served at sector granularity)
 
 usage (on the GPU box, from the repo root):
   python tools/pmc_traffic.py collect gpurun_out/pmc        # runs two rocprofv3 passes of bench.py
-  python tools/pmc_traffic.py parse   gpurun_out/pmc profiles/r01_pmc_traffic.json
+  python tools/pmc_traffic.py parse   gpurun_out/pmc profiles/pmc_traffic.json
+The record carries the hash of the kernel sources it was measured on (`bench.csrc_sha`); bench.py reports the traffic
+only while that hash matches the code it runs.
 """
 import csv
 import glob
@@ -15,6 +17,9 @@ import os
 import re
 import subprocess
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha  # noqa: E402
 
 KERNELS = ("k_conv_mfma", "k_conv_wave16")
 BENCH = ["python3", "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--coder", "symbols"]
@@ -51,7 +56,7 @@ def parse(out, dst):
            "hbm_read_bytes_per_launch": read, "hbm_write_bytes_per_launch": write,
            "hbm_bytes_per_launch": read + write,
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), KiB*1024, FETCH x2 (gfx950)",
-           "command": " ".join(BENCH)}
+           "command": " ".join(BENCH), "csrc_sha": csrc_sha()}
     json.dump(rec, open(dst, "w"), indent=1)
     print(json.dumps(rec))
 

@@ -152,20 +152,29 @@ class MinkowskiLeakyReLU(_Elementwise):
 
 
 class MinkowskiPruning(nn.Module):
-    """`ME.MinkowskiPruning` (`model/transforms.py:163,280`): keep rows where mask is True (A.6)."""
+    """`ME.MinkowskiPruning` (`model/transforms.py:163,280`): keep rows where mask is True, in the input's relative
+    order; an all-False mask gives an empty tensor."""
 
     def forward(self, input, mask):
         if mask.dtype != torch.bool or mask.shape[0] != len(input):
             raise L.PccError("pruning mask must be a bool tensor with one entry per row")
         mask = mask.to(input.device)
         cs = input._cset
-        if input._perm is not None:
-            mc = mask[input._perm]
-        else:
-            mc = mask
-        keys, feats, k = S.prune(cs.keys, cs.n, input._canonical_features(), mc)
+        if input._perm is None:
+            keys, feats, k = S.prune(cs.keys, cs.n, input._canonical_features(), mask)
+            return SparseTensor._from_canonical(S.CoordSet(keys, k, cs.ts, cs.bounds), feats)
+        # user-ordered rows: the kept set in canonical order for the kernels, .C / .F in the caller's row order
+        keys, _, k = S.prune(cs.keys, cs.n, None, mask[input._perm])
         out_set = S.CoordSet(keys, k, cs.ts, cs.bounds)
-        return SparseTensor._from_canonical(out_set, feats)
+        rank = torch.empty(cs.n, dtype=torch.int64, device=input.device)      # user row -> canonical position
+        rank[input._perm] = torch.arange(cs.n, device=input.device)
+        kept_user = torch.nonzero(mask)[:, 0]
+        order = torch.argsort(rank[kept_user])                                 # canonical position among kept -> kept user row
+        t = SparseTensor.__new__(SparseTensor)
+        C = input.C[kept_user].contiguous()
+        C._pcc_cset, C._pcc_perm, C._pcc_version = out_set, order, C._version
+        t._cset, t._perm, t._C, t._F, t._Fc = out_set, order, C, input.F[kept_user], None
+        return t
 
 
 class MinkowskiAvgPooling(nn.Module):

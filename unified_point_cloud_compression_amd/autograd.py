@@ -55,7 +55,7 @@ class SparseConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, kernel, bias, module, in_set, out_set, kmap, act, slope):
         K, cin, cout = module.kernel_volume, module.in_channels, module.out_channels
-        packed = module._packed.get(kernel)
+        packed = module._packed.get(kernel, tag_from=module.kernel)
         feats = feats.contiguous()
         if isinstance(kmap, tuple):
             out = S.convt_forward_csr(feats, packed, bias, K, cin, cout, kmap, out_set.n, act, slope)

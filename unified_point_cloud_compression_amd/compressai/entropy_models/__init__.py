@@ -1,6 +1,11 @@
 """`compressai.entropy_models` subset: `EntropyBottleneck`, `GaussianConditional`
 (`model/entropy_models.py:8,161,175,272,282-285,312-319,371-372,396-400,438,468-484`).
 
+Attribution: CompressAI (InterDigital, BSD 3-Clause Clear) is not part of /root/reference; parameter names, shapes,
+initial values and the table construction (`update`: minima / maxima / pmf_start / pmf_length / samples) restate its
+published `compressai/entropy_models/entropy_models.py` 1.2.4 because they ARE the state_dict schema and the bitstream
+tables a drop-in must reproduce.  The arithmetic on the hot path (likelihood, index, quantise, rANS) is libpcc_hip.
+
 Tensor layout at this surface is CompressAI's [B, C, N]; the HIP kernels work on row-major [N, C]
 (the layout the sparse convolutions produce), so the [N, C] entry points `*_rows` are what the
 build's own model uses and the [B, C, N] methods transpose around them.
@@ -66,6 +71,23 @@ class EntropyModel(nn.Module):
         self.register_buffer("_offset", torch.IntTensor())
         self.register_buffer("_quantized_cdf", torch.IntTensor())
         self.register_buffer("_cdf_length", torch.IntTensor())
+        self._tables_gen = 0          # bumped whenever the tables change: keys the packed encoder / decoder tables
+
+    _RESIZABLE = ("_offset", "_quantized_cdf", "_cdf_length", "scale_table")
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """A checkpoint written after `model.update()` (`train.py:169-174,322`) holds populated tables while a fresh
+        model's are empty: resize the table buffers to the checkpoint's shapes before the copy, as CompressAI's
+        `update_registered_buffers` does for `load_state_dict` (`evaluate.py:86`)."""
+        for name in self._RESIZABLE:
+            buf = self._buffers.get(name)
+            src = state_dict.get(prefix + name)
+            if buf is not None and src is not None and tuple(buf.shape) != tuple(src.shape):
+                self._buffers[name] = torch.empty(tuple(src.shape), dtype=buf.dtype, device=buf.device)
+        self._tables_gen += 1
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
 
     # ---- tables -----------------------------------------------------------------------------------------
     def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
@@ -154,7 +176,7 @@ class EntropyModel(nn.Module):
 
     def _dec_table(self, dev):
         """Compact decoder table of the current CDFs (rebuilt when the tables change)."""
-        tag = (self._quantized_cdf.data_ptr(), self._quantized_cdf._version, str(dev))
+        tag = (self._tables_gen, self._quantized_cdf._version, str(dev))
         if getattr(self, "_dec_tag", None) != tag:
             cdf, sizes, _ = self._host_tables()
             lib = L.load()
@@ -168,7 +190,7 @@ class EntropyModel(nn.Module):
 
     def _enc_table(self, dev):
         """Division-free encoder entries of the current CDFs (rebuilt when the tables change)."""
-        tag = (self._quantized_cdf.data_ptr(), self._quantized_cdf._version, str(dev))
+        tag = (self._tables_gen, self._quantized_cdf._version, str(dev))
         if getattr(self, "_enc_tag", None) != tag:
             cdf, sizes, _ = self._host_tables()
             tab = np.zeros(cdf.shape[0] * cdf.shape[1] * 2, dtype=np.uint64)
@@ -253,6 +275,18 @@ class EntropyBottleneck(EntropyModel):
         self.register_buffer("target", torch.Tensor([np.log(2 / self.tail_mass - 1)]))
         self._packed_tag, self._packed = None, None
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """Accept both spellings of the factorised-prior parameters: `_matrix{i}` / `_bias{i}` / `_factor{i}` (CompressAI
+        <= 1.2.0 attribute names, used here) and `matrices.{i}` / `biases.{i}` / `factors.{i}` (the ParameterList names
+        SURVEY B.4 records for 1.2.4), so a checkpoint written by either loads."""
+        for i in range(len(self.filters) + 1):
+            for new, old in ((f"matrices.{i}", f"_matrix{i}"), (f"biases.{i}", f"_bias{i}"), (f"factors.{i}", f"_factor{i}")):
+                if prefix + new in state_dict and prefix + old not in state_dict:
+                    state_dict[prefix + old] = state_dict.pop(prefix + new)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
     def _get_medians(self):
         return self.quantiles[:, :, 1:2].detach()
 
@@ -306,6 +340,7 @@ class EntropyBottleneck(EntropyModel):
         self._quantized_cdf = self._pmf_to_cdf(pmf, tail, pmf_length, max_length).to(dev)
         self._offset = (-minima).int().to(dev)
         self._cdf_length = (pmf_length + 2).int().to(dev)
+        self._tables_gen += 1
         return True
 
     def likelihood_rows(self, v):
@@ -362,11 +397,17 @@ class EntropyBottleneck(EntropyModel):
                 for s in strings]
         return torch.stack([o.t().reshape(self.channels, *size) for o in outs], dim=0)
 
+    noise_fn = None     # callable(like) -> U(-.5,.5) noise; tests install a deterministic one
+
     def forward(self, x, training=None):
+        """`EntropyBottleneck.forward` ([B,C,N]; `model/entropy_models.py:272,282`): training -> additive uniform noise
+        (`quantize(.., "noise")`), eval -> round(x - median) + median; likelihood of the result, floored at 1e-9."""
         training = self.training if training is None else training
-        if training:
-            raise L.PccError("EntropyBottleneck noise-mode forward (training) is not built in this round")
         rows, back = _rows(x)
+        if training:
+            noise = self.noise_fn(rows) if self.noise_fn is not None else torch.empty_like(rows).uniform_(-0.5, 0.5)
+            out = rows + noise
+            return back(out), back(self.likelihood_rows(out))
         _, zh, lik = self.encode_rows(rows)
         return back(zh), back(lik)
 
@@ -415,6 +456,7 @@ class GaussianConditional(EntropyModel):
         self._quantized_cdf = self._pmf_to_cdf(pmf, tail, pmf_length, max_length).to(dev)
         self._offset = (-pmf_center).int().to(dev)
         self._cdf_length = (pmf_length + 2).int().to(dev)
+        self._tables_gen += 1
 
     def _table(self, device):
         if self.scale_table.numel() == 0:
@@ -469,12 +511,17 @@ class GaussianConditional(EntropyModel):
         return back(idx)
 
     def forward(self, inputs, scales, means=None, training=None):
-        """Eval-mode forward: (round(x - mu) + mu, likelihood) (`model/entropy_models.py:312-316,329-333`)."""
+        """Eval: (round(x - mu) + mu, likelihood); training: (x + U(-.5,.5), likelihood)
+        (`model/entropy_models.py:312-316,329-333`)."""
         training = self.training if training is None else training
-        if training:
-            raise L.PccError("GaussianConditional noise-mode forward (training) is not built in this round")
         x, back = _rows(inputs)
         s, _ = _rows(scales)
         m = _rows(means)[0] if means is not None else torch.zeros_like(x)
+        if training:          # `quantize(inputs, "noise", means)`: inputs + U(-.5,.5) (`model/entropy_models.py:312-316,327-331`)
+            noise = self.noise_fn(x) if self.noise_fn is not None else torch.empty_like(x).uniform_(-0.5, 0.5)
+            out = x + noise
+            return back(out), back(self.likelihood_rows(out, s, m))
         sym, _, lik = self.encode_rows(x, torch.cat([s, m], dim=1))
         return back(sym.to(torch.float32) + m), back(lik)
+
+    noise_fn = None

@@ -255,7 +255,10 @@ class MeanScaleHyperprior(CompressionModel):
             signs = torch.sign(tmp).detach()
             a = torch.abs(tmp)
             y_q_abs = a + ny if self.quantization_mode == "uniform" else quantize_ste(a)
-            y_lik = gc.likelihood_rows(yf * scale + ny, scales_hat * scale, means_hat * scale)
+            # the likelihood branch draws its own noise (`gaussian_conditional(...)` in training mode, reference
+            # `model/entropy_models.py:312-316`), independent of `quantize_noise` at `:304`
+            n_lik = self._noise("y_lik", yf) if self.quantization_mode == "uniform" else ny
+            y_lik = gc.likelihood_rows(yf * scale + n_lik, scales_hat * scale, means_hat * scale)
             stdev = gc.lower_bound_scale(scales_hat * scale)
             off = -self.get_offsets(stdev, scale.detach())
             off = torch.where(y_q_abs < 0.0001, off.new_zeros(1), off)

@@ -109,7 +109,8 @@ class UnifiedModel(CompressionModel):
         return bitstreams, block_shapes, block_k, block_coordinates, block_q_vals
 
     @torch.no_grad()
-    def decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None, q_vals=None, trace=None):
+    def decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None, q_vals=None, trace=None,
+                   probe=None):
         device = self.g_s.down_conv.kernel.device
         if path:
             coordinates, strings, shape, k, q_vals = self.load_bitstream(path)
@@ -126,7 +127,7 @@ class UnifiedModel(CompressionModel):
             # z coordinates: two k3-s2 `down_conv`s in the reference (`model/model.py:227-229`) = coordinate-only stride
             z_cset = y_cset.stride(16).stride(32)
             y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i], check=status)
-            x_hat = self.g_s(y_hat, k=block_k, trace=trace)
+            x_hat = self.g_s(y_hat, k=block_k, trace=trace, probe=probe)
             feats.append(x_hat.F)
             coords.append(x_hat.C)
         if status and int(torch.stack(status).abs().max().item()) != 0:     # one deferred check for all rANS containers

@@ -178,7 +178,7 @@ class SparseSynthesisTransform(nn.Module):
                 and c0.out_channels >= self.FUSE_MIN_HEAD_CHANNELS and c0.out_channels % 4 == 0
                 and x._cset.n > 0 and x._cset.n * 343 < (1 << 31) and x._cset.grid() is not None)
 
-    def _up_predict_fused(self, up, head, x, k_lvl):
+    def _up_predict_fused(self, up, head, x, k_lvl, probe=None, lvl=0):
         """Returns (x pruned to the top-k rows, prediction over all candidate rows, mask)."""
         for m in list(up)[:-1]:
             x = m(x)
@@ -195,6 +195,10 @@ class SparseSynthesisTransform(nn.Module):
         logit = c2._apply_conv(SparseTensor._from_canonical(out_set, h), out_set, kmap3)
         pred = SparseTensor._from_canonical(out_set, logit)
         mask, n_keep = self._topk_prediction(pred, k_lvl)
+        if probe is not None:
+            forced = probe("select", lvl, out_set, logit, mask, None)
+            if forced is not None:
+                mask, n_keep = forced, int(forced.sum().item())
         keys, _, n = S.prune(out_set.keys, out_set.n, None, mask, n_keep)
         kept = S.CoordSet(keys, n, ts_out, out_set.bounds)
         # the up-sampled features, for the kept rows only: transposed conv restricted to them, in pair-list form
@@ -207,26 +211,38 @@ class SparseSynthesisTransform(nn.Module):
         else:       # narrow shapes: slot map of the kept rows + the generic convolution
             xk = S.conv_forward(feats, packed, gen.bias, 125, gen.in_channels, gen.out_channels,
                                 S.map_from_csr(csr5, cs_in.n, n, 5), n)
+        if probe is not None:
+            probe("kept", lvl, kept, None, None, xk)
         return SparseTensor._from_canonical(kept, xk), pred, mask
 
-    def forward(self, y, coords=None, k=None, trace=None):
-        """y (stride 8) -> x (stride 1) features at the k-selected voxels (`model/transforms.py:170-225`)."""
+    def forward(self, y, coords=None, k=None, trace=None, probe=None):
+        """y (stride 8) -> x (stride 1) features at the k-selected voxels (`model/transforms.py:170-225`).
+        trace (dict): run layer by layer and record every level's keys / features / logits / mask.
+        probe (callable, tests): probe("select", lvl, candidate set, logits [n,1], mask, feats | None) may return a
+        replacement mask (the full-size parity test pins the rows inside the float-noise band around the k-th logit to
+        the oracle's choice); probe("kept", lvl, kept set, None, None, kept features) observes the pruned tensor."""
         predictions = []
         x = y
         for lvl, (up, head) in enumerate(((self.up_1, self.predict_1), (self.up_2, self.predict_2),
                                           (self.up_3, self.predict_3))):
             if coords is None and trace is None and self._can_fuse(up, head, x if lvl else y):
-                x, pred, _ = self._up_predict_fused(up, head, x, k[lvl])
+                x, pred, _ = self._up_predict_fused(up, head, x, k[lvl], probe, lvl)
                 predictions.append(pred)
                 continue
             x = up(x)
             pred = self._predict(head, x)
             mask, n_keep = self._topk_prediction(pred, k[lvl])
+            if probe is not None:
+                forced = probe("select", lvl, x._cset, pred.F, mask, x.F)
+                if forced is not None:
+                    mask, n_keep = forced, int(forced.sum().item())
             if trace is not None:
                 trace[f"keys_{lvl}"], trace[f"feats_{lvl}"] = x._cset.keys[:x._cset.n], x.F
                 trace[f"logit_{lvl}"], trace[f"mask_{lvl}"] = pred.F, mask
             predictions.append(pred)
             x = self._prune_tensor(x, mask, n_keep)
+            if probe is not None:
+                probe("kept", lvl, x._cset, None, None, x.F)
         x = self.color_conv(x)
         if coords is None:
             return x

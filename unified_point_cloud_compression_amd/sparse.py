@@ -427,11 +427,15 @@ class PackedConv:
         self.packed = None
         self.transposed = transposed
 
-    def get(self, kernel, state_dict_order=False):
+    def get(self, kernel, state_dict_order=False, tag_from=None):
         """state_dict_order: `kernel` is a module parameter as stored in a checkpoint (see WEIGHT_OFFSET_ORDER);
-        otherwise its K axis already is in the native offset order."""
+        otherwise its K axis already is in the native offset order.  tag_from: the Parameter `kernel` was derived from
+        (e.g. `param[perm]`): a temporary's (data_ptr, _version) does not identify its contents -- the allocator
+        recycles addresses -- so the cache is keyed on the parameter itself."""
         w = kernel.detach()
-        tag = (w.data_ptr(), kernel._version, tuple(w.shape), str(w.device), WEIGHT_OFFSET_ORDER if state_dict_order else "")
+        src = tag_from if tag_from is not None else kernel
+        tag = (src.data_ptr(), src._version, tuple(w.shape), str(w.device),
+               WEIGHT_OFFSET_ORDER if (state_dict_order or tag_from is not None) else "")
         if tag != self.tag:
             w3 = w if w.dim() == 3 else w.unsqueeze(0)
             perm = weight_offset_perm(w3.shape[0], w3.device) if state_dict_order else None

@@ -183,9 +183,10 @@ int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows
  * Weights are consumed in a packed layout produced once per parameter update.
  * ---------------------------------------------------------------------------------------- */
 int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
-/* W: ME layout [K, cin, cout] row-major (state_dict `kernel`) */
+/* W: ME layout [K, cin, cout] row-major (state_dict `kernel`).  packed_cap: floats available at
+ * `packed`; a buffer smaller than pcc_conv_packed_elems(K, cin, cout) is refused (PCC_EWS), never written past. */
 int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
-                          void* stream);
+                          int64_t packed_cap, void* stream);
 size_t pcc_conv_ws_bytes(int64_t n_in, int32_t K, int32_t cin, int32_t cout);
 int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                  const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* hdr,
@@ -216,7 +217,8 @@ int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t cin, const fl
  *   out[o]     = act(bias + sum_k T[nbr_k(o)][k][:])   ordered gather-sum through the transposed map
  * T: caller scratch of n_in*K*cout floats.  hdr/nbr/rows: a transposed map from pcc_kernel_map_build. */
 int64_t pcc_convt_packed_elems(int32_t K, int32_t cin, int32_t cout);
-int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed, void* stream);
+int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
+                           int64_t packed_cap, void* stream);
 int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                   const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* hdr,
                   const int32_t* nbr, const int32_t* rows, int64_t n_out, float* T, float* out, int32_t act,
@@ -236,7 +238,7 @@ int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const flo
  * (0 = unsupported channel count), beta_eff: c floats. */
 int64_t pcc_gdn_packed_elems(int32_t c);
 int pcc_gdn_pack(const float* beta_raw, const float* gamma_raw, int32_t c, float beta_min,
-                 float* packed, float* beta_eff, void* stream);
+                 float* packed, int64_t packed_cap, float* beta_eff, void* stream);
 int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* packed, const float* beta_eff,
                 int32_t inverse, float* out, void* stream);
 

@@ -55,3 +55,67 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(d, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(d, f)
+
+
+GRID = (1, 3, 4, 8, 16, 32, 64, 128, 192, 256)
+
+
+def _mfma_ok(cin, cout):
+    return cout > 4 and (cin in (4, 8, 16) or (cin >= 32 and cin % 32 == 0))
+
+
+def _cout_pad(cout):
+    bn = 128 if cout >= 128 else (64 if cout > 32 else 32)
+    return (cout + bn - 1) // bn * bn
+
+
+def _layout_extent(K, cin, cout):
+    """Floats the pack kernel of each kernel kind writes, restated from the documented layouts:
+    thin [K][cout][cin]; wave16 [K][16][cin] (weights resident in LDS: K*16*(cin+4)*4 <= 64 KB); MFMA
+    [K*cin/CB][cout_pad][CB]."""
+    if cout <= 4:
+        return K * cin * cout
+    if cout <= 16 and cin in (16, 32, 64) and K * 16 * (cin + 4) * 4 <= 64 * 1024:
+        return K * 16 * cin
+    return K * cin * _cout_pad(cout) if _mfma_ok(cin, cout) else 0
+
+
+def test_packed_size_queries_cover_what_the_pack_kernels_write():
+    """Round 1 lost a GPU process to a packed buffer sized with the wrong query (GDN(16) sized by the conv query: 256
+    floats for a 512-float MFMA layout).  For every kernel kind over the channel grid: the size query
+    equals the layout's extent, and the pack entry points refuse (PCC_EWS, before any launch) a buffer one float short --
+    so an undersized buffer can no longer be written past, whichever query the caller used."""
+    from unified_point_cloud_compression_amd import lib
+    L = lib.load()
+    dummy = (ctypes.c_float * 4)()
+    ptr = ctypes.cast(dummy, ctypes.c_void_p)
+    EWS = -3
+    checked = 0
+    for K in (1, 8, 27, 125):
+        for cin in GRID:
+            for cout in GRID:
+                want = _layout_extent(K, cin, cout)
+                got = L.pcc_conv_packed_elems(K, cin, cout)
+                assert got == want, (K, cin, cout, got, want)
+                if got > 0:
+                    assert L.pcc_conv_pack_weights(ptr, K, cin, cout, ptr, got - 1, None) == EWS
+                    checked += 1
+                # generative transpose, input-stationary: one flat [cin, K*cout] GEMM operand
+                wt = cin * _cout_pad(K * cout) if _mfma_ok(cin, K * cout) else 0
+                assert L.pcc_convt_packed_elems(K, cin, cout) == wt, (K, cin, cout)
+                if wt > 0:
+                    assert L.pcc_convt_pack_weights(ptr, K, cin, cout, ptr, wt - 1, None) == EWS
+                # thin two-pass form: projection buffer t[K*cout][n_in]
+                if cout <= 4 and cin in (4, 8, 16, 32, 64) and K * cout * cin * 4 <= 48 * 1024:
+                    assert L.pcc_conv_ws_bytes(1000, K, cin, cout) >= K * cout * 1000 * 4
+    for c in GRID:
+        want = c * _cout_pad(c) if _mfma_ok(c, c) else 0
+        assert L.pcc_gdn_packed_elems(c) == want, c
+        if want:
+            assert L.pcc_gdn_pack(ptr, ptr, c, 1e-6, ptr, want - 1, ptr, None) == EWS
+            # the round-1 failure: the conv query of the same shape can be smaller than the GDN layout -> now refused
+            conv_q = L.pcc_conv_packed_elems(1, c, c)
+            if conv_q < want:
+                assert L.pcc_gdn_pack(ptr, ptr, c, 1e-6, ptr, conv_q, ptr, None) == EWS
+    assert L.pcc_conv_packed_elems(1, 16, 16) < L.pcc_gdn_packed_elems(16)      # the exact round-1 case
+    assert checked > 100

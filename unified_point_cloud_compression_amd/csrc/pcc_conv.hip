@@ -888,10 +888,14 @@ __global__ void k_pack_thin(const float* __restrict__ W, int K, int cin, int cou
 }
 
 extern "C" int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
-                                     void* stream) {
+                                     int64_t packed_cap, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(W && packed && K >= 1 && K <= MAXK && cin >= 1 && cout >= 1, "pcc_conv_pack_weights: bad arguments");
   const int64_t total = pcc_conv_packed_elems(K, cin, cout);
+  if (packed_cap < total) {   // a buffer sized with another layout's query (round 1: GDN sized by the conv query) is refused
+    pcc_set_error("pcc_conv_pack_weights: packed buffer holds %lld floats, the layout needs %lld", (long long)packed_cap, (long long)total);
+    return PCC_EWS;
+  }
   const unsigned g = (unsigned)pcc_cdiv(total > 0 ? total : 1, 256);
   switch (conv_kind(K, cin, cout)) {
     case KIND_MFMA: k_pack_mfma<<<g, 256, 0, s>>>(W, K, cin, cout, cout_pad_for(cout), cb_log2_for(cin), packed); break;
@@ -1489,11 +1493,15 @@ extern "C" int64_t pcc_convt_packed_elems(int32_t K, int32_t cin, int32_t cout) 
 }
 
 extern "C" int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
-                                      void* stream) {
+                                      int64_t packed_cap, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(W && packed && K >= 1 && K <= MAXK_T && cin >= 1 && cout >= 1, "pcc_convt_pack_weights: bad arguments");
   PCC_REQUIRE(mfma_ok(cin, K * cout), "pcc_convt: unsupported shape cin=%d (needs 4, 8, 16 or a multiple of 32)", cin);
   const int64_t total = pcc_convt_packed_elems(K, cin, cout);
+  if (packed_cap < total) {
+    pcc_set_error("pcc_convt_pack_weights: packed buffer holds %lld floats, the layout needs %lld", (long long)packed_cap, (long long)total);
+    return PCC_EWS;
+  }
   k_pack_convt<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(W, K, cin, cout, K * cout, cout_pad_for(K * cout),
                                                              cb_log2_for(cin), packed);
   PCC_LAUNCH_CHECK();
@@ -1710,14 +1718,18 @@ __global__ void k_gdn_pack(const float* __restrict__ beta_raw, const float* __re
 extern "C" int64_t pcc_gdn_packed_elems(int32_t c) { return mfma_ok(c, c) ? (int64_t)c * cout_pad_for(c) : 0; }
 
 extern "C" int pcc_gdn_pack(const float* beta_raw, const float* gamma_raw, int32_t c, float beta_min, float* packed,
-                            float* beta_eff, void* stream) {
+                            int64_t packed_cap, float* beta_eff, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(beta_raw && gamma_raw && packed && beta_eff, "pcc_gdn_pack: NULL array");
   PCC_REQUIRE(mfma_ok(c, c), "pcc_gdn: channel count %d unsupported (needs 8, 16 or a multiple of 32)", c);
   const double pedestal = 1.0 / 68719476736.0;   // 2^-36
   const float beta_bound = (float)sqrt((double)beta_min + pedestal);
   const float gamma_bound = (float)sqrt(pedestal);
-  const int64_t total = (int64_t)c * cout_pad_for(c);
+  const int64_t total = pcc_gdn_packed_elems(c);
+  if (packed_cap < total) {
+    pcc_set_error("pcc_gdn_pack: packed buffer holds %lld floats, the layout needs %lld", (long long)packed_cap, (long long)total);
+    return PCC_EWS;
+  }
   k_gdn_pack<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(beta_raw, gamma_raw, c, beta_bound, gamma_bound,
                                                            (float)pedestal, cout_pad_for(c), cb_log2_for(c), packed,
                                                            beta_eff);

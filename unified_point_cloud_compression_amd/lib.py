@@ -52,11 +52,11 @@ SIGNATURES = {
     "pcc_coords_expand_grid_csr": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
     "pcc_map_to_dense": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
-    "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _i64, _p]),
     "pcc_conv_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "pcc_conv_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _f32, _p, _sz, _p]),
     "pcc_convt_packed_elems": (_i64, [_i32, _i32, _i32]),
-    "pcc_convt_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "pcc_convt_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _i64, _p]),
     "pcc_convt_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _f32, _p]),
     "pcc_convt_fwd_csr": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p, _i32, _p,
                                     _p]),
@@ -69,7 +69,7 @@ SIGNATURES = {
     "pcc_conv_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_convt_scatter_rows": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_gdn_packed_elems": (_i64, [_i32]),
-    "pcc_gdn_pack": (C.c_int, [_p, _p, _i32, _f32, _p, _p, _p]),
+    "pcc_gdn_pack": (C.c_int, [_p, _p, _i32, _f32, _p, _i64, _p, _p]),
     "pcc_gdn_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p]),
     "pcc_topk_ws_bytes": (_sz, [_i64]),
     "pcc_topk_mask": (C.c_int, [_p, _i64, C.POINTER(_i64), C.POINTER(_i64), _i32, _p, _p, _sz, _p]),

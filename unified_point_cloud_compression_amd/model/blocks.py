@@ -29,7 +29,7 @@ class MinkowskiGDN(GDN):
             self._packed = torch.empty(n, dtype=torch.float32, device=dev)
             self._beta_eff = torch.empty(c, dtype=torch.float32, device=dev)
             L.call("pcc_gdn_pack", L.ptr(self.beta.detach().contiguous()), L.ptr(self.gamma.detach().contiguous()), c,
-                   float(self.beta_min), L.ptr(self._packed), L.ptr(self._beta_eff), L.stream())
+                   float(self.beta_min), L.ptr(self._packed), self._packed.numel(), L.ptr(self._beta_eff), L.stream())
             self._tag = tag
         return self._packed, self._beta_eff
 

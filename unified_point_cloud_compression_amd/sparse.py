@@ -448,7 +448,7 @@ class PackedConv:
             if n <= 0:
                 raise L.PccError(f"unsupported convolution shape K={K} cin={cin} cout={cout}")
             self.packed = torch.empty(n, dtype=torch.float32, device=w.device)
-            L.call(pre + "_pack_weights", L.ptr(w3), K, cin, cout, L.ptr(self.packed), L.stream())
+            L.call(pre + "_pack_weights", L.ptr(w3), K, cin, cout, L.ptr(self.packed), self.packed.numel(), L.stream())
             self.tag = tag
         return self.packed
 

@@ -112,19 +112,27 @@ def account_flops(model, pc, q):
         calls.append((int(csr[0][n_out].item()), K, cin, cout, n_out, feats.shape[0]))  # pairs of the map (full expansion: n_in*K)
         return orig_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope, **kw)
 
-    orig_r = S.convt_forward_rows
+    orig_r, orig_h = S.convt_forward_rows, S.conv_head_forward
 
     def spy_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
         calls.append((int(csr[0][n_out].item()), K, cin, cout, n_out, feats.shape[0]))
         return orig_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope)
 
-    S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr, S.convt_forward_rows = True, spy, spy_t, spy_c, spy_r
+    def spy_h(feats, packed_w0, bias0, cmid, w2, bias2, cset, kmap):    # fused head: the cin -> cmid convolution is the MFMA launch
+        calls.append((kmap, 27, feats.shape[1], cmid, feats.shape[0], feats.shape[0]))
+        return orig_h(feats, packed_w0, bias0, cmid, w2, bias2, cset, kmap)
+
+    names = ("conv_forward", "convt_forward", "convt_forward_csr", "convt_forward_rows", "conv_head_forward")
+    S.COUNT_PAIRS = True
+    for nme, f in zip(names, (spy, spy_t, spy_c, spy_r, spy_h)):
+        setattr(S, nme, f)
     try:
         step(model, pc, q)
         torch.cuda.synchronize()
     finally:
-        S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr, S.convt_forward_rows = (
-            False, orig, orig_t, orig_c, orig_r)
+        S.COUNT_PAIRS = False
+        for nme, f in zip(names, (orig, orig_t, orig_c, orig_r, orig_h)):
+            setattr(S, nme, f)
     flops, launches, pairs_total, alg_bytes = 0.0, 0, 0, 0.0
     for kmap, K, cin, cout, n_out, n_in in calls:
         if not mfma_shape(cin, cout):

@@ -182,12 +182,36 @@ int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows
  *  model/transforms.py:33-43,127-166; model/entropy_models.py:178-190.)
  * Weights are consumed in a packed layout produced once per parameter update.
  * ---------------------------------------------------------------------------------------- */
+/* MFMA-path arithmetic: 1 (default; env PCC_MFMA_SPLIT) evaluates every fp32 product on the bf16 matrix pipe from an
+ * exact three-way bf16 split of both operands (six cross terms, fp32 accumulation: fp32 accuracy at 2.67x the fp32-MFMA
+ * rate); 0 selects the fp32-input MFMA kernels.  Process-wide switch (tests compare both). */
+int pcc_set_mfma_split(int32_t on);
 int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
 /* W: ME layout [K, cin, cout] row-major (state_dict `kernel`).  packed_cap: floats available at
  * `packed`; a buffer smaller than pcc_conv_packed_elems(K, cin, cout) is refused (PCC_EWS), never written past. */
 int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
                           int64_t packed_cap, void* stream);
 size_t pcc_conv_ws_bytes(int64_t n_in, int32_t K, int32_t cin, int32_t cout);
+/* Occupancy head `predict_i` (model/transforms.py:141-160) in one pass over the features:
+ *   logits = conv_k3(relu(conv_k3(x; W0, b0)); W2, b2),  W0: cin -> cmid (4 < cmid <= 16), W2: cmid -> 1.
+ * packed_w0: pcc_conv_pack_weights(27, cin, cmid) layout; w2: the second kernel as [27][cmid] (its
+ * pcc_conv_pack_weights(27, cmid, 1) layout); hdr/nbr: the canonical 3x3x3 map of the set onto itself;
+ * tiles/n_tiles: optional band-ordered tile table (pcc_band_tiles_build) or both NULL; ws: pcc_conv_head_ws_bytes(n). */
+int pcc_conv_head_supported(int32_t cin, int32_t cmid);
+size_t pcc_conv_head_ws_bytes(int64_t n);
+int pcc_conv_head_fwd(const float* feat, int64_t n, int32_t cin, const float* packed_w0, const float* bias0 /*nullable*/,
+                      int32_t cmid, const float* w2, const float* bias2 /*nullable [1]*/, const int32_t* hdr,
+                      const int32_t* nbr, const int32_t* tiles, const int32_t* n_tiles, float* logits, void* ws,
+                      size_t ws_bytes, void* stream);
+/* Band-ordered tiles (<= 16 consecutive canonical rows each, word = row0 | (rows-1) << 27) of a single-batch canonical
+ * set for the stencil kernels: y cut into `nbands` bands, tiles numbered band-major then x ascending, so that a
+ * contiguous tile range sweeps x inside one band and the dx = +-1 neighbour slabs stay in an XCD's L2.
+ * lo_x/lo_y: smallest coordinate per axis, nx/ny: lattice cells per axis at pitch ts.  n < 2^27. */
+int64_t pcc_band_tiles_cap(int64_t n, int32_t nx, int32_t nbands);
+size_t pcc_band_tiles_ws_bytes(int32_t nx, int32_t nbands);
+int pcc_band_tiles_build(const int64_t* keys, int64_t n, int32_t lo_x, int32_t nx, int32_t lo_y, int32_t ny, int32_t ts,
+                         int32_t nbands, int32_t* tiles, int64_t tiles_cap, int32_t* n_tiles /*device*/, void* ws,
+                         size_t ws_bytes, void* stream);
 int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                  const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* hdr,
                  const int32_t* nbr, const int32_t* rows, int64_t n_out, float* out, int32_t act,

@@ -31,11 +31,12 @@ def test_size_queries_are_pure_host_functions():
     L = lib.load()
     assert L.pcc_sort_ws_bytes(1000) > 8000 and L.pcc_map_nbr_elems(1000, 5, 1, 0) == 125000
     assert L.pcc_map_nbr_elems(1000, 5, 2, 1) == 27000 and L.pcc_map_nbr_elems(1000, 2, 2, 1) == 1000
-    assert L.pcc_conv_packed_elems(125, 128, 128) == 125 * 128 * 128
-    assert L.pcc_conv_packed_elems(27, 192, 192) == 27 * 192 * 256            # padded to the 128-wide column tile
+    assert L.pcc_conv_packed_elems(125, 128, 128) == 125 * 128 * 128 * 5 // 2   # fp32 image + three bf16 planes
+    assert L.pcc_conv_packed_elems(27, 192, 192) == 27 * 192 * 256 * 5 // 2     # padded to the 128-wide column tile
+    assert L.pcc_conv_packed_elems(125, 4, 128) == 125 * 4 * 128                # narrow inputs: fp32 image only
     assert L.pcc_conv_packed_elems(27, 24, 24) == 0                           # unsupported shape is reported, not guessed
-    assert L.pcc_convt_packed_elems(125, 128, 32) == 128 * 4096
-    assert L.pcc_gdn_packed_elems(128) == 128 * 128 and L.pcc_gdn_packed_elems(24) == 0
+    assert L.pcc_convt_packed_elems(125, 128, 32) == 128 * 4096 * 5 // 2
+    assert L.pcc_gdn_packed_elems(128) == 128 * 128 * 5 // 2 and L.pcc_gdn_packed_elems(24) == 0
 
 
 def test_no_cpu_fallback():
@@ -77,7 +78,12 @@ def _layout_extent(K, cin, cout):
         return K * cin * cout
     if cout <= 16 and cin in (16, 32, 64) and K * 16 * (cin + 4) * 4 <= 64 * 1024:
         return K * 16 * cin
-    return K * cin * _cout_pad(cout) if _mfma_ok(cin, cout) else 0
+    return _mfma_total(K * cin * _cout_pad(cout), cin) if _mfma_ok(cin, cout) else 0
+
+
+def _mfma_total(fp32_elems, cin):
+    """MFMA weight image: fp32 layout, plus (cin a multiple of 32) three bf16 planes of the split path = 1.5x floats."""
+    return fp32_elems + fp32_elems // 2 * 3 if cin % 32 == 0 else fp32_elems
 
 
 def test_packed_size_queries_cover_what_the_pack_kernels_write():
@@ -101,7 +107,7 @@ def test_packed_size_queries_cover_what_the_pack_kernels_write():
                     assert L.pcc_conv_pack_weights(ptr, K, cin, cout, ptr, got - 1, None) == EWS
                     checked += 1
                 # generative transpose, input-stationary: one flat [cin, K*cout] GEMM operand
-                wt = cin * _cout_pad(K * cout) if _mfma_ok(cin, K * cout) else 0
+                wt = _mfma_total(cin * _cout_pad(K * cout), cin) if _mfma_ok(cin, K * cout) else 0
                 assert L.pcc_convt_packed_elems(K, cin, cout) == wt, (K, cin, cout)
                 if wt > 0:
                     assert L.pcc_convt_pack_weights(ptr, K, cin, cout, ptr, wt - 1, None) == EWS
@@ -109,7 +115,7 @@ def test_packed_size_queries_cover_what_the_pack_kernels_write():
                 if cout <= 4 and cin in (4, 8, 16, 32, 64) and K * cout * cin * 4 <= 48 * 1024:
                     assert L.pcc_conv_ws_bytes(1000, K, cin, cout) >= K * cout * 1000 * 4
     for c in GRID:
-        want = c * _cout_pad(c) if _mfma_ok(c, c) else 0
+        want = _mfma_total(c * _cout_pad(c), c) if _mfma_ok(c, c) else 0
         assert L.pcc_gdn_packed_elems(c) == want, c
         if want:
             assert L.pcc_gdn_pack(ptr, ptr, c, 1e-6, ptr, want - 1, ptr, None) == EWS

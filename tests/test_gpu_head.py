@@ -1,0 +1,100 @@
+"""Occupancy head in one pass (`predict_i`, reference `model/transforms.py:141-160`): conv k3 -> ReLU -> conv k3 -> logit
+with the hidden features kept on chip (`pcc_conv_head_fwd`), and the band-ordered tile table its stencil kernel walks
+(`pcc_band_tiles_build`), against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as co, ops
+from tests.util import dev, t, n, cloud_keys, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _cs(keys, ts):
+    from unified_point_cloud_compression_amd import sparse as S
+    C = co.unpack_keys(keys)
+    return S.CoordSet(t(keys), len(keys), ts, S.Bounds(0, C[:, 1:].min(0), C[:, 1:].max(0)))
+
+
+@pytest.fixture()
+def small_bands():
+    from unified_point_cloud_compression_amd import sparse as S
+    old = S.BAND_MIN_ROWS, S.BAND_COUNT
+    S.BAND_MIN_ROWS, S.BAND_COUNT = 1, 5
+    yield
+    S.BAND_MIN_ROWS, S.BAND_COUNT = old
+
+
+@pytest.mark.parametrize("ts,shift", [(1, 0), (2, -6)])
+def test_band_tiles_partition_the_rows(ts, shift, small_bands):
+    """Every row in exactly one tile; a tile = <= 16 consecutive rows of one (y-band, x) run; tiles are numbered band-major
+    with x ascending inside a band."""
+    keys = cloud_keys(7, 37, 0.2, ts)
+    C = co.unpack_keys(keys)
+    C[:, 1:] += shift * ts                                       # negative coordinates too
+    keys = np.unique(co.pack_keys(C))
+    C = co.unpack_keys(keys)
+    cs = _cs(keys, ts)
+    tiles, n_tiles = cs.band_tiles()
+    nt = int(n_tiles.item())
+    tw = n(tiles)[:nt].astype(np.int64)
+    row0, cnt = tw & 0x07FFFFFF, ((tw >> 27) & 31) + 1
+    assert cnt.max() <= 16 and cnt.min() >= 1
+    cover = np.zeros(len(keys), np.int32)
+    ny = (C[:, 2].max() - C[:, 2].min()) // ts + 1
+    band_h = -(-ny // 5)
+    band_of = ((C[:, 2] - C[:, 2].min()) // ts) // band_h
+    order = []
+    for r0, c in zip(row0, cnt):
+        cover[r0:r0 + c] += 1
+        assert len(set(C[r0:r0 + c, 1])) == 1 and len(set(band_of[r0:r0 + c])) == 1
+        order.append((band_of[r0], C[r0, 1], r0))
+    assert np.all(cover == 1)
+    assert order == sorted(order)
+
+
+@pytest.mark.parametrize("cin,cmid,bands", [(32, 16, True), (32, 16, False), (16, 8, True), (32, 8, False)])
+def test_fused_head_matches_oracle(cin, cmid, bands, small_bands):
+    from unified_point_cloud_compression_amd import sparse as S
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    from unified_point_cloud_compression_amd.MinkowskiEngine.sparse_tensor import SparseTensor
+    from unified_point_cloud_compression_amd.model.transforms import SparseSynthesisTransform as G
+    rng = np.random.default_rng(cin + cmid)
+    keys = cloud_keys(11, 30, 0.25, 1)
+    keys = keys[: len(keys) - (len(keys) % 16) + 5]              # a ragged last tile
+    cs = _cs(keys, 1)
+    x = rng.standard_normal((len(keys), cin)).astype(np.float32)
+    c0 = ME.MinkowskiConvolution(cin, cmid, kernel_size=3, stride=1, bias=True, dimension=3).to(dev())
+    c2 = ME.MinkowskiConvolution(cmid, 1, kernel_size=3, stride=1, bias=True, dimension=3).to(dev())
+    with torch.no_grad():
+        c0.kernel.mul_(3.0)
+        c2.kernel.mul_(3.0)
+    head = torch.nn.Sequential(c0, ME.MinkowskiReLU(), c2)
+    nbr = co.kernel_map(keys, keys, 3, 1)
+    h = ops.relu(ops.conv(x, n(c0.kernel), n(c0.bias), nbr))
+    want = ops.conv(h, n(c2.kernel), n(c2.bias), nbr)
+    old = S.BAND_TILES, S.HEAD_FUSED
+    try:
+        S.BAND_TILES, S.HEAD_FUSED = bands, True
+        assert (cs.band_tiles() is not None) == bands
+        with torch.no_grad():
+            xt = SparseTensor._from_canonical(cs, t(x))
+            got = G._predict(head, xt)
+            S.HEAD_FUSED = False
+            ref = G._predict(head, xt)
+            seq = head(xt)                                        # plain module calls
+    finally:
+        S.BAND_TILES, S.HEAD_FUSED = old
+    assert_close(n(got.F), want, what="fused head vs oracle")
+    assert_close(n(ref.F), want, what="layer-wise head vs oracle")
+    assert_close(n(seq.F), want, what="Sequential head vs oracle")
+    assert float((got.F - ref.F).abs().max().item()) <= 1e-5
+    # deterministic: bit-identical on a second evaluation
+    with torch.no_grad():
+        S.BAND_TILES = bands
+        try:
+            again = G._predict(head, SparseTensor._from_canonical(cs, t(x)))
+        finally:
+            S.BAND_TILES = old[0]
+    assert torch.equal(again.F, got.F)

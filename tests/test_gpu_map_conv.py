@@ -265,3 +265,45 @@ def test_unsupported_shape_fails_loudly():
         S.PackedConv().get(torch.nn.Parameter(torch.zeros(27, 24, 24, device=dev())))
     with pytest.raises(L.PccError):
         L.ptr(torch.zeros(4))      # CPU tensors never reach the library
+
+
+@pytest.mark.parametrize("cin,cout,ks", [(128, 128, 3), (192, 256, 3), (128, 64, 5), (32, 32, 3)])
+def test_split_path_accuracy(cin, cout, ks):
+    """The default MFMA path evaluates fp32 products on the bf16 matrix pipe from an exact 3-way bf16 split of both
+    operands (six cross terms, fp32 accumulation).  Its error against a float64 evaluation must be at the level of the
+    fp32-input MFMA path's own rounding error -- fp32 accuracy, not bf16 accuracy -- and both must meet the 1e-4 bar."""
+    from unified_point_cloud_compression_amd import sparse as S, lib as L
+    keys = cloud_keys(31, 26, 0.15, 1)
+    cs = _cs(keys, 1)
+    rng = np.random.default_rng(cin * 7 + cout)
+    f = (rng.standard_normal((len(keys), cin)) * np.exp(rng.uniform(-3, 3, (len(keys), cin)))).astype(np.float32)   # 3 decades of magnitudes
+    K = ks ** 3
+    W = (rng.standard_normal((K, cin, cout)) / np.sqrt(cin * 10)).astype(np.float32)
+    b = rng.standard_normal((1, cout)).astype(np.float32)
+    m = cs.kernel_map(cs, ks)
+    nbr = co.kernel_map(keys, keys, ks, 1)
+    want64 = np.zeros((len(keys), cout)) + b.astype(np.float64)
+    f64, W64 = f.astype(np.float64), W.astype(np.float64)
+    for k in range(K):
+        o = np.nonzero(nbr[k] >= 0)[0]
+        want64[o] += f64[nbr[k, o]] @ W64[k]
+    scale = np.abs(want64).max()
+    pk = S.PackedConv().get(torch.nn.Parameter(t(W)))
+    old_pair = S.PAIR_MIN_K
+    S.PAIR_MIN_K = 1 << 30
+    try:
+        got_split = n(S.conv_forward(t(f), pk, t(b), K, cin, cout, m, cs.n))
+        L.call("pcc_set_mfma_split", 0)
+        got_fp32 = n(S.conv_forward(t(f), pk, t(b), K, cin, cout, m, cs.n))
+    finally:
+        L.call("pcc_set_mfma_split", 1)
+        S.PAIR_MIN_K = old_pair
+    e_split = np.abs(got_split - want64).max() / scale
+    e_fp32 = np.abs(got_fp32 - want64).max() / scale
+    rms_split = np.sqrt(((got_split - want64) ** 2).mean()) / scale
+    rms_fp32 = np.sqrt(((got_fp32 - want64) ** 2).mean()) / scale
+    print(f"cin={cin} cout={cout} K={K}: max err / scale split {e_split:.2e} fp32 {e_fp32:.2e}; rms split {rms_split:.2e} fp32 {rms_fp32:.2e}")
+    assert e_fp32 < 5e-6 and e_split < 5e-6                      # both far inside the 1e-4 bar
+    assert rms_split <= 3.0 * rms_fp32 + 1e-8                    # fp32-level error, not bf16-level (which would be ~1e-3)
+    assert_close(got_split, want64, what="split path vs float64")
+    assert not np.array_equal(got_split, got_fp32) or cin < 32   # the two paths really are different kernels

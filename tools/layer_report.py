@@ -64,7 +64,20 @@ def spy_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
     return out
 
 
+orig_h = S.conv_head_forward
+
+
+def spy_h(feats, packed_w0, bias0, cmid, w2, bias2, cset, kmap):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = orig_h(feats, packed_w0, bias0, cmid, w2, bias2, cset, kmap)
+    e1.record()
+    calls.append((kmap, 27, feats.shape[1], cmid, feats.shape[0], feats.shape[0], e0, e1))     # + the cmid -> 1 projection and gather
+    return out
+
+
 S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr, S.convt_forward_rows = True, spy, spy_t, spy_c, spy_r
+S.conv_head_forward = spy_h
 bench.step(model, pc, q)
 torch.cuda.synchronize()
 tot_ms = tot_fl = 0

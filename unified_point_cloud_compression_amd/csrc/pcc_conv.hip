@@ -25,6 +25,7 @@ static constexpr int MAXK = 128;    // kernel offsets per segment (K <= 125)
 static constexpr int MAXK_T = 512;  // offsets of the input-stationary transposed conv (a flat GEMM: 7^3 composites fit)
 
 enum { MODE_CONV = 0, MODE_GDN = 1, MODE_IGDN = 2 };
+__device__ inline float act1(float v, int act, float slope);
 
 struct ConvArgs {
   const float* feat;      // [n_in, cin]
@@ -40,6 +41,7 @@ struct ConvArgs {
   const int* pair_in = nullptr;   // pair mode (pcc_conv_fwd_pairs): input row of every (padded) pair, -1 = padding
   const int* tile_k = nullptr;    // pair mode: kernel offset of each 128-pair tile
   const long long* n_tiles = nullptr;   // pair mode: device count of tiles (the grid is an upper bound)
+  const unsigned char* featb = nullptr; // split path: bf16 planes of feat, [n_in][cin/32][3][32] (k_feat_split)
   int cin, cout, cout_pad;
   int cb_log2;            // log2(CB), CB = min(cin, 32)
   int ppo;                // pieces per offset = cin / CB
@@ -77,8 +79,16 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
   const int cpx = gridDim.x >> 3;                         // grid is a multiple of 8
   const int wid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
   const int gy = a.cout_pad / BN;
-  const int tile_id = wid / gy;
-  const int colblock = (wid - tile_id * gy) * BN;
+  int tile_id = wid / gy;
+  int colblock = (wid - tile_id * gy) * BN;
+  if (a.hdr == nullptr && a.pair_in == nullptr && gy > 8) {
+    // dense GEMM with many column blocks (generative transposed convs: [n_in, cin] x [cin, K*cout], weights > L2):
+    // groups of 8 row tiles sweep the column blocks together, so a block's weights are fetched once per group instead of
+    // once per row tile (the grid covers whole groups, launch_mfma)
+    const int g = wid / (8 * gy), rem = wid - g * 8 * gy;
+    colblock = (rem >> 3) * BN;
+    tile_id = g * 8 + (rem & 7);
+  }
 
   // ---- locate (segment, tile) --------------------------------------------------------------
   int pos0, npos, k_count, koff_begin;
@@ -368,6 +378,367 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The same implicit GEMM on the bf16 matrix pipe at fp32 accuracy ("split" path, cin a multiple of 32).
+//
+// gfx950 runs fp32-input MFMAs at the vector rate (157 TFLOP/s) and bf16-input MFMAs 16 times faster.  Every fp32
+// operand is split EXACTLY into three bf16 values, x = h + m + l (h = rne_bf16(x), m = rne_bf16(x - h),
+// l = x - h - m: 8 + 8 + 8 mantissa bits and a sign each, both subtractions exact), and a product is evaluated as the
+// six cross terms of first and second order,
+//     x*w ~= l*h' + h*l' + m*m' + m*h' + h*m' + h*h'        (dropped: m*l' + l*m' + l*l' <= 2^-23 |x*w|)
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- the same fp32 accumulation the
+// fp32 MFMA performs.  Six bf16 MFMAs of K = 16 replace eight fp32 MFMAs of K = 2 at a quarter of the cycles each
+// (MI355X_MICROARCH.md: 32 against 64 cycles per SIMD): 2.67x the matrix throughput, error at the level of fp32
+// rounding (tests/test_gpu_map_conv.py::test_split_path_accuracy compares both paths with a float64 evaluation).
+// Weights are split once when packed (three bf16 planes behind the fp32 image); the feature rows of a convolution's
+// input are split by one pass of k_feat_split into planes [row][cin/32][3][32] (library scratch), so the MFMA kernel
+// stages pure 16-byte copies.  (First version: split while staging, 5.5 VALU operations per element -- SQ counters
+// showed 5.4 VALU instructions per MFMA and the SIMD issue-bound at 33 % MFMA utilisation; and for the shallow
+// generative GEMMs every column block repeated the split of the same rows.)
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__host__ __device__ inline long long bf_plane_elems(long long fp32_elems) { return fp32_elems / 2 * 3; }   // floats holding 3 bf16 planes
+
+__device__ __forceinline__ void bf_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const f32x2v v = {x0, x1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+  const f32x2v r1 = {x0 - __builtin_bit_cast(float, h << 16), x1 - __builtin_bit_cast(float, h & 0xFFFF0000u)};
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2v));
+  const f32x2v r2 = {r1.x - __builtin_bit_cast(float, m << 16), r1.y - __builtin_bit_cast(float, m & 0xFFFF0000u)};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2v));
+}
+
+// fp32 packed image [rows][32] -> bf16 planes [rows][3][32]
+__global__ void k_split_packed(const float* __restrict__ src, long long pairs, unsigned* __restrict__ dst) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one pair of consecutive channels
+  if (t >= pairs) return;
+  const long long row = t >> 4;
+  const int cp = (int)(t & 15);
+  unsigned h, m, l;
+  bf_split2(src[2 * t], src[2 * t + 1], h, m, l);
+  unsigned* d = dst + row * 48 + cp;
+  d[0] = h; d[16] = m; d[32] = l;
+}
+
+// feature rows fp32 [n][c] -> bf16 planes [n][c/32][3][32] (of |x| for the GDN modes: the split is odd, so the planes of
+// -x are the negated planes of x).  One pass per convolution input, so that the MFMA kernel stages pure copies.
+__global__ void k_feat_split(const float* __restrict__ x, long long pairs, int cpairs, int take_abs, unsigned* __restrict__ dst) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one pair of consecutive channels
+  if (t >= pairs) return;
+  const long long row = t / cpairs;
+  const int cp = (int)(t - row * cpairs);
+  float2 v = reinterpret_cast<const float2*>(x)[t];
+  if (take_abs) { v.x = fabsf(v.x); v.y = fabsf(v.y); }
+  unsigned h, m, l;
+  bf_split2(v.x, v.y, h, m, l);
+  unsigned* d = dst + (row * (cpairs >> 4) + (cp >> 4)) * 48 + (cp & 15);
+  d[0] = h; d[16] = m; d[32] = l;
+}
+
+// Grow-only device scratch of the library (per device; stream-ordered reuse on the caller's stream): the bf16 planes of
+// the current convolution's input.  The only memory libpcc_hip owns.
+static void* g_scratch[64];
+static size_t g_scratch_bytes[64];
+static int lib_scratch(size_t bytes, void** out) {
+  int dev = 0;
+  PCC_CHECK_HIP(hipGetDevice(&dev));
+  dev &= 63;
+  if (g_scratch_bytes[dev] < bytes) {
+    if (g_scratch[dev]) { PCC_CHECK_HIP(hipDeviceSynchronize()); PCC_CHECK_HIP(hipFree(g_scratch[dev])); g_scratch[dev] = nullptr; g_scratch_bytes[dev] = 0; }
+    const size_t want = bytes + bytes / 4 + (1 << 20);
+    PCC_CHECK_HIP(hipMalloc(&g_scratch[dev], want));
+    g_scratch_bytes[dev] = want;
+  }
+  *out = g_scratch[dev];
+  return PCC_OK;
+}
+static int make_planes(ConvArgs& a, bool take_abs, hipStream_t s) {
+  void* p = nullptr;
+  PCC_TRY(lib_scratch((size_t)a.n_in * a.cin * 6, &p));
+  const long long pairs = (long long)a.n_in * a.cin / 2;
+  k_feat_split<<<(unsigned)pcc_cdiv(pairs, 256), 256, 0, s>>>(a.feat, pairs, a.cin / 2, take_abs ? 1 : 0, (unsigned*)p);
+  PCC_LAUNCH_CHECK();
+  a.featb = (const unsigned char*)p;
+  return PCC_OK;
+}
+
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(BN <= 128 && BM <= 128, "one feature row and one weight row per thread (pair)");
+  // LDS images [row][13 x 16 B]: the 12 units (plane, slot) of a row's 192-byte piece plus one unit of padding.  Staging
+  // writes go 8 consecutive units at a time (contiguous), a fragment read takes one unit of 16 different rows: row * 52
+  // dwords mod 64 is a permutation of the bank quads over the rows of any ds_read_b128 lane group.  Conflict-free both ways.
+  constexpr int LDU = 13;
+  __shared__ __attribute__((aligned(16))) uint4 As[BM * LDU];
+  __shared__ __attribute__((aligned(16))) uint4 Bs[BN * LDU];
+  __shared__ unsigned char act_flag[MAXK];
+  __shared__ unsigned char act_list[MAXK];
+  __shared__ unsigned char act_kid[MAXK];
+  __shared__ int s_nact;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cpx = gridDim.x >> 3;
+  const int wid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  const int gy = a.cout_pad / BN;
+  int tile_id = wid / gy;
+  int colblock = (wid - tile_id * gy) * BN;
+  if (a.hdr == nullptr && a.pair_in == nullptr && gy > 8) {
+    // dense GEMM with many column blocks (generative transposed convs: [n_in, cin] x [cin, K*cout], weights > L2):
+    // groups of 8 row tiles sweep the column blocks together, so a block's weights are fetched once per group instead of
+    // once per row tile (the grid covers whole groups, launch_mfma)
+    const int g = wid / (8 * gy), rem = wid - g * 8 * gy;
+    colblock = (rem >> 3) * BN;
+    tile_id = g * 8 + (rem & 7);
+  }
+
+  int pos0, npos, k_count, koff_begin;
+  long long seg_pos_count;
+  const int* seg_nbr = nullptr;
+  const bool pair_mode = (a.pair_in != nullptr);
+  const bool identity = (a.hdr == nullptr) && !pair_mode;
+  if (pair_mode) {
+    if (tile_id >= *a.n_tiles) return;
+    pos0 = tile_id * BM; npos = BM; k_count = 1; koff_begin = 0; seg_pos_count = 0;
+    seg_nbr = a.pair_in + pos0;
+  } else if (identity) {
+    const long long p0 = (long long)tile_id * BM;
+    if (p0 >= a.n_out) return;
+    pos0 = (int)p0;
+    npos = (int)min((long long)BM, a.n_out - p0);
+    k_count = 1; koff_begin = 0; seg_pos_count = a.n_out;
+  } else {
+    const int nseg = a.hdr[HDR_NSEG];
+    int tile = tile_id, sgi = 0;
+    bool found = false;
+    int pb = 0, pc = 0;
+    for (; sgi < nseg; ++sgi) {
+      const int* sg = a.hdr + HDR_SEG0 + sgi * SEG_WORDS;
+      pb = sg[SEG_POS_BEGIN]; pc = sg[SEG_POS_COUNT];
+      const int tiles = (pc + BM - 1) / BM;
+      if (tile < tiles) { found = true; break; }
+      tile -= tiles;
+    }
+    if (!found) return;
+    const int* sg = a.hdr + HDR_SEG0 + sgi * SEG_WORDS;
+    k_count = sg[SEG_K_COUNT];
+    koff_begin = sg[SEG_KOFF_BEGIN];
+    const long long nb = ((long long)(unsigned)sg[SEG_NBR_LO]) | ((long long)sg[SEG_NBR_HI] << 32);
+    seg_nbr = a.nbr + nb;
+    seg_pos_count = pc;
+    const int local0 = tile * BM;
+    pos0 = pb + local0;
+    npos = min(BM, pc - local0);
+    seg_nbr += local0;
+  }
+
+  if (pair_mode) {
+    if (tid == 0) { act_list[0] = 0; act_kid[0] = (unsigned char)a.tile_k[tile_id]; s_nact = 1; }
+  } else if (identity) {
+    if (tid == 0) { act_list[0] = 0; act_kid[0] = 0; s_nact = 1; }
+  } else {
+    for (int j = w; j < k_count; j += 4) {
+      bool any = false;
+      for (int r = lane; r < npos; r += 64) any |= (seg_nbr[(long long)j * seg_pos_count + r] >= 0);
+      const unsigned long long mk = __ballot(any);
+      if (lane == 0) act_flag[j] = mk ? 1 : 0;
+    }
+    __syncthreads();
+    if (w == 0) {
+      int nn = 0;
+      for (int j0 = 0; j0 < k_count; j0 += 64) {
+        const int u = j0 + lane;
+        const int j = (u < k_count) ? a.hdr[HDR_ORDER + koff_begin + u] : 0;
+        const bool f = (u < k_count) && act_flag[j];
+        const unsigned long long mk = __ballot(f);
+        if (f) {
+          const int p = nn + __popcll(mk & ((1ull << lane) - 1ull));
+          act_list[p] = (unsigned char)j;
+          act_kid[p] = (unsigned char)a.hdr[HDR_KOFFS + koff_begin + j];
+        }
+        nn += __popcll(mk);
+      }
+      if (lane == 0) s_nact = nn;
+    }
+  }
+  __syncthreads();
+  const int nact = s_nact;
+  const int nchunks = nact * a.ppo;                   // CB = 32: one piece per chunk
+
+  // staging roles: the 16-byte units u = j * 256 + tid of the tile's piece, 12 per row (3 planes x 4 slots), rows contiguous:
+  // consecutive lanes read consecutive 16-byte units of a feature / weight row (coalesced), and write them side by side
+  constexpr int NA = (BM * 12 + 255) / 256, NB = (BN * 12 + 255) / 256;
+  int a_row[NA], a_w[NA], b_row[NB], b_w[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) { const int u = j * 256 + tid; a_row[j] = u / 12; a_w[j] = u - a_row[j] * 12; if (u >= BM * 12) a_row[j] = -1; }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) { const int u = j * 256 + tid; b_row[j] = u / 12; b_w[j] = u - b_row[j] * 12; if (u >= BN * 12) b_row[j] = -1; }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm = w / WN, wn = w % WN;
+  const int half = lane >> 5, r31 = lane & 31;
+
+  const unsigned row_bytes = (unsigned)a.cin * 6u;    // [cin/32][3][32] bf16
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(a.featb), (short)0, (int)(unsigned)((size_t)a.n_in * row_bytes), 0x00020000);
+  const float* wb = a.wp + a.wp_elems;                // bf16 planes behind the fp32 image: [piece][cout_pad][3][32] bf16
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wb), (short)0, (int)(unsigned)((size_t)bf_plane_elems(a.wp_elems) * 4), 0x00020000);
+
+  auto load_rows = [&](int ai, int (&rows)[NA]) {
+    const int slot = act_list[ai];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int rc = min(max(a_row[j], 0), npos - 1);          // tail rows repeat the tile's last row (never stored)
+      rows[j] = identity ? (pos0 + rc) : seg_nbr[(long long)slot * seg_pos_count + rc];
+      if (a_row[j] < 0) rows[j] = -1;
+    }
+  };
+  auto issue = [&](int ai, int cbi, const int (&rows)[NA], uint4 (&av)[NA], uint4 (&bv)[NB]) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const unsigned off = rows[j] >= 0 ? (unsigned)rows[j] * row_bytes + (unsigned)cbi * 192u + (unsigned)a_w[j] * 16u : BUF_OOB;
+      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+    }
+    const unsigned wbase = (unsigned)((act_kid[ai] * a.ppo + cbi) * a.cout_pad + colblock) * 192u;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const unsigned off = b_row[j] >= 0 ? wbase + (unsigned)(j * 256 + tid) * 16u : BUF_OOB;
+      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+    }
+  };
+
+  int rows_cur[NA], rows_nxt[NA];
+  uint4 av[NA], bv[NB];
+  int ai_c = 0, cbi_c = 0, ai_n = 0, cbi_n = 0;
+  if (nchunks > 0) {
+    load_rows(0, rows_cur);
+    issue(0, 0, rows_cur, av, bv);
+    if (nchunks > 1) {
+      ai_n = 1 / a.ppo; cbi_n = 1 - ai_n * a.ppo;
+      if (ai_n != ai_c) load_rows(ai_n, rows_nxt);
+      else {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) rows_nxt[j] = rows_cur[j];
+      }
+    }
+  }
+
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if (a_row[j] >= 0) As[a_row[j] * LDU + a_w[j]] = av[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (b_row[j] >= 0) Bs[b_row[j] * LDU + b_w[j]] = bv[j];
+    __syncthreads();
+    if (c + 1 < nchunks) {          // next chunk's global loads fly during this chunk's MFMAs
+#pragma unroll
+      for (int j = 0; j < NA; ++j) rows_cur[j] = rows_nxt[j];
+      ai_c = ai_n; cbi_c = cbi_n;
+      issue(ai_c, cbi_c, rows_cur, av, bv);
+      if (c + 2 < nchunks) {
+        ai_n = (c + 2) / a.ppo; cbi_n = (c + 2) - ai_n * a.ppo;
+        if (ai_n != ai_c) load_rows(ai_n, rows_nxt);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs, not next to its use
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[p][i] = __builtin_bit_cast(bf16x8, As[((wm * TM + i) * 32 + r31) * LDU + p * 4 + ks * 2 + half]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bf[p][j] = __builtin_bit_cast(bf16x8, Bs[((wn * TN + j) * 32 + r31) * LDU + p * 4 + ks * 2 + half]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {           // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: bias, activation (or GDN), store -------------------------------------------
+  // Full tiles written to consecutive rows take a branch-free path: one base pointer per lane, the activation chosen
+  // once per tile.  (The general loop below costs ~50 instructions per element -- row-list lookups, tail checks and
+  // the activation switch for each of the 64 values a lane holds -- which is as much as the whole MFMA phase of a
+  // 128-deep GEMM tile.)
+  if (!a.rows && npos == BM) {
+    const size_t lane_off = (size_t)(pos0 + wm * TM * 32 + 4 * half) * a.cout + colblock + wn * TN * 32 + r31;
+    float* const lane_out = a.out + lane_off;
+    const float* const lane_x = a.feat + lane_off;             // GDN / IGDN: cin == cout, same element of the input
+    auto store_tile = [&](auto actf) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = colblock + (wn * TN + j) * 32 + r31;
+        if (col >= a.cout) continue;
+        const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const size_t o = (size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * a.cout + j * 32;
+            lane_out[o] = actf(acc[i][j][e] + b, o);
+          }
+      }
+    };
+    if (MODE == MODE_GDN) store_tile([&](float v, size_t o) { return lane_x[o] / v; });
+    else if (MODE == MODE_IGDN) store_tile([&](float v, size_t o) { return lane_x[o] * v; });
+    else if (a.act == PCC_ACT_RELU) store_tile([](float v, size_t) { return fmaxf(v, 0.f); });
+    else if (a.act == PCC_ACT_LEAKY) { const float sl = a.slope; store_tile([sl](float v, size_t) { return v >= 0.f ? v : v * sl; }); }
+    else store_tile([](float v, size_t) { return v; });
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = colblock + (wn * TN + j) * 32 + r31;
+    if (col >= a.cout) continue;
+    const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (r >= npos) continue;
+        const long long orow = a.rows ? a.rows[pos0 + r] : (pos0 + r);
+        float v = acc[i][j][e] + b;
+        if (MODE == MODE_CONV) {
+          if (a.act == PCC_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == PCC_ACT_LEAKY) v = v >= 0.f ? v : v * a.slope;
+        } else {
+          const float x = a.feat[orow * a.cin + col];
+          v = (MODE == MODE_GDN) ? x / v : x * v;
+        }
+        a.out[orow * a.cout + col] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // thin outputs (cout <= 4) or channel counts the MFMA tiling does not take: VALU, gather-bound.
 // Wt layout [K][cout][cin].  LPR lanes share one output position.
 // ------------------------------------------------------------------------------------------
@@ -569,18 +940,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Wave16Args {
   const float* feat; const float* wl; const float* bias; const int* hdr; const int* nbr; const int* rows;
   float* out; long long n_out, n_in; int K, cout, act; float slope;
+  // z-run kernel only: optional tile table (band order, pcc_band_tiles_build) and the fused 16 -> 1 head projection
+  const int* tiles = nullptr; const int* n_tiles = nullptr;
+  const float* w2 = nullptr;      // [27][cout] second convolution of an occupancy head (thin layout), PROJ variant
+  float* t = nullptr;             // [27][n_out] projections t[k][i] = <relu(h_i), w2_k>, PROJ variant
 };
+
+// LDS image of the narrow-output weights: [K][CIN/4][16][4] -- k-quad major, then the 16 output columns, 4 channels
+// each.  A ds_read_b128 is served in groups of 16 lanes and every group holds each column r16 exactly once (lanes
+// {0-3,12-15,20-27}, ... of MI355X_MICROARCH.md's LDS table), so with the column as the fastest 16-byte index the 16
+// lanes of a group always hit 16 different bank quads: conflict-free.  (The round-1 layout [K][16][CIN+4] put the
+// k-quad in the low address bits: SQ_LDS_BANK_CONFLICT = 1/2 SQ_LDS_IDX_ACTIVE, profiles/r01_sq_counters_conv.txt.)
+template <int CIN>
+__device__ __forceinline__ const float* wave16_w(const float* wl_s, int kid, int kq, int r16) {
+  return wl_s + ((kid * (CIN / 4) + kq) * 16 + r16) * 4;
+}
 
 template <int CIN>
 __global__ void __launch_bounds__(512) k_conv_wave16(Wave16Args a) {
-  constexpr int LD = CIN + 4;
   constexpr int G = CIN / 16;
   constexpr int NW = 8;                                            // waves per workgroup
-  extern __shared__ __attribute__((aligned(16))) float wl_s[];   // [K][16][LD]
-  for (int i = threadIdx.x; i < a.K * 16 * (CIN / 4); i += 512) {
-    const int row = i / (CIN / 4), c4 = i - row * (CIN / 4);
-    reinterpret_cast<float4*>(wl_s + row * LD)[c4] = reinterpret_cast<const float4*>(a.wl + (long long)row * CIN)[c4];
-  }
+  extern __shared__ __attribute__((aligned(16))) float wl_s[];   // [K][CIN/4][16][4]
+  for (int i = threadIdx.x; i < a.K * 16 * (CIN / 4); i += 512)
+    reinterpret_cast<float4*>(wl_s)[i] = reinterpret_cast<const float4*>(a.wl)[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
   const bool identity = (a.hdr == nullptr);
@@ -648,7 +1030,7 @@ __global__ void __launch_bounds__(512) k_conv_wave16(Wave16Args a) {
         const int kid = identity ? 0 : a.hdr[HDR_KOFFS + koff_begin + j];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          const float4 w = *reinterpret_cast<const float4*>(wl_s + (kid * 16 + r16) * LD + 16 * g + 4 * q);
+          const float4 w = *reinterpret_cast<const float4*>(wave16_w<CIN>(wl_s, kid, 4 * g + q, r16));
           accA0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].x, w.x, accA0, 0, 0, 0);
           accB0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[g].x, w.x, accB0, 0, 0, 0);
           accA1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].y, w.y, accA1, 0, 0, 0);
@@ -700,25 +1082,40 @@ __device__ __forceinline__ float dpp_f(float v) {
 }
 static constexpr int DPP_SHL1 = 0x101, DPP_SHR1 = 0x111;
 
-template <int CIN>
+template <int CIN, bool PROJ>
 __global__ void __launch_bounds__(512) k_conv_wave16z(Wave16Args a) {
-  constexpr int LD = CIN + 4;
   constexpr int G = CIN / 16;
   constexpr int NW = 8;
-  extern __shared__ __attribute__((aligned(16))) float wl_s[];   // [27][16][LD]
-  for (int i = threadIdx.x; i < 27 * 16 * (CIN / 4); i += 512) {
-    const int row = i / (CIN / 4), c4 = i - row * (CIN / 4);
-    reinterpret_cast<float4*>(wl_s + row * LD)[c4] = reinterpret_cast<const float4*>(a.wl + (long long)row * CIN)[c4];
-  }
+  extern __shared__ __attribute__((aligned(16))) float wl_s[];   // [27][CIN/4][16][4] (+ PROJ: per-wave 16x17 scratch)
+  for (int i = threadIdx.x; i < 27 * 16 * (CIN / 4); i += 512)
+    reinterpret_cast<float4*>(wl_s)[i] = reinterpret_cast<const float4*>(a.wl)[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
   const unsigned spc = (unsigned)a.n_out;                          // one segment: positions = output rows
-  const unsigned total_tiles = (spc + 15) / 16;
+  // tiles of <= 16 consecutive rows: plain 16-row cuts, or the band-ordered table of pcc_band_tiles_build (rows of one
+  // (x, y-band) run per tile, bands outermost: the dx = +-1 neighbours of a band's current x-slab then stay in the
+  // XCD's L2 until that slab is processed itself)
+  const unsigned total_tiles = a.tiles ? (unsigned)*a.n_tiles : (spc + 15) / 16;
   const unsigned cpx = gridDim.x >> 3;
   const unsigned per_xcd = (total_tiles + 7) / 8;
   const unsigned xcd_lo = (blockIdx.x & 7) * per_xcd;
   const unsigned xcd_hi = min(total_tiles, xcd_lo + per_xcd);
-  const float* wl_lane = wl_s + r16 * LD + 4 * q;
+  const float* wl_lane = wl_s + r16 * 4 + q * 64;                  // wave16_w(kid, 4g+q, r16) = wl_lane + (kid*(CIN/4) + 4g) * 64
+
+  // PROJ: B operand of the head's second convolution, out[o] = b2 + sum_k <relu(h[nbr_k(o)]), w2_k>, evaluated as
+  // t[k][i] = <relu(h_i), w2_k> for the tile in registers (one more 16x16x4 MFMA block), so h never goes to memory
+  float w2r[2][4];
+  float* hs = nullptr;
+  if constexpr (PROJ) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 16 * nt + r16, c = 4 * j + q;
+        w2r[nt][j] = (k < 27 && c < a.cout) ? a.w2[k * a.cout + c] : 0.f;
+      }
+    hs = wl_s + 27 * 16 * CIN + (threadIdx.x >> 6) * (16 * 17);
+  }
 
   // One (dx,dy) group of a 16-row tile: the dz=0 rows, and the dz=-+1 rows, each either the neighbouring lane's dz=0
   // row (mask k*) or loaded.  All rows come through buffer loads whose offset is out of range for an absent or
@@ -730,8 +1127,14 @@ __global__ void __launch_bounds__(512) k_conv_wave16z(Wave16Args a) {
   constexpr unsigned OOB = 0xFFFFFF00u;
 
   for (unsigned wt = xcd_lo + (blockIdx.x >> 3) * NW + (threadIdx.x >> 6); wt < xcd_hi; wt += cpx * NW) {
-    const unsigned pos0 = wt * 16;
-    const unsigned r = min(pos0 + r16, spc - 1);                   // tail rows repeat the last row, never stored
+    unsigned pos0, npos;
+    if (a.tiles) {
+      const unsigned tw = (unsigned)a.tiles[wt];
+      pos0 = tw & 0x07FFFFFFu; npos = (tw >> 27) + 1;
+    } else {
+      pos0 = wt * 16; npos = min(16u, spc - pos0);
+    }
+    const unsigned r = pos0 + min((unsigned)r16, npos - 1);        // tail rows repeat the tile's last row, never stored
     const int* nb = a.nbr + r;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
 
@@ -753,7 +1156,7 @@ __global__ void __launch_bounds__(512) k_conv_wave16z(Wave16Args a) {
       }
     };
     auto mfma4 = [&](const float4& x, int slot, int g) {
-      const float4 w = *reinterpret_cast<const float4*>(wl_lane + (slot * 16) * LD + 16 * g);
+      const float4 w = *reinterpret_cast<const float4*>(wl_lane + (slot * (CIN / 4) + 4 * g) * 64);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, w.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, w.y, acc1, 0, 0, 0);
       acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, w.z, acc2, 0, 0, 0);
@@ -800,12 +1203,39 @@ __global__ void __launch_bounds__(512) k_conv_wave16z(Wave16Args a) {
     }
     compute(x, 8);
     // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
-    if (r16 < a.cout) {
-      const float b = a.bias ? a.bias[r16] : 0.f;
+    const float b = (a.bias && r16 < a.cout) ? a.bias[r16] : 0.f;
+    if constexpr (!PROJ) {
+      if (r16 < a.cout) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned row = pos0 + 4 * q + e;
-        if (row < spc) a.out[(size_t)row * a.cout + r16] = act1(acc0[e] + acc1[e] + acc2[e] + acc3[e] + b, a.act, a.slope);
+        for (int e = 0; e < 4; ++e) {
+          const unsigned lr = 4 * q + e;
+          if (lr < npos) a.out[(size_t)(pos0 + lr) * a.cout + r16] = act1(acc0[e] + acc1[e] + acc2[e] + acc3[e] + b, a.act, a.slope);
+        }
+      }
+    } else {
+      // h tile (activation applied) -> per-wave LDS scratch [row][17] -> A operand (lane = row, k = channel quad)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        hs[(4 * q + e) * 17 + r16] = r16 < a.cout ? act1(acc0[e] + acc1[e] + acc2[e] + acc3[e] + b, a.act, a.slope) : 0.f;
+      __builtin_amdgcn_wave_barrier();      // same wave writes and reads: LDS executes a wave's operations in order
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+      // t^T tile = W2 (A: lane = offset, k = channel quad) x h^T (B: lane = row): rows end up across the lanes, so each
+      // store instruction writes four 64-byte runs of consecutive rows instead of 64 scattered words
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float hv = hs[r16 * 17 + 4 * j + q];
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[0][j], hv, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[1][j], hv, d1, 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();      // the next tile's scratch writes stay behind these reads
+      // D: lane (row = r16, q) holds t[k = 4q+e (+16)][row]
+      if ((unsigned)r16 < npos) {
+        float* tp = a.t + (size_t)(4 * q) * spc + pos0 + r16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          tp[(size_t)e * spc] = d0[e];
+          if (16 + 4 * q + e < 27) tp[(size_t)(16 + e) * spc] = d1[e];
+        }
       }
     }
   }
@@ -823,6 +1253,14 @@ static int cb_log2_for(int cin) { return cin >= 32 ? 5 : (cin == 16 ? 4 : (cin =
 static int cout_pad_for(int cout) { const int bn = bn_for(cout); return (cout + bn - 1) / bn * bn; }
 
 enum { KIND_NONE = -1, KIND_MFMA = 0, KIND_WAVE16 = 1, KIND_THIN_T = 2, KIND_THIN = 3 };
+// MFMA weight images: the fp32 layout, followed (cin a multiple of 32) by the three bf16 planes of the split path
+static int64_t mfma_packed_total(int64_t fp32_elems, int cin) { return cin % 32 == 0 ? fp32_elems + bf_plane_elems(fp32_elems) : fp32_elems; }
+static int split_planes(float* packed, int64_t fp32_elems, int cin, hipStream_t s) {
+  if (cin % 32 != 0) return PCC_OK;
+  k_split_packed<<<(unsigned)pcc_cdiv(fp32_elems / 2, 256), 256, 0, s>>>(packed, fp32_elems / 2, (unsigned*)(packed + fp32_elems));
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
 static int conv_kind(int K, int cin, int cout) {
   if (cout <= 4) {
     const bool pow2 = cin == 4 || cin == 8 || cin == 16 || cin == 32 || cin == 64;
@@ -837,7 +1275,7 @@ static int conv_kind(int K, int cin, int cout) {
 extern "C" int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout) {
   if (K <= 0 || cin <= 0 || cout <= 0) return 0;
   switch (conv_kind(K, cin, cout)) {
-    case KIND_MFMA: return (int64_t)K * cin * cout_pad_for(cout);
+    case KIND_MFMA: return mfma_packed_total((int64_t)K * cin * cout_pad_for(cout), cin);
     case KIND_WAVE16: return (int64_t)K * 16 * cin;
     case KIND_THIN_T: case KIND_THIN: return (int64_t)K * cin * cout;
     default: return 0;
@@ -867,13 +1305,16 @@ __global__ void k_pack_mfma(const float* __restrict__ W, int K, int cin, int cou
   out[t] = (col < cout) ? W[((long long)kid * cin + ci) * cout + col] : 0.f;
 }
 
-// W [K][cin][cout] -> wave16 layout [K][16][cin] (column-major per offset, zero padded to 16 columns)
+// W [K][cin][cout] -> wave16 layout [K][cin/4][16][4] (k-quad major, 16 zero-padded output columns, 4 channels each:
+// the LDS image of k_conv_wave16*, see wave16_w)
 __global__ void k_pack_wave16(const float* __restrict__ W, int K, int cin, int cout, float* __restrict__ out) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)K * 16 * cin) return;
-  const int c = (int)(t % cin);
-  const int o = (int)((t / cin) % 16);
+  const int c4 = (int)(t & 3);
+  const int o = (int)((t >> 2) & 15);
+  const int kq = (int)((t >> 6) % (cin / 4));
   const int k = (int)(t / ((long long)cin * 16));
+  const int c = kq * 4 + c4;
   out[t] = o < cout ? W[((long long)k * cin + c) * cout + o] : 0.f;
 }
 
@@ -898,7 +1339,13 @@ extern "C" int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int
   }
   const unsigned g = (unsigned)pcc_cdiv(total > 0 ? total : 1, 256);
   switch (conv_kind(K, cin, cout)) {
-    case KIND_MFMA: k_pack_mfma<<<g, 256, 0, s>>>(W, K, cin, cout, cout_pad_for(cout), cb_log2_for(cin), packed); break;
+    case KIND_MFMA: {
+      const int64_t base = (int64_t)K * cin * cout_pad_for(cout);
+      k_pack_mfma<<<(unsigned)pcc_cdiv(base, 256), 256, 0, s>>>(W, K, cin, cout, cout_pad_for(cout), cb_log2_for(cin), packed);
+      PCC_LAUNCH_CHECK();
+      PCC_TRY(split_planes(packed, base, cin, s));
+      break;
+    }
     case KIND_WAVE16: k_pack_wave16<<<g, 256, 0, s>>>(W, K, cin, cout, packed); break;
     case KIND_THIN_T: case KIND_THIN: k_pack_thin<<<g, 256, 0, s>>>(W, K, cin, cout, packed); break;
     default:
@@ -949,20 +1396,35 @@ extern "C" int pcc_prof_collect(double* h_conv_ms, int64_t* h_conv_launches) {
 }
 
 static bool g_mfma_buf = getenv("PCC_MFMA_BUF") ? atoi(getenv("PCC_MFMA_BUF")) != 0 : true;
+// split path (fp32 products as six bf16 MFMA terms, k_conv_mfma_bf); PCC_MFMA_SPLIT=0 selects the fp32-input MFMA kernels
+static bool g_mfma_split = getenv("PCC_MFMA_SPLIT") ? atoi(getenv("PCC_MFMA_SPLIT")) != 0 : true;
+extern "C" int pcc_set_mfma_split(int32_t on) { g_mfma_split = on != 0; return PCC_OK; }
+static bool split_ok(const ConvArgs& a) {
+  return g_mfma_split && g_mfma_buf && a.cb_log2 == 5 && a.n_in > 0 && a.n_in * a.cin * 6 <= BUF_MAX_BYTES && a.wp_elems > 0 &&
+         bf_plane_elems(a.wp_elems) * 4 <= BUF_MAX_BYTES;
+}
 
 template <int MODE>
-static int launch_mfma(const ConvArgs& a, int tiles_bound_extra, hipStream_t s) {
+static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t s) {
+  ConvArgs a = a_in;
   const int bn = bn_for(a.cout);
   const long long gy = a.cout_pad / bn;
-  auto tiles = [&](int bm) { return (long long)(pcc_cdiv(a.n_out, bm) + tiles_bound_extra); };
+  const bool gemm_groups = !a.hdr && !a.pair_in && gy > 8;      // k_conv_mfma*: row tiles in groups of 8 (whole groups in the grid)
+  auto tiles = [&](int bm) {
+    const long long t = pcc_cdiv(a.n_out, bm) + tiles_bound_extra;
+    return gemm_groups ? (t + 7) / 8 * 8 : t;
+  };
   auto grid = [&](int bm) { return dim3((unsigned)((tiles(bm) * gy + 7) / 8 * 8)); };   // 1-D, multiple of 8 (XCD ranges)
   // few rows: shrink the row tile until the grid covers the 256 CUs about twice
   const long long want = 512;
   const bool buf = g_mfma_buf && a.n_in > 0 && a.n_in * a.cin * 4 <= BUF_MAX_BYTES && a.wp_elems > 0 &&
                    a.wp_elems * 4 <= BUF_MAX_BYTES;
+  const bool split = split_ok(a);
+  if (split) PCC_TRY(make_planes(a, MODE != MODE_CONV, s));
 #define PCC_LAUNCH_MFMA(WM, WN, TM, TN, BMV)                                                     \
   do {                                                                                           \
-    if (buf) k_conv_mfma<WM, WN, TM, TN, MODE, true><<<grid(BMV), 256, 0, s>>>(a);               \
+    if (split) k_conv_mfma_bf<WM, WN, TM, TN, MODE><<<grid(BMV), 256, 0, s>>>(a);                \
+    else if (buf) k_conv_mfma<WM, WN, TM, TN, MODE, true><<<grid(BMV), 256, 0, s>>>(a);          \
     else k_conv_mfma<WM, WN, TM, TN, MODE, false><<<grid(BMV), 256, 0, s>>>(a);                  \
   } while (0)
   if (bn == 128) {
@@ -982,11 +1444,15 @@ static bool g_wave16_zrun = getenv("PCC_WAVE16_ZRUN") ? atoi(getenv("PCC_WAVE16_
 
 template <int CIN>
 static int launch_wave16(const Wave16Args& a, hipStream_t s) {
-  const size_t lds = (size_t)a.K * 16 * (CIN + 4) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  const size_t lds = (size_t)a.K * 16 * CIN * sizeof(float);
+  int dev = 0;
+  PCC_CHECK_HIP(hipGetDevice(&dev));
+  static unsigned long long attr_set = 0;                         // one bit per device (hipFuncSetAttribute is per device)
+  if (!(attr_set >> (dev & 63) & 1ull)) {
     PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_wave16<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_set = true;
+    PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_wave16z<CIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_wave16z<CIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_set |= 1ull << (dev & 63);
   }
   const long long tiles = pcc_cdiv(a.n_out, 32) + (a.rows ? PCC_MAP_MAX_SEG : 0);
   long long want = pcc_cdiv(tiles, 8);
@@ -995,15 +1461,12 @@ static int launch_wave16(const Wave16Args& a, hipStream_t s) {
   // 3x3x3 conv map in canonical row order (k_map_conv: one segment, all 27 offsets, no row list): z-run reuse variant
   if (g_wave16_zrun && a.K == 27 && a.hdr && !a.rows && a.n_out * 27 < (1ll << 31) &&
       a.n_in * CIN * 4 <= 0xFFFFFE00ll) {                          // 32-bit buffer offsets
-    static bool attr_z = false;
-    if (!attr_z) {
-      PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_wave16z<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      attr_z = true;
-    }
-    k_conv_wave16z<CIN><<<grid, 512, lds, s>>>(a);
+    if (a.t) k_conv_wave16z<CIN, true><<<grid, 512, lds + 8 * 16 * 17 * sizeof(float), s>>>(a);
+    else k_conv_wave16z<CIN, false><<<grid, 512, lds, s>>>(a);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
   }
+  PCC_REQUIRE(!a.t, "pcc_conv_head_fwd: the fused head needs a canonical 3x3x3 map (one segment, no row list)");
   k_conv_wave16<CIN><<<grid, 512, lds, s>>>(a);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
@@ -1083,6 +1546,147 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
     PCC_TRY(prof_event(&e1, s));
     ++g_launches;
   }
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Band-ordered tile table for stencil kernels over large canonical sets (k_conv_wave16z).
+// Canonical order is (x, y, z) with x slowest: the dx = +-1 neighbours of a row live one whole x-slab away, and on the
+// 14.5 M-row level of the decoder three slabs of features (8 MB) do not fit an XCD's 4 MB L2, so every row was
+// fetched from the fabric three times (round 1: 14.6 GB per launch for 1.86 GB of input).  Here the y range is cut into
+// bands; the rows of one (band, x) pair are a contiguous run of the canonical order (found by two binary searches);
+// tiles are cut inside the runs and numbered band-major, x ascending.  An XCD's contiguous tile range then sweeps
+// x inside one band: the band's part of a slab (~0.3 MB) is still in L2 when it is needed again as dx = 0 and dx = -1.
+// Tile word: row0 | (rows - 1) << 27.
+// ------------------------------------------------------------------------------------------
+__global__ void k_band_segments(const long long* __restrict__ keys, long long n, int lo_x, int nx, int lo_y, int ny, int ts,
+                                int nbands, int band_h, int* __restrict__ seg_row0, int* __restrict__ seg_tiles) {
+  const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sidx >= nbands * nx) return;
+  const int band = sidx / nx, xi = sidx - band * nx;
+  const long long x = (long long)lo_x + (long long)xi * ts + PCC_BIAS;
+  const int cy0 = band * band_h, cy1 = min(ny, cy0 + band_h);
+  auto lower = [&](long long key) {
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  long long b = 0, e = 0;
+  if (cy0 < cy1) {
+    const long long y0 = (long long)lo_y + (long long)cy0 * ts + PCC_BIAS, y1 = (long long)lo_y + (long long)cy1 * ts + PCC_BIAS;
+    b = lower((x << 32) | (y0 << 16));
+    e = lower((x << 32) | (y1 << 16));
+  }
+  seg_row0[sidx] = (int)b;
+  seg_tiles[sidx] = (int)((e - b + 15) / 16);
+  seg_row0[nbands * nx + sidx] = (int)(e - b);       // second half of the array: rows of the run
+}
+
+__global__ void __launch_bounds__(1024) k_band_scan(const int* __restrict__ seg_tiles, int nseg, int* __restrict__ seg_tile0,
+                                                    int* __restrict__ n_tiles) {
+  __shared__ int part[1024];
+  const int per = (nseg + 1023) / 1024;
+  const int b = threadIdx.x * per, e = min(nseg, b + per);
+  int sum = 0;
+  for (int i = b; i < e; ++i) sum += seg_tiles[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - sum;
+  for (int i = b; i < e; ++i) { seg_tile0[i] = run; run += seg_tiles[i]; }
+  if (threadIdx.x == 1023) *n_tiles = part[1023];
+}
+
+__global__ void __launch_bounds__(256) k_band_fill(const int* __restrict__ seg_row0, const int* __restrict__ seg_rows,
+                                                   const int* __restrict__ seg_tile0, int nseg, int* __restrict__ tiles) {
+  const int sidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sidx >= nseg) return;
+  const int rows = seg_rows[sidx], r0 = seg_row0[sidx], t0 = seg_tile0[sidx];
+  const int nt = (rows + 15) / 16;
+  for (int j = threadIdx.x & 63; j < nt; j += 64) {
+    const int cnt = min(16, rows - 16 * j);
+    tiles[t0 + j] = (r0 + 16 * j) | ((cnt - 1) << 27);
+  }
+}
+
+extern "C" int64_t pcc_band_tiles_cap(int64_t n, int32_t nx, int32_t nbands) { return n / 16 + (int64_t)nx * nbands + 16; }
+extern "C" size_t pcc_band_tiles_ws_bytes(int32_t nx, int32_t nbands) { return pcc_align_up((size_t)nx * nbands * 4) * 4 + 256; }
+
+extern "C" int pcc_band_tiles_build(const int64_t* keys, int64_t n, int32_t lo_x, int32_t nx, int32_t lo_y, int32_t ny,
+                                    int32_t ts, int32_t nbands, int32_t* tiles, int64_t tiles_cap, int32_t* n_tiles,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(keys && tiles && n_tiles && ws && n > 0 && n < (1ll << 27), "pcc_band_tiles_build: bad arguments (rows must stay below 2^27)");
+  PCC_REQUIRE(nx >= 1 && ny >= 1 && ts >= 1 && nbands >= 1 && (int64_t)nx * nbands <= (1 << 20), "pcc_band_tiles_build: bad lattice");
+  PCC_REQUIRE(tiles_cap >= pcc_band_tiles_cap(n, nx, nbands), "pcc_band_tiles_build: tile table too small (pcc_band_tiles_cap)");
+  if (ws_bytes < pcc_band_tiles_ws_bytes(nx, nbands)) { pcc_set_error("pcc_band_tiles_build: workspace too small"); return PCC_EWS; }
+  const int nseg = nx * nbands;
+  const size_t st = pcc_align_up((size_t)nseg * 4);
+  int* seg_row0 = (int*)ws;                              // [2][nseg]: first row, row count
+  int* seg_tiles = (int*)((char*)ws + 2 * st);
+  int* seg_tile0 = (int*)((char*)ws + 3 * st);
+  PCC_REQUIRE(st >= (size_t)nseg * 4, "pcc_band_tiles_build: internal");
+  const int band_h = (ny + nbands - 1) / nbands;
+  // seg_row0 holds both arrays back to back (k_band_segments writes seg_row0[nseg + s] = rows): needs 2*nseg ints
+  k_band_segments<<<(unsigned)pcc_cdiv(nseg, 256), 256, 0, s>>>((const long long*)keys, n, lo_x, nx, lo_y, ny, ts, nbands, band_h,
+                                                                seg_row0, seg_tiles);
+  PCC_LAUNCH_CHECK();
+  k_band_scan<<<1, 1024, 0, s>>>(seg_tiles, nseg, seg_tile0, n_tiles);
+  PCC_LAUNCH_CHECK();
+  k_band_fill<<<(unsigned)pcc_cdiv(nseg, 4), 256, 0, s>>>(seg_row0, seg_row0 + nseg, seg_tile0, nseg, tiles);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Occupancy head in one pass over the features (model/transforms.py:141-160, `predict_i`):
+//   logits = conv_k3(relu(conv_k3(x; W0, b0)); W2, b2),   W0: cin -> cmid <= 16,  W2: cmid -> 1
+// k_conv_wave16z<.., PROJ> evaluates the first convolution, the ReLU and the projections t[k][i] = <h_i, w2_k> tile by
+// tile (h never reaches memory), k_thin_gather sums t through the same 3x3x3 map in ascending offset order (fixed
+// order, deterministic; the projection runs on the MFMA, so the last bits differ from k_thin_project's VALU dot).
+// ------------------------------------------------------------------------------------------
+extern "C" int pcc_conv_head_supported(int32_t cin, int32_t cmid) {
+  return (cmid > 4 && cmid <= 16 && conv_kind(27, cin, cmid) == KIND_WAVE16 && (size_t)27 * 16 * cin * 4 + 8 * 16 * 17 * 4 <= 64 * 1024) ? 1 : 0;
+}
+extern "C" size_t pcc_conv_head_ws_bytes(int64_t n) { return (size_t)27 * (size_t)(n > 0 ? n : 1) * sizeof(float) + 256; }
+
+extern "C" int pcc_conv_head_fwd(const float* feat, int64_t n, int32_t cin, const float* packed_w0, const float* bias0,
+                                 int32_t cmid, const float* w2, const float* bias2, const int32_t* hdr, const int32_t* nbr,
+                                 const int32_t* tiles, const int32_t* n_tiles, float* logits, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(feat && packed_w0 && w2 && hdr && nbr && logits && ws, "pcc_conv_head_fwd: NULL array");
+  PCC_REQUIRE(pcc_conv_head_supported(cin, cmid), "pcc_conv_head_fwd: unsupported shape cin=%d cmid=%d", cin, cmid);
+  PCC_REQUIRE((tiles == nullptr) == (n_tiles == nullptr), "pcc_conv_head_fwd: tiles and n_tiles go together");
+  PCC_REQUIRE(n * 27 < (1ll << 31) && n * cin * 4 <= 0xFFFFFE00ll && g_wave16_zrun, "pcc_conv_head_fwd: set too large for 32-bit offsets");
+  if (ws_bytes < pcc_conv_head_ws_bytes(n)) { pcc_set_error("pcc_conv_head_fwd: workspace too small"); return PCC_EWS; }
+  Wave16Args a;
+  a.feat = feat; a.wl = packed_w0; a.bias = bias0; a.hdr = hdr; a.nbr = nbr; a.rows = nullptr; a.out = nullptr;
+  a.n_out = n; a.n_in = n; a.K = 27; a.cout = cmid; a.act = PCC_ACT_RELU; a.slope = 0.f;
+  a.tiles = tiles; a.n_tiles = n_tiles; a.w2 = w2; a.t = (float*)ws;
+  hipEvent_t e0, e1;
+  if (g_prof_on) PCC_TRY(prof_event(&e0, s));
+  if (cin == 16) PCC_TRY(launch_wave16<16>(a, s));
+  else if (cin == 32) PCC_TRY(launch_wave16<32>(a, s));
+  else PCC_TRY(launch_wave16<64>(a, s));
+  if (g_prof_on) {
+    PCC_TRY(prof_event(&e1, s));
+    ++g_launches;
+  }
+  ThinGatherArgs g;
+  g.t = (const float*)ws; g.bias = bias2; g.hdr = hdr; g.nbr = nbr; g.rows = nullptr; g.out = logits; g.n_in = n; g.n_out = n;
+  g.cout = 1; g.act = PCC_ACT_NONE; g.slope = 0.f;
+  k_thin_gather<1><<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(g);
+  PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
 
@@ -1255,9 +1859,11 @@ extern "C" int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t ci
     const long long gy = a.cout_pad / bn;
     const dim3 grid((unsigned)((padded_pairs / PAIR_BM * gy + 7) / 8 * 8));
     const bool buf = g_mfma_buf && n_in * cin * 4 <= BUF_MAX_BYTES && a.wp_elems * 4 <= BUF_MAX_BYTES;
-    if (bn == 128) { if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
-    else if (bn == 64) { if (buf) k_conv_mfma<2, 2, 2, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
-    else { if (buf) k_conv_mfma<4, 1, 1, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<4, 1, 1, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    const bool split = split_ok(a);
+    if (split) PCC_TRY(make_planes(a, false, s));
+    if (bn == 128) { if (split) k_conv_mfma_bf<2, 2, 2, 2, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    else if (bn == 64) { if (split) k_conv_mfma_bf<2, 2, 2, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    else { if (split) k_conv_mfma_bf<4, 1, 1, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<4, 1, 1, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<4, 1, 1, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     PCC_LAUNCH_CHECK();
     if (g_prof_on) {
       PCC_TRY(prof_event(&e1, s));
@@ -1441,9 +2047,11 @@ extern "C" int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t ci
     const long long gy = a.cout_pad / bn;
     const dim3 grid((unsigned)((tiles_cap * gy + 7) / 8 * 8));
     const bool buf = g_mfma_buf && n_in * cin * 4 <= BUF_MAX_BYTES && a.wp_elems * 4 <= BUF_MAX_BYTES;
-    if (bn == 128) { if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
-    else if (bn == 64) { if (buf) k_conv_mfma<2, 2, 2, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
-    else { if (buf) k_conv_mfma<4, 1, 1, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<4, 1, 1, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    const bool split = split_ok(a);
+    if (split) PCC_TRY(make_planes(a, false, s));
+    if (bn == 128) { if (split) k_conv_mfma_bf<2, 2, 2, 2, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    else if (bn == 64) { if (split) k_conv_mfma_bf<2, 2, 2, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    else { if (split) k_conv_mfma_bf<4, 1, 1, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<4, 1, 1, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<4, 1, 1, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     PCC_LAUNCH_CHECK();
     if (g_prof_on) {
       PCC_TRY(prof_event(&e1, s));
@@ -1489,7 +2097,7 @@ __global__ void k_pack_convt(const float* __restrict__ W, int K, int cin, int co
 
 extern "C" int64_t pcc_convt_packed_elems(int32_t K, int32_t cin, int32_t cout) {
   if (K <= 0 || cin <= 0 || cout <= 0 || !mfma_ok(cin, K * cout)) return 0;
-  return (int64_t)cin * cout_pad_for(K * cout);
+  return mfma_packed_total((int64_t)cin * cout_pad_for(K * cout), cin);
 }
 
 extern "C" int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
@@ -1502,10 +2110,11 @@ extern "C" int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, in
     pcc_set_error("pcc_convt_pack_weights: packed buffer holds %lld floats, the layout needs %lld", (long long)packed_cap, (long long)total);
     return PCC_EWS;
   }
-  k_pack_convt<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(W, K, cin, cout, K * cout, cout_pad_for(K * cout),
-                                                             cb_log2_for(cin), packed);
+  const int64_t base = (int64_t)cin * cout_pad_for(K * cout);
+  k_pack_convt<<<(unsigned)pcc_cdiv(base, 256), 256, 0, s>>>(W, K, cin, cout, K * cout, cout_pad_for(K * cout),
+                                                            cb_log2_for(cin), packed);
   PCC_LAUNCH_CHECK();
-  return PCC_OK;
+  return split_planes(packed, base, cin, s);
 }
 
 struct GatherArgs {
@@ -1715,7 +2324,7 @@ __global__ void k_gdn_pack(const float* __restrict__ beta_raw, const float* __re
   packed[t] = v;
 }
 
-extern "C" int64_t pcc_gdn_packed_elems(int32_t c) { return mfma_ok(c, c) ? (int64_t)c * cout_pad_for(c) : 0; }
+extern "C" int64_t pcc_gdn_packed_elems(int32_t c) { return mfma_ok(c, c) ? mfma_packed_total((int64_t)c * cout_pad_for(c), c) : 0; }
 
 extern "C" int pcc_gdn_pack(const float* beta_raw, const float* gamma_raw, int32_t c, float beta_min, float* packed,
                             int64_t packed_cap, float* beta_eff, void* stream) {
@@ -1730,11 +2339,12 @@ extern "C" int pcc_gdn_pack(const float* beta_raw, const float* gamma_raw, int32
     pcc_set_error("pcc_gdn_pack: packed buffer holds %lld floats, the layout needs %lld", (long long)packed_cap, (long long)total);
     return PCC_EWS;
   }
-  k_gdn_pack<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(beta_raw, gamma_raw, c, beta_bound, gamma_bound,
-                                                           (float)pedestal, cout_pad_for(c), cb_log2_for(c), packed,
-                                                           beta_eff);
+  const int64_t base = (int64_t)c * cout_pad_for(c);
+  k_gdn_pack<<<(unsigned)pcc_cdiv(base, 256), 256, 0, s>>>(beta_raw, gamma_raw, c, beta_bound, gamma_bound,
+                                                          (float)pedestal, cout_pad_for(c), cb_log2_for(c), packed,
+                                                          beta_eff);
   PCC_LAUNCH_CHECK();
-  return PCC_OK;
+  return split_planes(packed, base, c, s);
 }
 
 extern "C" int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* packed, const float* beta_eff,

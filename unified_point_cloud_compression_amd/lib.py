@@ -51,10 +51,17 @@ SIGNATURES = {
     "pcc_expand_grid_csr_ws_bytes": (_sz, [_i64]),
     "pcc_coords_expand_grid_csr": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
     "pcc_map_to_dense": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
+    "pcc_set_mfma_split": (C.c_int, [_i32]),
     "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _i64, _p]),
     "pcc_conv_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "pcc_conv_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _f32, _p, _sz, _p]),
+    "pcc_conv_head_supported": (C.c_int, [_i32, _i32]),
+    "pcc_conv_head_ws_bytes": (_sz, [_i64]),
+    "pcc_conv_head_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pcc_band_tiles_cap": (_i64, [_i64, _i32, _i32]),
+    "pcc_band_tiles_ws_bytes": (_sz, [_i32, _i32]),
+    "pcc_band_tiles_build": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
     "pcc_convt_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_convt_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _i64, _p]),
     "pcc_convt_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _f32, _p]),

@@ -116,6 +116,15 @@ class SparseSynthesisTransform(nn.Module):
         c0, c2 = head[0], head[2]
         cs = x._cset
         kmap = cs.kernel_map(cs, 3)
+        f = x._canonical_features()
+        if (S.HEAD_FUSED and not (torch.is_grad_enabled() and (f.requires_grad or c0.kernel.requires_grad))
+                and c0.kernel_size == 3 and c2.kernel_size == 3 and c0.stride == 1 and c2.stride == 1 and c2.out_channels == 1
+                and kmap.rows is None and L.load().pcc_conv_head_supported(c0.in_channels, c0.out_channels)):
+            # narrow heads (predict_3: 32 -> 16 -> 1): one pass over the features, the hidden layer stays on chip
+            w0 = c0._packed.get(c0.kernel, state_dict_order=True)
+            w2 = c2._packed.get(c2.kernel, state_dict_order=True)
+            logit = S.conv_head_forward(f, w0, c0.bias, c0.out_channels, w2, c2.bias, cs, kmap)
+            return SparseTensor._from_canonical(cs, logit)
         h = c0._apply_conv(x, cs, kmap, act=L.ACT_RELU)
         ht = SparseTensor._from_canonical(cs, h)
         logit = c2._apply_conv(ht, cs, kmap)

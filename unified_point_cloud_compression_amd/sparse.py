@@ -8,6 +8,7 @@ coordinate manager.
 import ctypes as C
 
 import itertools
+import os
 import weakref
 
 import torch
@@ -99,6 +100,10 @@ EXPAND_BY_GRID = True  # generative expansion through the bitmaps (False: 32-bit
 STRIDE_BY_GRID = True  # strided sets read out of the coarse occupancy bitmap (False: mask + radix sort + unique)
 USE_GRID = True       # neighbour lookup through the bitmap+rank grid index (False: binary search; tests run both)
 GRID_MAX_BYTES = 8 << 30
+BAND_TILES = os.environ.get("PCC_BAND_TILES", "1") != "0"      # stencil kernels over large sets visit their tiles band by band (L2 locality of the dx = +-1 slabs)
+BAND_MIN_ROWS = 1 << 20
+BAND_COUNT = 16
+HEAD_FUSED = os.environ.get("PCC_HEAD_FUSED", "1") != "0"      # occupancy heads with <= 16 hidden channels: conv + ReLU + projection in one kernel
 
 
 _SET_SERIAL = itertools.count()
@@ -116,6 +121,7 @@ class CoordSet:
         self._derived = {}
         self._maps = {}
         self._grid = None
+        self._bands = None
         self.uid = next(_SET_SERIAL)
 
     @property
@@ -154,6 +160,26 @@ class CoordSet:
                        L.stream())
                 self._grid = (bits, rank, h)
         return self._grid or None
+
+    def band_tiles(self):
+        """Band-ordered tile table (tiles int32, n_tiles int32[1]) for the stencil kernels over this set, or None when
+        the set is small (its neighbour slabs fit L2 anyway), batched, or too large for the 27-bit row field."""
+        if self._bands is None:
+            self._bands = False
+            b = self.bounds
+            if BAND_TILES and b.bmax == 0 and BAND_MIN_ROWS <= self.n < (1 << 27):
+                lib = L.load()
+                nx = (b.hi[0] - b.lo[0]) // self.ts + 1
+                ny = (b.hi[1] - b.lo[1]) // self.ts + 1
+                nb = max(1, min(BAND_COUNT, ny))
+                cap = lib.pcc_band_tiles_cap(self.n, nx, nb)
+                tiles = torch.empty(cap, dtype=torch.int32, device=self.device)
+                n_tiles = torch.zeros(1, dtype=torch.int32, device=self.device)
+                ws = L.workspace(lib.pcc_band_tiles_ws_bytes(nx, nb), self.device)
+                L.call("pcc_band_tiles_build", L.ptr(self.keys), self.n, b.lo[0], nx, b.lo[1], ny, self.ts, nb, L.ptr(tiles),
+                       cap, L.ptr(n_tiles), L.ptr(ws), ws.numel(), L.stream())
+                self._bands = (tiles, n_tiles)
+        return self._bands or None
 
     # ---- derived sets ------------------------------------------------------------------------
     def stride(self, new_stride):
@@ -474,6 +500,24 @@ def conv_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NON
            L.ptr(kmap.hdr) if kmap is not None else None, L.ptr(kmap.nbr) if kmap is not None else None,
            L.ptr(kmap.rows) if kmap is not None else None, n_out, L.ptr(out), act, float(slope), L.ptr(ws),
            ws.numel(), L.stream())
+    return out
+
+
+def conv_head_forward(feats, packed_w0, bias0, cmid, w2, bias2, cset, kmap):
+    """Occupancy head over a canonical set: conv_k3(relu(conv_k3(x))) -> [n, 1] logits, hidden features never stored
+    (`predict_i`, reference `model/transforms.py:141-160`).  w2: the second kernel in its packed thin layout."""
+    feats = feats.contiguous()
+    n, cin = feats.shape
+    out = torch.empty((n, 1), dtype=torch.float32, device=feats.device)
+    if n == 0:
+        return out
+    bands = cset.band_tiles()
+    ws = L.workspace(L.load().pcc_conv_head_ws_bytes(n), feats.device)
+    b0 = bias0.detach().reshape(-1).contiguous() if bias0 is not None else None
+    b2 = bias2.detach().reshape(-1).contiguous() if bias2 is not None else None
+    L.call("pcc_conv_head_fwd", L.ptr(feats), n, cin, L.ptr(packed_w0), L.ptr(b0), cmid, L.ptr(w2), L.ptr(b2),
+           L.ptr(kmap.hdr), L.ptr(kmap.nbr), L.ptr(bands[0]) if bands else None, L.ptr(bands[1]) if bands else None,
+           L.ptr(out), L.ptr(ws), ws.numel(), L.stream())
     return out
 
 

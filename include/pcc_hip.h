@@ -307,6 +307,14 @@ int pcc_gauss_decode(const int32_t* sym, const float* params, const int64_t* key
                      int64_t n, int32_t c, const float* table, int32_t n_table, float* y_hat,
                      int32_t* idx, void* stream);
 
+/* Differentiable Gaussian likelihood of the TRAINING forward (GaussianConditional._likelihood + lower bound 1e-9;
+ * model/entropy_models.py:312-316,327-331; rate term loss.py:77-79) on n elements:
+ *   lik = max(Phi((.5 - |v - mean|)/s) - Phi((-.5 - |v - mean|)/s), 1e-9),  s = max(scale, 0.11)
+ * and its gradients w.r.t. v, scale and mean (CompressAI LowerBound gradient rule on both bounds); mean nullable. */
+int pcc_gauss_lik_fwd(const float* v, const float* scale, const float* mean, int64_t n, float* lik, void* stream);
+int pcc_gauss_lik_bwd(const float* v, const float* scale, const float* mean, const float* grad_lik, int64_t n,
+                      float* dv /*nullable*/, float* dscale /*nullable*/, float* dmean /*nullable*/, void* stream);
+
 /* a8  factorised prior on z            (compressai EntropyBottleneck, model/entropy_models.py:272,
  *                                       282-285,371-372,438); filters (3,3,3,3).
  * eb_packed [c,58]: softplus(matrices) (3,9,9,9,3) | biases (3,3,3,3,1) | tanh(factors) (3,3,3,3);

@@ -106,3 +106,72 @@ class SparseConvFn(torch.autograd.Function):
         if g_kernel is not None and kernel.dim() == 2:
             g_kernel = g_kernel[0]
         return g_feats, g_kernel, g_bias, None, None, None, None, None, None
+
+
+class GdnFn(torch.autograd.Function):
+    """`MinkowskiGDN.forward` under autograd (reference `model/blocks.py:38-57`, GDN1 form): the forward is the fused MFMA
+    kernel `pcc_gdn_fwd`; the backward runs on the library's kernels too --
+        n  = beta + |x| gamma^T                          (K = 1 convolution)
+        GDN   y = x / n : u = -g y / n,  dx = g / n + sign(x) (u gamma)
+        IGDN  y = x n   : u =  g x,      dx = g n   + sign(x) (u gamma)
+        dbeta = sum_rows u,   dgamma = u^T |x|              (`pcc_conv_wgrad`, deterministic)
+    and the two [C] / [C,C] parameter gradients go through CompressAI's NonNegativeParametrizer by torch autograd."""
+
+    @staticmethod
+    def forward(ctx, x, beta_raw, gamma_raw, module):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        packed, beta_eff = module._pack()
+        L.call("pcc_gdn_fwd", L.ptr(x), x.shape[0], module.in_channels, L.ptr(packed), L.ptr(beta_eff),
+               1 if module.inverse else 0, L.ptr(out), L.stream())
+        ctx.save_for_backward(x, beta_raw, gamma_raw)
+        ctx.module = module
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, beta_raw, gamma_raw = ctx.saved_tensors
+        m = ctx.module
+        g = g.contiguous()
+        with torch.enable_grad():
+            b_leaf = beta_raw.detach().requires_grad_(True)
+            g_leaf = gamma_raw.detach().requires_grad_(True)
+            beta = m.beta_reparam(b_leaf)
+            gamma = m.gamma_reparam(g_leaf)
+        with torch.no_grad():
+            ax = x.abs()
+            n = _conv_any(ax, gamma.detach().t().unsqueeze(0).contiguous(), None, x.shape[0]) + beta.detach()
+            if m.inverse:
+                u = g * x
+                dx0 = g * n
+            else:
+                u = -(g * x) / (n * n)
+                dx0 = g / n
+            dx = dx0 + torch.sign(x) * _conv_any(u, gamma.detach().unsqueeze(0).contiguous(), None, x.shape[0])
+            d_beta = u.sum(dim=0)
+            d_gamma = S.conv_wgrad(ax, u.contiguous(), 1, ax.shape[1], u.shape[1], None)[0].t()      # [ci][co] = sum |x|_ci u_co
+        gb, gg = torch.autograd.grad([beta, gamma], [b_leaf, g_leaf], [d_beta, d_gamma.contiguous()])
+        return (dx if ctx.needs_input_grad[0] else None), gb, gg, None
+
+
+class GaussLikFn(torch.autograd.Function):
+    """Gaussian likelihood of the training forward as one kernel per direction (`pcc_gauss_lik_fwd/bwd`)."""
+
+    @staticmethod
+    def forward(ctx, v, scale, mean):
+        v, scale, mean = v.contiguous(), scale.contiguous(), mean.contiguous()
+        lik = torch.empty_like(v)
+        L.call("pcc_gauss_lik_fwd", L.ptr(v), L.ptr(scale), L.ptr(mean), v.numel(), L.ptr(lik), L.stream())
+        ctx.save_for_backward(v, scale, mean)
+        return lik
+
+    @staticmethod
+    def backward(ctx, g):
+        v, scale, mean = ctx.saved_tensors
+        g = g.contiguous()
+        dv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        ds = torch.empty_like(v) if ctx.needs_input_grad[1] else None
+        dm = torch.empty_like(v) if ctx.needs_input_grad[2] else None
+        L.call("pcc_gauss_lik_bwd", L.ptr(v), L.ptr(scale), L.ptr(mean), L.ptr(g), v.numel(), L.ptr(dv), L.ptr(ds), L.ptr(dm),
+               L.stream())
+        return dv, ds, dm

@@ -421,6 +421,7 @@ class GaussianConditional(EntropyModel):
         if scale_bound is None and scale_table:
             scale_bound = scale_table[0]
         self.lower_bound_scale = LowerBound(scale_bound)
+        self._scale_bound_value = float(scale_bound) if scale_bound is not None else None
         self.register_buffer("scale_table", torch.Tensor(tuple(float(s) for s in scale_table)) if scale_table else torch.Tensor())
         self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]) if scale_bound is not None else None)
 
@@ -464,7 +465,12 @@ class GaussianConditional(EntropyModel):
         return self.scale_table.to(device=device, dtype=torch.float32).contiguous()
 
     def likelihood_rows(self, values, scales, means):
-        """Differentiable Gaussian likelihood of [N,C] rows (training path; torch ops)."""
+        """Differentiable Gaussian likelihood of [N,C] rows (training path): one HIP kernel per direction on the GPU
+        (`pcc_gauss_lik_fwd/bwd`, bounds 0.11 / 1e-9 as constructed by the reference); torch ops otherwise."""
+        if (values.is_cuda and self.use_likelihood_bound and values.dtype == torch.float32
+                and self._scale_bound_value is not None and abs(self._scale_bound_value - 0.11) < 1e-7 and values.shape == scales.shape == means.shape):
+            from ...autograd import GaussLikFn
+            return GaussLikFn.apply(values, scales, means)
         s = self.lower_bound_scale(scales)
         a = torch.abs(values - means)
         lik = self._standardized_cumulative((0.5 - a) / s) - self._standardized_cumulative((-0.5 - a) / s)

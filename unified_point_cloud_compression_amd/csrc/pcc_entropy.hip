@@ -140,3 +140,65 @@ extern "C" int pcc_eb_encode(const float* z, int64_t n, int32_t c, const float* 
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Differentiable Gaussian likelihood of the training forward (`GaussianConditional._likelihood` +
+// likelihood lower bound; reference call sites `model/entropy_models.py:312-316,327-331`, rate term `loss.py:77-79`):
+//   s = max(scale, 0.11), a = |v - mean|,  lik = max(Phi((.5 - a)/s) - Phi((-.5 - a)/s), 1e-9)
+// forward and backward as one element-wise kernel each (the torch chain is ~15 launches per direction).  Gradients
+// follow CompressAI's LowerBound rule: a bounded quantity passes the gradient when it is inside the bound or when the
+// gradient would move it back inside (g < 0).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gauss_lik_fwd(const float* __restrict__ v, const float* __restrict__ scale,
+                                                       const float* __restrict__ mean, long long n, float* __restrict__ lik) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const float s = fmaxf(scale[t], SCALE_BOUND);
+  const float a = fabsf(v[t] - (mean ? mean[t] : 0.f));
+  lik[t] = fmaxf(std_cum((0.5f - a) / s) - std_cum((-0.5f - a) / s), LIK_BOUND);
+}
+
+__global__ void __launch_bounds__(256) k_gauss_lik_bwd(const float* __restrict__ v, const float* __restrict__ scale,
+                                                       const float* __restrict__ mean, const float* __restrict__ g,
+                                                       long long n, float* __restrict__ dv, float* __restrict__ dscale,
+                                                       float* __restrict__ dmean) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const float sc = scale[t];
+  const float s = fmaxf(sc, SCALE_BOUND);
+  const float d = v[t] - (mean ? mean[t] : 0.f);
+  const float a = fabsf(d);
+  const float u1 = (0.5f - a) / s, u2 = (-0.5f - a) / s;
+  const float raw = std_cum(u1) - std_cum(u2);
+  float gl = g[t];
+  if (!(raw >= LIK_BOUND || gl < 0.f)) gl = 0.f;                      // LowerBound(1e-9) on the likelihood
+  const float inv_sqrt_2pi = 0.39894228040143267794f;
+  const float p1 = inv_sqrt_2pi * expf(-0.5f * u1 * u1), p2 = inv_sqrt_2pi * expf(-0.5f * u2 * u2);
+  const float dl_da = (p2 - p1) / s;
+  const float dl_ds = (u2 * p2 - u1 * p1) / s;
+  const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);          // torch.abs: zero gradient at 0
+  const float gv = gl * dl_da * sg;
+  if (dv) dv[t] = gv;
+  if (dmean) dmean[t] = -gv;
+  if (dscale) {
+    const float gs = gl * dl_ds;
+    dscale[t] = (sc >= SCALE_BOUND || gs < 0.f) ? gs : 0.f;          // LowerBound(0.11) on the scale
+  }
+}
+
+extern "C" int pcc_gauss_lik_fwd(const float* v, const float* scale, const float* mean, int64_t n, float* lik, void* stream) {
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(v && scale && lik, "pcc_gauss_lik_fwd: NULL array");
+  k_gauss_lik_fwd<<<(unsigned)pcc_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(v, scale, mean, n, lik);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_gauss_lik_bwd(const float* v, const float* scale, const float* mean, const float* grad_lik, int64_t n,
+                                 float* dv, float* dscale, float* dmean, void* stream) {
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(v && scale && grad_lik, "pcc_gauss_lik_bwd: NULL array");
+  k_gauss_lik_bwd<<<(unsigned)pcc_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(v, scale, mean, grad_lik, n, dv, dscale, dmean);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}

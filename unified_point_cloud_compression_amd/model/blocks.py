@@ -36,11 +36,8 @@ class MinkowskiGDN(GDN):
     def forward_rows(self, feats):
         """[N,C] canonical-order rows -> GDN / IGDN rows."""
         if torch.is_grad_enabled() and (feats.requires_grad or self.gamma.requires_grad):
-            # training path (BASELINE config 4): the [N,C]x[C,C] product is a plain library GEMM, autograd does the rest
-            beta = self.beta_reparam(self.beta)
-            gamma = self.gamma_reparam(self.gamma)
-            norm = feats.abs() @ gamma.t() + beta
-            return feats * norm if self.inverse else feats / norm
+            from ..autograd import GdnFn            # training path (BASELINE config 4): fused forward, library-kernel backward
+            return GdnFn.apply(feats, self.beta, self.gamma, self)
         feats = feats.contiguous()
         out = torch.empty_like(feats)
         packed, beta_eff = self._pack()

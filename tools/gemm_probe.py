@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
-"""Plain GEMM through the MFMA conv kernel (identity map): gemm_probe.py M K N -> ms, TFLOP/s (diagnostic)."""
-import os, sys
+"""Dense GEMM [n, cin] x [cin, ncol] through the library's MFMA path (K = 1 convolution), for profiling the generative
+transposed convolutions' GEMM half: gemm_probe.py N CIN NCOL [reps].  PCC_DBG selects diagnostic variants."""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from unified_point_cloud_compression_amd import sparse as S
-M, K, N = (int(v) for v in sys.argv[1:4])
+import torch  # noqa: E402
+
+from unified_point_cloud_compression_amd import sparse as S  # noqa: E402
+
+n, cin, ncol = (int(v) for v in sys.argv[1:4])
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 dev = torch.device("cuda:0")
-x = torch.randn(M, K, device=dev)
-w = torch.nn.Parameter(torch.randn(K, N, device=dev) * 0.05)
+x = torch.randn(n, cin, device=dev)
+w = torch.nn.Parameter(torch.randn(cin, ncol, device=dev) * 0.05)
 pk = S.PackedConv().get(w)
-for _ in range(2):
-    y = S.conv_forward(x, pk, None, 1, K, N, None, M)
+S.conv_forward(x, pk, None, 1, cin, ncol, None, n)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(5):
-    y = S.conv_forward(x, pk, None, 1, K, N, None, M)
+for _ in range(reps):
+    S.conv_forward(x, pk, None, 1, cin, ncol, None, n)
 e1.record()
 torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 5
-print(f"M {M} K {K} N {N}: {ms:.3f} ms  {2e-9 * M * K * N / ms:.1f} TFLOP/s  out {M * N * 4 / 1e9:.2f} GB -> {M * N * 4 / ms / 1e6:.0f} GB/s written")
+ms = e0.elapsed_time(e1) / reps
+print(f"PCC_DBG={os.environ.get('PCC_DBG', '0')} split={os.environ.get('PCC_MFMA_SPLIT', '1')} n {n} cin {cin} ncol {ncol}: {ms:.3f} ms  "
+      f"{2.0 * n * cin * ncol / ms / 1e9:.1f} TFLOP/s  out {n * ncol * 4 / ms / 1e6:.0f} GB/s")

@@ -25,6 +25,7 @@ static constexpr int MAXK = 128;    // kernel offsets per segment (K <= 125)
 static constexpr int MAXK_T = 512;  // offsets of the input-stationary transposed conv (a flat GEMM: 7^3 composites fit)
 
 enum { MODE_CONV = 0, MODE_GDN = 1, MODE_IGDN = 2 };
+static constexpr int PAIR_BM_C = 128;   // rows per pair tile (pair-list GEMMs)
 __device__ inline float act1(float v, int act, float slope);
 
 struct ConvArgs {
@@ -42,6 +43,7 @@ struct ConvArgs {
   const int* tile_k = nullptr;    // pair mode: kernel offset of each 128-pair tile
   const long long* n_tiles = nullptr;   // pair mode: device count of tiles (the grid is an upper bound)
   const unsigned char* featb = nullptr; // split path: bf16 planes of feat, [n_in][cin/32][3][32] (k_feat_split)
+  int dbg = 0;                          // diagnostics (env PCC_DBG): 1 = no output stores, 2 = no MFMA phase, 4 = no staging loads
   int cin, cout, cout_pad;
   int cb_log2;            // log2(CB), CB = min(cin, 32)
   int ppo;                // pieces per offset = cin / CB
@@ -609,13 +611,13 @@ __global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const unsigned off = rows[j] >= 0 ? (unsigned)rows[j] * row_bytes + (unsigned)cbi * 192u + (unsigned)a_w[j] * 16u : BUF_OOB;
-      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (a.dbg & 4) ? BUF_OOB : off, 0, 0));
     }
     const unsigned wbase = (unsigned)((act_kid[ai] * a.ppo + cbi) * a.cout_pad + colblock) * 192u;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const unsigned off = b_row[j] >= 0 ? wbase + (unsigned)(j * 256 + tid) * 16u : BUF_OOB;
-      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (a.dbg & 4) ? BUF_OOB : off, 0, 0));
     }
   };
 
@@ -655,6 +657,7 @@ __global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs, not next to its use
+    if (a.dbg & 2) continue;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[3][TM], bf[3][TN];
@@ -681,6 +684,7 @@ __global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
     }
   }
 
+  if (a.dbg & 1) { if (acc[0][0][0] != 12345.678f) return; }
   // ---- epilogue: bias, activation (or GDN), store -------------------------------------------
   // Full tiles written to consecutive rows take a branch-free path: one base pointer per lane, the activation chosen
   // once per tile.  (The general loop below costs ~50 instructions per element -- row-list lookups, tail checks and
@@ -735,6 +739,187 @@ __global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
         a.out[orow * a.cout + col] = v;
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent form of the split kernel for the GEMM-shaped launches -- dense [n, cin] x [cin, ncol] (generative transposed
+// convolutions, 1x1 convolutions, GDN) and the gathered pair GEMMs (one kernel offset per 128-pair tile).  Their
+// reduction is only cin deep (4 chunks at cin = 128): with one tile per workgroup the tile's first loads (full memory
+// latency) and its drain were exposed on every tile, and the matrix pipe idled two thirds of the time (SQ counters,
+// DESIGN.md section 8).  Here a workgroup walks a strided sequence of tiles as ONE chunk stream: the loads of the next
+// tile's first chunk are in flight while the current tile's last chunk is multiplied and its accumulators are stored.
+// Work ids are dealt in contiguous ranges per XCD (L2 locality as in k_conv_mfma); the dense form visits row tiles in
+// groups of 8 per column block so that a block's weights are fetched once per group.
+// ------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ void __launch_bounds__(256, 2) k_gemm_bf(ConvArgs a) {
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int LDU = 13;
+  __shared__ __attribute__((aligned(16))) uint4 As[BM * LDU];
+  __shared__ __attribute__((aligned(16))) uint4 Bs[BN * LDU];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool pair_mode = (a.pair_in != nullptr);
+  const int gy = a.cout_pad / BN;
+  const long long n_tiles = pair_mode ? *a.n_tiles : (a.n_out + BM - 1) / BM;
+  const bool groups = !pair_mode && gy > 8;
+  const long long total = (groups ? (n_tiles + 7) / 8 * 8 : n_tiles) * gy;
+  const int nwg_x = gridDim.x >> 3;
+  const long long per = (total + 7) / 8;
+  const long long lo = (long long)(blockIdx.x & 7) * per, hi = min(total, lo + per);
+
+  constexpr int NA = (BM * 12 + 255) / 256, NB = (BN * 12 + 255) / 256;
+  int a_row[NA], a_w[NA], b_row[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) { const int u = j * 256 + tid; a_row[j] = u / 12; a_w[j] = u - a_row[j] * 12; if (u >= BM * 12) a_row[j] = -1; }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) { const int u = j * 256 + tid; b_row[j] = (u < BN * 12) ? u / 12 : -1; }
+
+  const int wm = w / WN, wn = w % WN;
+  const int half = lane >> 5, r31 = lane & 31;
+  const unsigned row_bytes = (unsigned)a.cin * 6u;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(a.featb), (short)0, (int)(unsigned)((size_t)a.n_in * row_bytes), 0x00020000);
+  const float* wb = a.wp + a.wp_elems;
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wb), (short)0, (int)(unsigned)((size_t)bf_plane_elems(a.wp_elems) * 4), 0x00020000);
+
+  struct Work { long long id; int tile, colblock, pos0, npos, kid; };
+  auto decode = [&](long long id, Work& wk) {           // first valid work item at or after `id` (stride nwg_x); id >= hi: none
+    for (; id < hi; id += nwg_x) {
+      int tile, cb;
+      if (groups) { const long long g = id / (8 * gy); const int rem = (int)(id - g * 8 * gy); cb = rem >> 3; tile = (int)(g * 8 + (rem & 7)); }
+      else { tile = (int)(id / gy); cb = (int)(id - (long long)tile * gy); }
+      if (tile < n_tiles) {
+        wk.tile = tile; wk.colblock = cb * BN; wk.pos0 = tile * BM;
+        wk.npos = pair_mode ? BM : (int)min((long long)BM, a.n_out - (long long)tile * BM);
+        wk.kid = pair_mode ? a.tile_k[tile] : 0;
+        break;
+      }
+    }
+    wk.id = id;
+  };
+  auto load_rows = [&](const Work& wk, int (&rows)[NA]) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int rc = min(max(a_row[j], 0), wk.npos - 1);        // tail rows repeat the tile's last row (never stored)
+      rows[j] = pair_mode ? a.pair_in[wk.pos0 + rc] : (wk.pos0 + rc);
+      if (a_row[j] < 0) rows[j] = -1;
+    }
+  };
+  auto issue = [&](const Work& wk, int cbi, const int (&rows)[NA], uint4 (&av)[NA], uint4 (&bv)[NB]) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const unsigned off = rows[j] >= 0 ? (unsigned)rows[j] * row_bytes + (unsigned)cbi * 192u + (unsigned)a_w[j] * 16u : BUF_OOB;
+      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+    }
+    const unsigned wbase = (unsigned)((wk.kid * a.ppo + cbi) * a.cout_pad + wk.colblock) * 192u;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const unsigned off = b_row[j] >= 0 ? wbase + (unsigned)(j * 256 + tid) * 16u : BUF_OOB;
+      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+    }
+  };
+
+  Work cur, nxt;
+  decode(lo + (blockIdx.x >> 3), cur);
+  if (cur.id >= hi) return;
+  int rows_cur[NA], rows_nxt[NA];
+  uint4 av[NA], bv[NB];
+  load_rows(cur, rows_cur);
+  issue(cur, 0, rows_cur, av, bv);
+  int c = 0;                                             // chunk of `cur` whose data sits in av / bv
+  const int ppo = a.ppo;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // what the chunk after (cur, c) is: the same tile's next piece, or the first piece of the next work item
+  bool have_nxt = false;
+  if (ppo == 1) { decode(cur.id + nwg_x, nxt); have_nxt = nxt.id < hi; if (have_nxt) load_rows(nxt, rows_nxt); }
+
+  while (true) {
+    __syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if (a_row[j] >= 0) As[a_row[j] * LDU + a_w[j]] = av[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (b_row[j] >= 0) Bs[b_row[j] * LDU + (j * 256 + tid) - b_row[j] * 12] = bv[j];
+    __syncthreads();
+    const bool last_piece = (c + 1 == ppo);
+    // prefetch the following chunk (possibly of the next tile) so that it flies during this chunk's MFMAs
+    if (!last_piece) {
+      issue(cur, c + 1, rows_cur, av, bv);
+      if (c + 2 == ppo) { decode(cur.id + nwg_x, nxt); have_nxt = nxt.id < hi; if (have_nxt) load_rows(nxt, rows_nxt); }
+    } else if (have_nxt) {
+      issue(nxt, 0, rows_nxt, av, bv);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[p][i] = __builtin_bit_cast(bf16x8, As[((wm * TM + i) * 32 + r31) * LDU + p * 4 + ks * 2 + half]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bf[p][j] = __builtin_bit_cast(bf16x8, Bs[((wn * TN + j) * 32 + r31) * LDU + p * 4 + ks * 2 + half]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {           // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (!last_piece) { ++c; continue; }
+
+    // ---- tile finished: bias, activation (or GDN), store; then move on to the prefetched tile ----------------------
+    {
+      const int pos0 = cur.pos0, npos = cur.npos, colblock = cur.colblock;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = colblock + (wn * TN + j) * 32 + r31;
+        const float b = (a.bias && col < a.cout) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int r = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            float v = acc[i][j][e] + b;
+            acc[i][j][e] = 0.f;
+            if (r >= npos || col >= a.cout) continue;
+            const size_t o = (size_t)(pos0 + r) * a.cout + col;
+            if (MODE == MODE_CONV) v = act1(v, a.act, a.slope);
+            else { const float x = a.feat[o]; v = (MODE == MODE_GDN) ? x / v : x * v; }
+            a.out[o] = v;
+          }
+        }
+      }
+    }
+    if (!have_nxt) break;
+    cur = nxt;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) rows_cur[j] = rows_nxt[j];
+    c = 0;
+    have_nxt = false;
+    if (ppo == 1) { decode(cur.id + nwg_x, nxt); have_nxt = nxt.id < hi; if (have_nxt) load_rows(nxt, rows_nxt); }
   }
 }
 
@@ -1404,6 +1589,30 @@ static bool split_ok(const ConvArgs& a) {
          bf_plane_elems(a.wp_elems) * 4 <= BUF_MAX_BYTES;
 }
 
+static bool g_gemm_persistent = getenv("PCC_GEMM_PERSISTENT") ? atoi(getenv("PCC_GEMM_PERSISTENT")) != 0 : false;   // measured slower (2 workgroups per CU): off
+static int g_dbg = getenv("PCC_DBG") ? atoi(getenv("PCC_DBG")) : 0;
+
+// persistent GEMM form (identity rows or pair lists; a.featb set): 2 workgroups per CU (the kernel needs ~200 VGPRs)
+template <int MODE>
+static int launch_gemm_bf(const ConvArgs& a, hipStream_t s) {
+  int dev = 0, cus = 0;
+  PCC_CHECK_HIP(hipGetDevice(&dev));
+  PCC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int bn = bn_for(a.cout);
+  const long long gy = a.cout_pad / bn;
+  const long long tiles128 = a.pair_in ? a.n_out / PAIR_BM_C : pcc_cdiv(a.n_out, 128);
+  long long work = tiles128 * gy;
+  long long grid = (long long)cus * 2;
+  if (work < grid) grid = work;
+  grid = (grid + 7) / 8 * 8;
+  if (grid < 8) grid = 8;
+  if (bn == 128) k_gemm_bf<2, 2, 2, 2, MODE><<<(unsigned)grid, 256, 0, s>>>(a);
+  else if (bn == 64) k_gemm_bf<2, 2, 2, 1, MODE><<<(unsigned)grid, 256, 0, s>>>(a);
+  else k_gemm_bf<4, 1, 1, 1, MODE><<<(unsigned)grid, 256, 0, s>>>(a);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
 template <int MODE>
 static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t s) {
   ConvArgs a = a_in;
@@ -1421,6 +1630,8 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
                    a.wp_elems * 4 <= BUF_MAX_BYTES;
   const bool split = split_ok(a);
   if (split) PCC_TRY(make_planes(a, MODE != MODE_CONV, s));
+  a.dbg = g_dbg;
+  if (split && !a.hdr && g_gemm_persistent) return launch_gemm_bf<MODE>(a, s);
 #define PCC_LAUNCH_MFMA(WM, WN, TM, TN, BMV)                                                     \
   do {                                                                                           \
     if (split) k_conv_mfma_bf<WM, WN, TM, TN, MODE><<<grid(BMV), 256, 0, s>>>(a);                \
@@ -1861,7 +2072,8 @@ extern "C" int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t ci
     const bool buf = g_mfma_buf && n_in * cin * 4 <= BUF_MAX_BYTES && a.wp_elems * 4 <= BUF_MAX_BYTES;
     const bool split = split_ok(a);
     if (split) PCC_TRY(make_planes(a, false, s));
-    if (bn == 128) { if (split) k_conv_mfma_bf<2, 2, 2, 2, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    if (split && g_gemm_persistent) PCC_TRY(launch_gemm_bf<MODE_CONV>(a, s));
+    else if (bn == 128) { if (split) k_conv_mfma_bf<2, 2, 2, 2, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     else if (bn == 64) { if (split) k_conv_mfma_bf<2, 2, 2, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     else { if (split) k_conv_mfma_bf<4, 1, 1, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<4, 1, 1, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<4, 1, 1, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     PCC_LAUNCH_CHECK();
@@ -2049,7 +2261,8 @@ extern "C" int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t ci
     const bool buf = g_mfma_buf && n_in * cin * 4 <= BUF_MAX_BYTES && a.wp_elems * 4 <= BUF_MAX_BYTES;
     const bool split = split_ok(a);
     if (split) PCC_TRY(make_planes(a, false, s));
-    if (bn == 128) { if (split) k_conv_mfma_bf<2, 2, 2, 2, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
+    if (split && g_gemm_persistent) PCC_TRY(launch_gemm_bf<MODE_CONV>(a, s));
+    else if (bn == 128) { if (split) k_conv_mfma_bf<2, 2, 2, 2, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     else if (bn == 64) { if (split) k_conv_mfma_bf<2, 2, 2, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     else { if (split) k_conv_mfma_bf<4, 1, 1, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<4, 1, 1, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<4, 1, 1, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     PCC_LAUNCH_CHECK();
@@ -2230,6 +2443,18 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
   if (o >= a.n_out) return;
   const int cvec = a.cout / VEC;
   const int t0 = a.first[o], t1 = a.first[o + 1];
+  // optional constant per existing neighbour (two fused affine layers): the lanes of the row's group fetch the ex_K presence
+  // flags side by side and share them by ballot (one load per lane instead of ex_K dependent loads: the serial loop cost
+  // 2.1 ms on the level-2 head in round 2)
+  unsigned long long present = 0;
+  if (a.ex_nbr) {
+    for (int k0 = 0; k0 < a.ex_K; k0 += lpr) {
+      const int k = k0 + cl;
+      const bool v = k < a.ex_K && a.ex_nbr[(long long)k * a.n_out + o] >= 0;
+      const unsigned long long bal = __ballot(v);
+      present |= ((bal >> ((lane >> a.lpr_log2) << a.lpr_log2)) & (lpr == 64 ? ~0ull : ((1ull << lpr) - 1ull))) << k0;
+    }
+  }
   for (int cv = cl; cv < cvec; cv += lpr) {
     VT acc;
     thin_zero(acc);
@@ -2246,9 +2471,10 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
 #pragma unroll
       for (int u = 0; u < JB; ++u) thin_acc(acc, x[u]);     // fixed order: pair id ascending
     }
-    if (a.ex_nbr) {              // neighbour k of this row exists -> its constant contribution (fused affine layers)
-      for (int k = 0; k < a.ex_K; ++k)
-        if (a.ex_nbr[(long long)k * a.n_out + o] >= 0) thin_acc(acc, reinterpret_cast<const VT*>(a.ex_bias + (long long)k * a.cout)[cv]);
+    for (unsigned long long pr = present; pr;) {          // neighbour k exists -> its constant contribution, ascending k
+      const int k = __ffsll((long long)pr) - 1;
+      pr &= pr - 1;
+      thin_acc(acc, reinterpret_cast<const VT*>(a.ex_bias + (long long)k * a.cout)[cv]);
     }
     VT b;
     thin_zero(b);

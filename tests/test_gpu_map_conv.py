@@ -307,3 +307,4 @@ def test_split_path_accuracy(cin, cout, ks):
     assert rms_split <= 3.0 * rms_fp32 + 1e-8                    # fp32-level error, not bf16-level (which would be ~1e-3)
     assert_close(got_split, want64, what="split path vs float64")
     assert not np.array_equal(got_split, got_fp32) or cin < 32   # the two paths really are different kernels
+

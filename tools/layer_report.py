@@ -78,6 +78,7 @@ def spy_h(feats, packed_w0, bias0, cmid, w2, bias2, cset, kmap):
 
 S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr, S.convt_forward_rows = True, spy, spy_t, spy_c, spy_r
 S.conv_head_forward = spy_h
+
 bench.step(model, pc, q)
 torch.cuda.synchronize()
 tot_ms = tot_fl = 0

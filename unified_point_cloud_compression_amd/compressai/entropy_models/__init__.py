@@ -142,12 +142,12 @@ class EntropyModel(nn.Module):
         per = lib.pcc_rans_stream_symbols(n, c, ng, segs)
         cap = lib.pcc_rans_container_max_bytes(per, ns)
         out = torch.empty(cap, dtype=torch.uint8, device=dev)
-        nb = torch.zeros(1, dtype=torch.int64, device=dev)
+        nb = L.counter()
         ws = L.workspace(lib.pcc_rans_streams_ws_bytes(per, ns), dev)
         L.call("pcc_rans_encode_streams", L.ptr(sym), L.ptr(idx.contiguous()) if idx is not None else None, n, c, ng, segs,
-               L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._enc_table(dev)), L.ptr(out), L.ptr(nb),
+               L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._enc_table(dev)), L.ptr(out), L.cptr(nb),
                L.ptr(ws), ws.numel(), L.stream())
-        return out[:int(nb.item())].cpu().numpy().tobytes()
+        return out[:int(L.read(nb)[0])].cpu().numpy().tobytes()
 
     def decompress_rows(self, data, n, c, idx=None, device=None, check=None):
         """bytes -> sym [N,C] int32 on `device`.  `check`: list collecting the status words for a deferred check

@@ -173,6 +173,44 @@ def workspace(nbytes, device):
     return buf
 
 
+# ---- zero-copy counters --------------------------------------------------------------------------------------
+# Sizes the host needs next (rows of a derived coordinate set, a canonical-order flag, bytes of a bitstream) are written
+# by the kernels straight into pinned host memory (device-visible at the same address under HIP's unified addressing):
+# the host zeroes the slot, launches, synchronises the stream and reads -- no device allocation, no fill kernel and no
+# device->host copy launch per read (round 1: ~40 `.item()` reads per step, 25-50 us of idle GPU each).
+_pin = {"buf": None, "next": 0}
+_PIN_SLOTS, _PIN_WORDS = 1024, 4
+PINNED_COUNTERS = os.environ.get("PCC_PINNED_COUNTERS", "0") != "0"   # measured 0.3 ms/step slower than `.item()` reads (round 2): off
+
+
+def counter(n=1, dtype=torch.int64):
+    """Zeroed pinned host tensor of `n` (<= 4) int64 (or 2n int32) words for a kernel to write into."""
+    if not PINNED_COUNTERS:           # A/B switch: plain device counters read back with a copy
+        return torch.zeros(n, dtype=dtype, device="cuda")
+    if _pin["buf"] is None:
+        _pin["buf"] = torch.zeros((_PIN_SLOTS, _PIN_WORDS), dtype=torch.int64).pin_memory()
+    slot = _pin["buf"][_pin["next"]]
+    _pin["next"] = (_pin["next"] + 1) % _PIN_SLOTS
+    slot.zero_()
+    t = slot if dtype == torch.int64 else slot.view(dtype)
+    return t[:n]
+
+
+def cptr(t):
+    """Pointer of a pinned counter as a kernel argument."""
+    if not (t.is_pinned() or t.is_cuda):
+        raise PccError("counter() tensors only")
+    return t.data_ptr()
+
+
+def read(t):
+    """Values of a counter once the kernels that write it have finished."""
+    if t.is_cuda:
+        return t.tolist()
+    torch.cuda.current_stream().synchronize()
+    return t.tolist()
+
+
 def call(name, *args):
     lib = load()
     check(getattr(lib, name)(*args), name)

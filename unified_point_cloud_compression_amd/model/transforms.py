@@ -12,6 +12,8 @@ Module structure, attribute names and Sequential indices equal the reference's (
     all ~40 candidates per parent with the 128-channel up-sampled features; the up-sampled features themselves are then
     computed only for the rows the top-k keeps (`SparseSynthesisTransform.FUSE_UP_PREDICT`).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -151,7 +153,9 @@ class SparseSynthesisTransform(nn.Module):
 
     # ---- up-sampling block + occupancy head as one composite generative convolution (inference) ------------
     FUSE_UP_PREDICT = True
-    FUSE_MIN_HEAD_CHANNELS = 32      # narrower heads (predict_3: 32 -> 16) gain nothing: the per-pair buffer dominates
+    # all three heads are fused since round 2 (round 1 left predict_3, 32 -> 16, layer-wise: with the fp32 GEMM its per-pair
+    # buffer and the 7-wide probing cost what the narrower convolution saved; with the split-path GEMM it is 0.9 ms ahead)
+    FUSE_MIN_HEAD_CHANNELS = int(os.environ.get("PCC_FUSE_MIN_HEAD", "16"))
 
     def _fused_weights(self, gen, c0):
         """(packed composite kernel [343, Cin, Ch], neighbour-existence bias [27, Ch]) of head_conv0(genT(.)), cached per

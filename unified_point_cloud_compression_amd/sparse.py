@@ -192,7 +192,7 @@ class CoordSet:
             dims = [(nb.hi[i] - nb.lo[i]) // new_stride + 1 for i in range(3)]
             h = (C.c_int32 * 8)(nb.lo[0], nb.lo[1], nb.lo[2], dims[0], dims[1], dims[2], new_stride, nb.bmax + 1)
             words = lib.pcc_grid_words(h)
-            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            cnt = L.counter()
             out = torch.empty(max(self.n, 1), dtype=torch.int64, device=dev)
             if USE_GRID and STRIDE_BY_GRID and self.n > 0 and words < (1 << 31) and words * 12 <= GRID_MAX_BYTES:
                 # through the occupancy bitmap of the coarse lattice: no sort, and the coarse set's grid index for free
@@ -200,16 +200,16 @@ class CoordSet:
                 rank = torch.empty(words, dtype=torch.int32, device=dev)
                 ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
                 L.call("pcc_coords_stride_grid", L.ptr(self.keys), self.n, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
-                       L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-                n = int(cnt.item())
+                       L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+                n = int(L.read(cnt)[0])
                 cs = CoordSet(out[:n].clone() if n < self.n // 2 else out, n, new_stride, nb)
                 cs._grid = (bits, rank, h)
                 self._derived[key] = cs
                 return cs
             ws = L.workspace(lib.pcc_stride_ws_bytes(self.n), dev)
             L.call("pcc_coords_stride", L.ptr(self.keys), self.n, new_stride, self.bounds.bit_mask(), L.ptr(out),
-                   L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-            n = int(cnt.item())
+                   L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+            n = int(L.read(cnt)[0])
             self._derived[key] = CoordSet(out[:n].clone() if n < self.n // 2 else out, n, new_stride, nb)
         return self._derived[key]
 
@@ -255,11 +255,11 @@ class CoordSet:
                 bits = torch.empty(words, dtype=torch.int64, device=dev)
                 rank = torch.empty(words, dtype=torch.int32, device=dev)
                 out = torch.empty(min(m, cells), dtype=torch.int64, device=dev)
-                cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+                cnt = L.counter()
                 ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
                 L.call("pcc_coords_expand_grid", L.ptr(self.keys), self.n, ksize, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
-                       L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-                n = int(cnt.item())
+                       L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+                n = int(L.read(cnt)[0])
                 cs = CoordSet(out[:n].clone() if n < out.numel() // 2 else out, n, ts_out, ob)
                 cs._grid = (bits, rank, h)
                 self._derived[key] = cs
@@ -271,23 +271,23 @@ class CoordSet:
                 out = torch.empty(m, dtype=torch.int64, device=dev)
                 pair_ids = torch.empty(m, dtype=torch.int32, device=dev)
                 first = torch.empty(m + 1, dtype=torch.int32, device=dev)
-                cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+                cnt = L.counter()
                 ws = L.workspace(L.load().pcc_expand_csr_ws_bytes(self.n, ksize), dev)
-                L.call("pcc_coords_expand_csr", L.ptr(self.keys), self.n, ksize, ts_out, h, L.ptr(out), L.ptr(cnt),
+                L.call("pcc_coords_expand_csr", L.ptr(self.keys), self.n, ksize, ts_out, h, L.ptr(out), L.cptr(cnt),
                        L.ptr(pair_ids), L.ptr(first), L.ptr(ws), ws.numel(), L.stream())
-                n = int(cnt.item())
+                n = int(L.read(cnt)[0])
                 cs = CoordSet(out[:n].clone(), n, ts_out, ob)
                 self._derived[key] = cs
                 self._derived[("csr", ksize, ts_out)] = (first[:n + 1].clone(), pair_ids)
                 return cs
             cap = max(self.n * K, 1)
             out = torch.empty(cap, dtype=torch.int64, device=dev)
-            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            cnt = L.counter()
             nb = L.load().pcc_expand_ws_bytes(self.n, ksize)
             ws = L.workspace(nb, dev)
             L.call("pcc_coords_expand", L.ptr(self.keys), self.n, ksize, ts_out, ob.bit_mask(), L.ptr(out),
-                   L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-            n = int(cnt.item())
+                   L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+            n = int(L.read(cnt)[0])
             self._derived[key] = CoordSet(out[:n].clone(), n, ts_out, ob)
         return self._derived[key]
 
@@ -333,9 +333,9 @@ class CoordSet:
 
 
 def _canon_check(keys, n):
-    flag = torch.empty(1, dtype=torch.int32, device=keys.device)
-    L.call("pcc_keys_is_canonical", L.ptr(keys), n, L.ptr(flag), L.stream())
-    return bool(flag.item())
+    flag = L.counter(1, torch.int32)
+    L.call("pcc_keys_is_canonical", L.ptr(keys), n, L.cptr(flag), L.stream())
+    return bool(L.read(flag)[0])
 
 
 def pack_keys(coords):
@@ -357,8 +357,7 @@ def bounds_of(coords):
     if coords.shape[0] == 0:
         return Bounds(0, (0, 0, 0), (0, 0, 0))
     c = coords.floor() if coords.dtype.is_floating_point else coords
-    mn = c.amin(dim=0).tolist()
-    mx = c.amax(dim=0).tolist()
+    mn, mx = torch.stack([c.amin(dim=0), c.amax(dim=0)]).tolist()          # one device->host read
     if mn[0] < 0:
         raise L.PccError("negative batch index")
     return Bounds(int(mx[0]), [int(v) for v in mn[1:]], [int(v) for v in mx[1:]])
@@ -386,11 +385,11 @@ def coordset_from_coords(coords, tensor_stride):
         rank = torch.empty(words, dtype=torch.int32, device=dev)
         ukeys = torch.empty(n, dtype=torch.int64, device=dev)
         first_user = torch.empty(n, dtype=torch.int32, device=dev)
-        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        cnt = L.counter(2)
         ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
         L.call("pcc_keys_canonicalize_grid", L.ptr(keys), n, h, L.ptr(bits), L.ptr(rank), L.ptr(ukeys), L.ptr(first_user),
-               L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-        nu, off_lattice = (int(v) for v in cnt.tolist())
+               L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+        nu, off_lattice = (int(v) for v in L.read(cnt))
         if not off_lattice:
             cs = CoordSet(ukeys[:nu].clone() if nu < n else ukeys, nu, tensor_stride, b)
             cs._grid = (bits, rank, h)
@@ -407,11 +406,11 @@ def coordset_from_coords(coords, tensor_stride):
     L.call("pcc_sort_keys", L.ptr(keys), n, b.bit_mask(), L.ptr(skeys), L.ptr(perm), L.ptr(ws), ws.numel(), L.stream())
     ukeys = torch.empty(n, dtype=torch.int64, device=dev)
     first = torch.empty(n, dtype=torch.int32, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    cnt = L.counter()
     ws = L.workspace(lib.pcc_unique_ws_bytes(n), dev)
-    L.call("pcc_unique_sorted", L.ptr(skeys), n, L.ptr(ukeys), L.ptr(first), L.ptr(cnt), L.ptr(ws), ws.numel(),
+    L.call("pcc_unique_sorted", L.ptr(skeys), n, L.ptr(ukeys), L.ptr(first), L.cptr(cnt), L.ptr(ws), ws.numel(),
            L.stream())
-    nu = int(cnt.item())
+    nu = int(L.read(cnt)[0])
     # stable sort => first[] points at the smallest user row of each run
     first_user = perm.long()[first[:nu].long()]
     cs = CoordSet(ukeys[:nu].clone() if nu < n else ukeys, nu, tensor_stride, b)
@@ -555,7 +554,7 @@ def convt_forward_csr(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT
     return out
 
 
-def convt_forward_rows(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT_NONE, slope=0.01):
+def convt_forward_rows(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT_NONE, slope=0.01, pairs_bound=None):
     """Transposed conv evaluated for the `n_out` output rows whose CSR pair lists are given (work ~ their pairs)."""
     feats = feats.contiguous()
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
@@ -563,7 +562,9 @@ def convt_forward_rows(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.AC
         return out
     first, pair_ids = csr
     lib = L.load()
-    pairs = int(first[n_out].item())
+    # (an upper bound on the CSR entries would save this read, but the pair GEMM's grid, its padding memset and the
+    #  bucket scan are sized by it: measured +1 ms per step with the bound ceil(k/2)^3 per row -- the exact count stays)
+    pairs = int(first[n_out].item()) if pairs_bound is None else pairs_bound
     T = torch.empty(max(lib.pcc_convt_rows_t_elems(pairs, K, cout), 1), dtype=torch.float32, device=feats.device)
     ws = L.workspace(lib.pcc_convt_rows_int_ws_bytes(pairs, K), feats.device)
     b = bias.detach().reshape(-1).contiguous() if bias is not None else None

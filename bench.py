@@ -19,7 +19,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32-input matrix peak (= the vector rate)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA peak (~2.5 PF)
+SPLIT_TERMS = 6                 # bf16 MFMA terms per fp32 product on the split path (k_conv_mfma_bf)
 BITS = 10
 
 R2_CONFIG = {
@@ -408,6 +410,8 @@ def main():
 
     if rank == 0:
         traffic, traffic_note = pmc_traffic()
+        split_on = os.environ.get("PCC_MFMA_SPLIT", "1") != "0"
+        peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if split_on else PEAK_FP32_MFMA_TFLOPS
         ms_step = dt_max / args.steps * 1e3
         # conv launches: only MFMA-shaped ones are event-timed inside the library
         ach = (flops_step * args.steps / (conv_ms.value * 1e-3) / 1e12) if conv_ms.value > 0 else None
@@ -422,17 +426,29 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: one synthetic longdress-like vox{args.bits} frame per GPU "
                                    f"({n_points} points on rank 0), R2 architecture, random-init weights, q=[[0.5,0.5]], "
                                    f"1 block; entropy coder in the timed region: {args.coder}",
+                       "arithmetic": ("fp32 features and accumulation; matrix products evaluated on the bf16 MFMA pipe from an exact "
+                                      "3-way bf16 split of both fp32 operands (6 cross terms; error at fp32 rounding level, "
+                                      "tests/test_gpu_map_conv.py::test_split_path_accuracy)") if split_on else "fp32-input MFMA",
                        "bpp_y_z_strings": bpp, "bpp_likelihood": rd["bpp_likelihood"], "d1_psnr": rd["d1_psnr_sym"],
                        "rate_distortion": rd, "ms_per_step_without_entropy_coder": hot_ms,
                        "frames_per_step": world, "encode_ms": recs[0][2] * 1e3, "decode_ms": recs[0][3] * 1e3,
                        "step_ms_rank0": [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_marks[:-1], step_marks)],
                        "device": arch, "cus": cu},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None, "traffic": traffic,
+            # dominant kernel family: the MFMA convolutions (k_conv_mfma_bf = fp32 products as 6 exact bf16 MFMA terms).
+            # `achieved` = ALGORITHMIC fp32 FLOPs (2*P*Cin*Cout) / event-timed launch durations; `peak` = the roof of that
+            # arithmetic for algorithmic FLOPs, i.e. the dense bf16 MFMA peak / 6 terms.  (The fp32-input MFMA pipe used in
+            # round 1 peaks at 157.3 TFLOP/s: `vs_fp32_mfma_peak`.)
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": (ach / peak) if ach else None, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
                          "alg_bytes_per_launch": (alg_bytes_step / launches_step) if launches_step else None,
-                         "kernel": "k_conv_mfma (pcc_conv_fwd)", "flop_per_step": flops_step,
-                         "pairs_per_step": pairs_step, "launches_per_step": launches_step,
+                         "kernel": "k_conv_mfma_bf (pcc_conv_fwd / pcc_conv_fwd_pairs / pcc_convt_fwd_csr GEMM): fp32 products as "
+                                   "6 bf16 MFMA terms" if split_on else "k_conv_mfma (fp32-input MFMA)",
+                         "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 split terms per fp32 product" if split_on
+                                       else "dense fp32-input MFMA peak"),
+                         "executed_bf16_tflops": (ach * SPLIT_TERMS) if (ach and split_on) else None,
+                         "vs_fp32_mfma_peak": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
+                         "flop_per_step": flops_step, "pairs_per_step": pairs_step, "launches_per_step": launches_step,
                          "avg_launch_ms": (conv_ms.value / conv_launches.value) if conv_launches.value else None,
                          "conv_ms_per_step": conv_ms.value / args.steps},
         }

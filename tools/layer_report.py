@@ -91,3 +91,11 @@ for kmap, K, cin, cout, n_in, n_out, e0, e1 in calls:
     tot_fl += fl
     print(f"{K:4d} {cin:4d} {cout:4d} {n_in:9d} {n_out:9d} {p:10d} {p/max(n_out,1):7.1f} {fl/1e9:8.1f} {ms:8.3f} {fl/ms/1e9:7.1f}")
 print(f"total {tot_fl/1e9:.1f} GF in {tot_ms:.2f} ms = {tot_fl/tot_ms/1e9:.1f} TF/s")
+if len(sys.argv) > 2:           # call list for tools/kernel_attribution.py
+    import json
+    rows = []
+    for kmap, K, cin, cout, n_in, n_out, e0, e1 in calls:
+        p = kmap if isinstance(kmap, int) else (kmap.pairs() if kmap is not None else n_out)
+        rows.append(dict(K=K, cin=cin, cout=cout, n_in=n_in, n_out=n_out, pairs=p, gflop=2.0 * p * cin * cout / 1e9,
+                         call_ms=e0.elapsed_time(e1)))
+    json.dump(rows, open(sys.argv[2], "w"))

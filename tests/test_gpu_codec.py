@@ -144,15 +144,15 @@ def test_fused_up_predict_matches_layerwise(which):
     model = _model(cfg, P)
     q = np.array([[0.5, 0.5]], dtype=np.float32)
     streams, shapes, ks, coords, qs = model.compress(t(pc), t(q), block_size=1024)
-    old_fuse, old_min = G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS
+    old_fuse, old_min, old_ratio = G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS, G.FUSE_NARROW_MIN_RATIO
     try:
-        G.FUSE_MIN_HEAD_CHANNELS = 8                # fuse every level the shapes allow, also the narrow last head
+        G.FUSE_MIN_HEAD_CHANNELS, G.FUSE_NARROW_MIN_RATIO = 8, 0      # fuse every level the shapes allow, also the narrow last head
         G.FUSE_UP_PREDICT = True
         rec_f = n(model.decompress(coordinates=coords, strings=streams, shape=shapes, k=ks, q_vals=qs))
         G.FUSE_UP_PREDICT = False
         rec_u = n(model.decompress(coordinates=coords, strings=streams, shape=shapes, k=ks, q_vals=qs))
     finally:
-        G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS = old_fuse, old_min
+        G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS, G.FUSE_NARROW_MIN_RATIO = old_fuse, old_min, old_ratio
     assert rec_f.shape == rec_u.shape == (pc.shape[0], 6)
     assert np.array_equal(rec_f[:, :3], rec_u[:, :3])                             # same occupancy decisions
     lv_f, lv_u = np.rint(rec_f[:, 3:] * 255).astype(int), np.rint(rec_u[:, 3:] * 255).astype(int)
@@ -173,9 +173,9 @@ def test_fused_path_edge_counts():
     pc = synth.random_block(2, 24, 0.1)
     q = np.array([[0.5, 0.5]], dtype=np.float32)
     streams, shapes, ks, coords, qs = model.compress(t(pc), t(q), block_size=1024)
-    old_fuse, old_min = G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS
+    old_fuse, old_min, old_ratio = G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS, G.FUSE_NARROW_MIN_RATIO
     try:
-        G.FUSE_MIN_HEAD_CHANNELS = 8
+        G.FUSE_MIN_HEAD_CHANNELS, G.FUSE_NARROW_MIN_RATIO = 8, 0
         for k_alt in ([[10 ** 9], [10 ** 9], ks[0][2]], [ks[0][0], [0], [0]]):
             out = {}
             for fuse in (True, False):
@@ -184,7 +184,7 @@ def test_fused_path_edge_counts():
             assert out[True].shape == out[False].shape
             assert np.array_equal(out[True][:, :3], out[False][:, :3])
     finally:
-        G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS = old_fuse, old_min
+        G.FUSE_UP_PREDICT, G.FUSE_MIN_HEAD_CHANNELS, G.FUSE_NARROW_MIN_RATIO = old_fuse, old_min, old_ratio
 
 
 def test_multi_block_partition_matches_oracle():

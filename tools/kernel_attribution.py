@@ -18,7 +18,11 @@ import sys
 trace = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 calls = json.load(open(sys.argv[2]))
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
-fam = [r for r in rows if re.search(r"k_conv_mfma|k_conv_wave16|k_gemm_bf", r["Kernel_Name"])]
+# convolution launches of the family: MODE_CONV instantiations only (the GDN / IGDN modes of the same kernel are not calls of
+# the list), and only the calls that take the MFMA path (thin heads with <= 4 output channels run VALU kernels)
+fam = [r for r in rows if re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>|k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0>|k_conv_wave16|k_gemm_bf<\d+, \d+, \d+, \d+, 0>",
+                                 r["Kernel_Name"])]
+calls = [c for c in calls if c["cout"] > 4 and (c["cin"] in (4, 8, 16) or c["cin"] % 32 == 0)]
 assert len(fam) >= len(calls), (len(fam), len(calls))
 fam = fam[-len(calls):]
 print("# one encode+decode step of bench.py's frame (tools/layer_report.py under rocprofv3 --kernel-trace); K < 0: generative")
@@ -31,7 +35,7 @@ for i, (c, r) in enumerate(zip(calls, fam)):
     ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
     peak = 416.7 if "_bf" in name else 157.3
-    tf = c["gflop"] / ms / 1e3
+    tf = c["gflop"] / ms
     print(f"{i:2d} {c['K']:4d} {c['cin']:4d} {c['cout']:4d} {c['n_out']:9d} {c['pairs']:10d} {c['gflop']:8.1f} {ms:9.3f} {tf:8.1f} {tf / peak:7.2f}  {name}")
     tot_f += c["gflop"]
     tot_t += ms
@@ -39,7 +43,7 @@ for i, (c, r) in enumerate(zip(calls, fam)):
     a[0] += 1
     a[1] += c["gflop"]
     a[2] += ms
-print(f"# total {tot_f:.1f} GFLOP in {tot_t:.3f} ms of MFMA-family kernels = {tot_f / tot_t / 1e3:.1f} TFLOP/s")
+print(f"# total {tot_f:.1f} GFLOP in {tot_t:.3f} ms of MFMA-family kernels = {tot_f / tot_t:.1f} TFLOP/s")
 print("# by instantiation: launches, GFLOP, ms, TFLOP/s")
 for name, (n, gf, ms) in sorted(by.items(), key=lambda kv: -kv[1][2]):
-    print(f"#   {name:48s} {n:3d} {gf:9.1f} {ms:8.3f} {gf / ms / 1e3:8.1f}")
+    print(f"#   {name:48s} {n:3d} {gf:9.1f} {ms:8.3f} {gf / ms:8.1f}")

@@ -183,13 +183,24 @@ class SparseSynthesisTransform(nn.Module):
                 cache[id(gen)] = hit = (tag, packed, cb.float().contiguous())
         return hit[1], hit[2]
 
+    # A narrow head (predict_3: 32 -> 16) pays for the composite form only when the candidate set is large relative to its
+    # parents: the composite GEMM costs n_in * 343 * Cin * Ch whatever the candidates, the layer-wise head n_out * 27 * Cm * Ch.
+    # Random weights scatter the kept voxels (66 candidates per parent at the last level: composite 0.9 ms ahead), a trained
+    # model keeps them on the surface (21 per parent: layer-wise 1.2 ms ahead) -- measured both ways, round 2.
+    FUSE_NARROW_MIN_RATIO = 40
+
     def _can_fuse(self, up, head, x):
         gen, c0, c2 = up[-1], head[0], head[2]
-        return (self.FUSE_UP_PREDICT and not torch.is_grad_enabled() and S.USE_GRID and S.USE_CSR and S.EXPAND_BY_GRID
-                and isinstance(gen, ME.MinkowskiGenerativeConvolutionTranspose) and gen.kernel_size == 5
-                and gen.stride == 2 and gen.bias is not None and c0.kernel_size == 3 and c0.stride == 1
-                and c0.out_channels >= self.FUSE_MIN_HEAD_CHANNELS and c0.out_channels % 4 == 0
-                and x._cset.n > 0 and x._cset.n * 343 < (1 << 31) and x._cset.grid() is not None)
+        ok = (self.FUSE_UP_PREDICT and not torch.is_grad_enabled() and S.USE_GRID and S.USE_CSR and S.EXPAND_BY_GRID
+              and isinstance(gen, ME.MinkowskiGenerativeConvolutionTranspose) and gen.kernel_size == 5
+              and gen.stride == 2 and gen.bias is not None and c0.kernel_size == 3 and c0.stride == 1
+              and c0.out_channels >= self.FUSE_MIN_HEAD_CHANNELS and c0.out_channels % 4 == 0
+              and x._cset.n > 0 and x._cset.n * 343 < (1 << 31) and x._cset.grid() is not None)
+        if ok and c0.out_channels < 32:
+            cs = x._cset
+            out_set = cs.expand(5, cs.ts // 2, want_csr=False)       # cached on the set: whichever path runs re-uses it
+            ok = out_set.n >= self.FUSE_NARROW_MIN_RATIO * cs.n
+        return ok
 
     def _up_predict_fused(self, up, head, x, k_lvl, probe=None, lvl=0):
         """Returns (x pruned to the top-k rows, prediction over all candidate rows, mask)."""

@@ -43,6 +43,8 @@ struct ConvArgs {
   const int* tile_k = nullptr;    // pair mode: kernel offset of each 128-pair tile
   const long long* n_tiles = nullptr;   // pair mode: device count of tiles (the grid is an upper bound)
   const unsigned char* featb = nullptr; // split path: bf16 planes of feat, [n_in][cin/32][3][32] (k_feat_split)
+  int ksplit = 1;                       // split path, map mode: the (offset, channel-block) reduction cut over ksplit workgroups
+  float* part = nullptr;                //   partial tiles [ksplit][n_out][cout], summed in fixed order by k_splitk_reduce
   int dbg = 0;                          // diagnostics (env PCC_DBG): 1 = no output stores, 2 = no MFMA phase, 4 = no staging loads
   int cin, cout, cout_pad;
   int cb_log2;            // log2(CB), CB = min(cin, 32)
@@ -485,7 +487,9 @@ __global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int cpx = gridDim.x >> 3;
-  const int wid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  int wid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  const int ks_id = wid % a.ksplit;                   // which slice of the reduction (ksplit == 1: the whole of it)
+  wid /= a.ksplit;
   const int gy = a.cout_pad / BN;
   int tile_id = wid / gy;
   int colblock = (wid - tile_id * gy) * BN;
@@ -569,7 +573,10 @@ __global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
   }
   __syncthreads();
   const int nact = s_nact;
-  const int nchunks = nact * a.ppo;                   // CB = 32: one piece per chunk
+  const int nchunks_all = nact * a.ppo;               // CB = 32: one piece per chunk
+  // split-K: slice ks_id takes the chunks [c_lo, c_hi) (contiguous: whole offsets stay together as far as possible)
+  const int c_lo = (int)((long long)nchunks_all * ks_id / a.ksplit), c_hi = (int)((long long)nchunks_all * (ks_id + 1) / a.ksplit);
+  const int nchunks = c_hi - c_lo;
 
   // staging roles: the 16-byte units u = j * 256 + tid of the tile's piece, 12 per row (3 planes x 4 slots), rows contiguous:
   // consecutive lanes read consecutive 16-byte units of a feature / weight row (coalesced), and write them side by side
@@ -625,10 +632,11 @@ __global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
   uint4 av[NA], bv[NB];
   int ai_c = 0, cbi_c = 0, ai_n = 0, cbi_n = 0;
   if (nchunks > 0) {
-    load_rows(0, rows_cur);
-    issue(0, 0, rows_cur, av, bv);
+    ai_c = c_lo / a.ppo; cbi_c = c_lo - ai_c * a.ppo;
+    load_rows(ai_c, rows_cur);
+    issue(ai_c, cbi_c, rows_cur, av, bv);
     if (nchunks > 1) {
-      ai_n = 1 / a.ppo; cbi_n = 1 - ai_n * a.ppo;
+      ai_n = (c_lo + 1) / a.ppo; cbi_n = (c_lo + 1) - ai_n * a.ppo;
       if (ai_n != ai_c) load_rows(ai_n, rows_nxt);
       else {
 #pragma unroll
@@ -652,7 +660,7 @@ __global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
       ai_c = ai_n; cbi_c = cbi_n;
       issue(ai_c, cbi_c, rows_cur, av, bv);
       if (c + 2 < nchunks) {
-        ai_n = (c + 2) / a.ppo; cbi_n = (c + 2) - ai_n * a.ppo;
+        ai_n = (c_lo + c + 2) / a.ppo; cbi_n = (c_lo + c + 2) - ai_n * a.ppo;
         if (ai_n != ai_c) load_rows(ai_n, rows_nxt);
       }
     }
@@ -685,6 +693,24 @@ __global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
   }
 
   if (a.dbg & 1) { if (acc[0][0][0] != 12345.678f) return; }
+  if (a.ksplit > 1) {                                 // raw partial sums; bias / activation are applied by k_splitk_reduce
+    float* const part = a.part + (size_t)ks_id * (size_t)a.n_out * a.cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = colblock + (wn * TN + j) * 32 + r31;
+      if (col >= a.cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (r >= npos) continue;
+          const long long orow = a.rows ? a.rows[pos0 + r] : (pos0 + r);
+          part[orow * a.cout + col] = acc[i][j][e];
+        }
+    }
+    return;
+  }
   // ---- epilogue: bias, activation (or GDN), store -------------------------------------------
   // Full tiles written to consecutive rows take a branch-free path: one base pointer per lane, the activation chosen
   // once per tile.  (The general loop below costs ~50 instructions per element -- row-list lookups, tail checks and
@@ -1589,6 +1615,25 @@ static bool split_ok(const ConvArgs& a) {
          bf_plane_elems(a.wp_elems) * 4 <= BUF_MAX_BYTES;
 }
 
+// out = act(bias + sum_s part[s]) in ascending s (fixed order: deterministic); 4 channels per thread
+__global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ part, int S, long long n4, int cout4,
+                                                       const float* __restrict__ bias, int act, float slope, float* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n4) return;
+  float4 v = reinterpret_cast<const float4*>(part)[t];
+  for (int sidx = 1; sidx < S; ++sidx) {
+    const float4 p = reinterpret_cast<const float4*>(part)[(long long)sidx * n4 + t];
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  }
+  if (bias) {
+    const float4 b = reinterpret_cast<const float4*>(bias)[t % cout4];
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  }
+  v.x = act1(v.x, act, slope); v.y = act1(v.y, act, slope); v.z = act1(v.z, act, slope); v.w = act1(v.w, act, slope);
+  reinterpret_cast<float4*>(out)[t] = v;
+}
+
+static bool g_splitk = getenv("PCC_SPLITK") ? atoi(getenv("PCC_SPLITK")) != 0 : true;
 static bool g_gemm_persistent = getenv("PCC_GEMM_PERSISTENT") ? atoi(getenv("PCC_GEMM_PERSISTENT")) != 0 : false;   // measured slower (2 workgroups per CU): off
 static int g_dbg = getenv("PCC_DBG") ? atoi(getenv("PCC_DBG")) : 0;
 
@@ -1623,14 +1668,38 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
     const long long t = pcc_cdiv(a.n_out, bm) + tiles_bound_extra;
     return gemm_groups ? (t + 7) / 8 * 8 : t;
   };
-  auto grid = [&](int bm) { return dim3((unsigned)((tiles(bm) * gy + 7) / 8 * 8)); };   // 1-D, multiple of 8 (XCD ranges)
+  int ksplit_grid = 1;
+  auto grid = [&](int bm) { return dim3((unsigned)((tiles(bm) * gy * ksplit_grid + 7) / 8 * 8)); };   // 1-D, multiple of 8 (XCD ranges)
   // few rows: shrink the row tile until the grid covers the 256 CUs about twice
   const long long want = 512;
   const bool buf = g_mfma_buf && a.n_in > 0 && a.n_in * a.cin * 4 <= BUF_MAX_BYTES && a.wp_elems > 0 &&
                    a.wp_elems * 4 <= BUF_MAX_BYTES;
   const bool split = split_ok(a);
-  if (split) PCC_TRY(make_planes(a, MODE != MODE_CONV, s));
+  // few row tiles but a deep (offset x channel-block) reduction -- the 15 k-row / 4 k-row / 1 k-row layers of the hyper-prior:
+  // a serial loop of 100-160 chunks at ~2 us per chunk on a handful of CUs.  Cut the reduction over ksplit workgroups
+  // (partial tiles in the library scratch, summed in fixed order): the chain gets ksplit times shorter and the grid fills.
+  int ksplit = 1;
+  if (split && g_splitk && MODE == MODE_CONV && a.hdr && !a.pair_in && (a.cout & 3) == 0) {
+    const int depth = 27 * a.ppo;                      // chunks of a 3x3x3 map (the maps that reach here; 5x5x5 take the pair form)
+    if (tiles(128) * gy < 256 && depth >= 64) {
+      ksplit = depth / 40;                             // ~40 chunks per workgroup
+      if (ksplit > 8) ksplit = 8;
+      if (ksplit < 2) ksplit = 1;
+    }
+  }
+  if (split) {
+    const size_t plane_bytes = pcc_align_up((size_t)a.n_in * a.cin * 6);
+    const size_t part_bytes = ksplit > 1 ? (size_t)ksplit * (size_t)a.n_out * a.cout * 4 : 0;
+    void* p = nullptr;
+    PCC_TRY(lib_scratch(plane_bytes + part_bytes, &p));
+    const long long pairs = (long long)a.n_in * a.cin / 2;
+    k_feat_split<<<(unsigned)pcc_cdiv(pairs, 256), 256, 0, s>>>(a.feat, pairs, a.cin / 2, MODE != MODE_CONV ? 1 : 0, (unsigned*)p);
+    PCC_LAUNCH_CHECK();
+    a.featb = (const unsigned char*)p;
+    if (ksplit > 1) { a.ksplit = ksplit; a.part = (float*)((char*)p + plane_bytes); }
+  }
   a.dbg = g_dbg;
+  ksplit_grid = a.ksplit;
   if (split && !a.hdr && g_gemm_persistent) return launch_gemm_bf<MODE>(a, s);
 #define PCC_LAUNCH_MFMA(WM, WN, TM, TN, BMV)                                                     \
   do {                                                                                           \
@@ -1648,6 +1717,11 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
   } else PCC_LAUNCH_MFMA(4, 1, 1, 1, 128);
 #undef PCC_LAUNCH_MFMA
   PCC_LAUNCH_CHECK();
+  if (a.ksplit > 1) {
+    const long long n4 = a.n_out * a.cout / 4;
+    k_splitk_reduce<<<(unsigned)pcc_cdiv(n4, 256), 256, 0, s>>>(a.part, a.ksplit, n4, a.cout / 4, a.bias, a.act, a.slope, a.out);
+    PCC_LAUNCH_CHECK();
+  }
   return PCC_OK;
 }
 

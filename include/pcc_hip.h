@@ -51,6 +51,10 @@ int pcc_device_info(int* h_cu_count, char* h_arch, int h_arch_len);
  * a1 / a11  coordinate keys            (ME.SparseTensor ctor: model/model.py:66-70,147-161,227;
  *                                       ME.utils.sparse_quantize: model/model.py:152-156)
  * ---------------------------------------------------------------------------------------- */
+/* {min b,x,y,z, max b,x,y,z} of [n,4] coordinates (int32, or float: floored) -- sizes the key range / grid lattices */
+int pcc_coords_bounds(const void* coords, int32_t is_float, int64_t n, int32_t* out8 /*device*/, void* stream);
+/* dst[i][:] = src[idx[i]][:]: features of user-ordered rows in canonical order (ME.SparseTensor) */
+int pcc_rows_gather(const float* src, const int64_t* idx, int64_t m, int32_t c, float* dst, void* stream);
 /* int32 [n,4] (b,x,y,z) -> keys */
 int pcc_keys_pack_i32(const int32_t* coords, int64_t n, int64_t* keys, void* stream);
 /* float [n,4] -> floor -> keys (the reference passes float coordinates, model/model.py:142-149) */

@@ -84,7 +84,14 @@ class SparseTensor:
         if self._perm is None:
             return self._F
         if self._Fc is None:
-            self._Fc = self._F[self._perm]
+            f = self._F
+            if f.requires_grad or not f.is_cuda or f.dtype != torch.float32:
+                self._Fc = f[self._perm]                 # training / odd dtypes: through autograd's index op
+            else:
+                f = f.contiguous()
+                self._Fc = torch.empty((self._perm.shape[0], f.shape[1]), dtype=torch.float32, device=f.device)
+                L.call("pcc_rows_gather", L.ptr(f), L.ptr(self._perm.contiguous()), self._perm.shape[0], f.shape[1],
+                       L.ptr(self._Fc), L.stream())
         return self._Fc
 
     # ---- ME surface -----------------------------------------------------------------------------

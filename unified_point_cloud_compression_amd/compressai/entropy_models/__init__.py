@@ -162,7 +162,7 @@ class EntropyModel(nn.Module):
             return torch.from_numpy(s.reshape(c, n).T.copy()).to(dev)
         buf = torch.frombuffer(bytearray(data) + bytearray(8), dtype=torch.uint8).to(dev)   # decoder looks one word ahead
         sym = torch.empty((n, c), dtype=torch.int32, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        status = L.counter(1, torch.int32)
         L.call("pcc_rans_decode_streams", L.ptr(buf), len(data), L.ptr(idx.contiguous()) if idx is not None else None,
                n, c, *self.n_streams(n, c), L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs),
                L.ptr(self._dec_table(dev)), self._dec_table(dev).numel(), L.ptr(sym), L.ptr(status), L.stream())

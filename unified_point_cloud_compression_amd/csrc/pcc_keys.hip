@@ -647,3 +647,59 @@ extern "C" int pcc_coords_expand_csr(const int64_t* keys, int64_t n, int32_t ker
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Bounds of user coordinates (what `Bounds` / the grid lattices are sized from) and the canonical-order row gather
+// of user-ordered features: the two torch reductions / gathers that were left on the inference path in round 1.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_coords_bounds(const T* __restrict__ coords, long long n, int* __restrict__ out8) {
+  __shared__ int s_min[4], s_max[4];
+  if (threadIdx.x < 4) { s_min[threadIdx.x] = 0x7FFFFFFF; s_max[threadIdx.x] = (int)0x80000000; }
+  __syncthreads();
+  int mn[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, mx[4] = {(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int v = (int)floorf((float)coords[i * 4 + c]);
+      mn[c] = min(mn[c], v); mx[c] = max(mx[c], v);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    for (int d = 32; d >= 1; d >>= 1) { mn[c] = min(mn[c], __shfl_xor(mn[c], d)); mx[c] = max(mx[c], __shfl_xor(mx[c], d)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&s_min[c], mn[c]); atomicMax(&s_max[c], mx[c]); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) { atomicMin(&out8[threadIdx.x], s_min[threadIdx.x]); atomicMax(&out8[4 + threadIdx.x], s_max[threadIdx.x]); }
+}
+
+// out8 = {min b, min x, min y, min z, max b, max x, max y, max z} (floor of float coordinates); n >= 1
+extern "C" int pcc_coords_bounds(const void* coords, int32_t is_float, int64_t n, int32_t* out8, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(coords && out8 && n >= 1, "pcc_coords_bounds: bad arguments");
+  PCC_CHECK_HIP(hipMemsetAsync(out8, 0x7F, 16, s));
+  PCC_CHECK_HIP(hipMemsetAsync(out8 + 4, 0x80, 16, s));
+  const unsigned g = (unsigned)(pcc_cdiv(n, 256) < 1024 ? pcc_cdiv(n, 256) : 1024);
+  if (is_float) k_coords_bounds<float><<<g, 256, 0, s>>>((const float*)coords, n, out8);
+  else k_coords_bounds<int><<<g, 256, 0, s>>>((const int*)coords, n, out8);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+__global__ void __launch_bounds__(256) k_rows_gather(const float* __restrict__ src, const long long* __restrict__ idx, long long m,
+                                                     int c, float* __restrict__ dst) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= m * c) return;
+  const long long r = t / c;
+  dst[t] = src[idx[r] * c + (t - r * c)];
+}
+
+// dst[i][:] = src[idx[i]][:]  (SparseTensor: features of user-ordered rows in canonical order)
+extern "C" int pcc_rows_gather(const float* src, const int64_t* idx, int64_t m, int32_t c, float* dst, void* stream) {
+  if (m <= 0) return PCC_OK;
+  PCC_REQUIRE(src && idx && dst && c >= 1, "pcc_rows_gather: bad arguments");
+  k_rows_gather<<<(unsigned)pcc_cdiv(m * c, 256), 256, 0, (hipStream_t)stream>>>(src, (const long long*)idx, m, c, dst);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}

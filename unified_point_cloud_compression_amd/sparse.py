@@ -65,7 +65,7 @@ class KernelMap:
                 lib = L.load()
                 pos = torch.empty(self.K * self.n_out, dtype=torch.int32, device=dev)
                 pstart = torch.empty(self.K + 1, dtype=torch.int32, device=dev)
-                info = torch.zeros(3, dtype=torch.int64, device=dev)
+                info = L.counter(3)
                 ws = L.workspace(lib.pcc_pair_plan_ws_bytes(self.n_out, self.K), dev)
                 L.call("pcc_pair_plan_rank", L.ptr(self.nbr), self.n_out, self.K, L.ptr(pos), L.ptr(pstart), L.ptr(info),
                        L.ptr(ws), ws.numel(), L.stream())
@@ -356,11 +356,15 @@ def pack_keys(coords):
 def bounds_of(coords):
     if coords.shape[0] == 0:
         return Bounds(0, (0, 0, 0), (0, 0, 0))
-    c = coords.floor() if coords.dtype.is_floating_point else coords
-    mn, mx = torch.stack([c.amin(dim=0), c.amax(dim=0)]).tolist()          # one device->host read
-    if mn[0] < 0:
+    c = coords.contiguous()
+    if c.dtype not in (torch.float32, torch.int32):
+        c = c.to(torch.float32) if c.dtype.is_floating_point else c.to(torch.int32)
+    out = torch.empty(8, dtype=torch.int32, device=c.device)
+    L.call("pcc_coords_bounds", L.ptr(c), 1 if c.dtype.is_floating_point else 0, c.shape[0], L.ptr(out), L.stream())
+    v = out.tolist()                                      # one device->host read
+    if v[0] < 0:
         raise L.PccError("negative batch index")
-    return Bounds(int(mx[0]), [int(v) for v in mn[1:]], [int(v) for v in mx[1:]])
+    return Bounds(v[4], v[1:4], v[5:8])
 
 
 def coordset_from_coords(coords, tensor_stride):

@@ -79,3 +79,22 @@ def test_d1_psnr_formula():
     d2, nn = ometrics.nearest(np.array([[5, 5, 5]]), np.array([[4, 5, 5], [5, 4, 5], [6, 5, 5], [9, 9, 9]]))
     assert d2[0] == 1 and nn[0] == 0
     assert metrics.count_bits([[b"ab"], [b"c", [b"de"]]]) == 40
+
+
+def test_corrupt_headers_fail_loudly(tmp_path):
+    """A damaged file must raise PccError before anything is allocated for the sizes its header claims."""
+    import struct
+    import pytest
+    from unified_point_cloud_compression_amd import container, lib as L
+    p = tmp_path / "bad.bin"
+    for payload in (b"", struct.pack("<i", -3), struct.pack("<i", 10 ** 8),
+                    struct.pack("<i", 1) + struct.pack("<iiddiiiii", 5, 10 ** 9, 0.5, 0.5, 4, 4, 1, 2, 3),
+                    struct.pack("<i", 1) + struct.pack("<iiddiiiii", 5, -1, 0.5, 0.5, 4, 4, 1, 2, 3),
+                    struct.pack("<i", 1) + b"\x00" * 10):
+        p.write_bytes(payload)
+        with pytest.raises(L.PccError):
+            container.load_bitstream(str(p))
+    with pytest.raises(L.PccError):
+        container.decode_points(b"\x00" * 8)
+    with pytest.raises(L.PccError):
+        container.decode_points(struct.pack("<iiiiB", 0, 0, 0, 0, 3) + b"\x00" * 16)          # pitch 0

@@ -45,11 +45,19 @@ def encode_points(coords, pitch=8):
 
 def decode_points(data):
     """bytes -> int32 [n,3] array of (x,y,z), ascending (x,y,z) (= canonical order of a one-batch set)."""
+    if len(data) < 17 + 5:
+        raise L.PccError("latent-coordinate stream truncated")
     ox, oy, oz, pitch, _depth = struct.unpack_from("<iiiiB", data, 0)
+    if pitch <= 0 or pitch > (1 << 15):
+        raise L.PccError(f"latent-coordinate stream: implausible pitch {pitch}")
     body = np.frombuffer(data, np.uint8, offset=17).copy()
     lib = L.load()
     n, depth = C.c_int64(0), C.c_int32(0)
     L.check(lib.pcc_octree_decode_host(_np_ptr(body), len(body), None, 0, C.byref(n), C.byref(depth)), "pcc_octree_decode_host")
+    # the point count comes from the stream header: bound it by what the payload could possibly code (a leaf costs at
+    # least a fraction of a bit; 64 points per payload byte is far beyond any real stream) before allocating for it
+    if n.value < 0 or n.value > 64 * max(len(body), 1) + 64:
+        raise L.PccError(f"latent-coordinate stream: header claims {n.value} points for {len(body)} payload bytes")
     cells = np.zeros((max(n.value, 1), 3), np.int32)
     L.check(lib.pcc_octree_decode_host(_np_ptr(body), len(body), _np_ptr(cells), n.value, C.byref(n), C.byref(depth)),
             "pcc_octree_decode_host")
@@ -80,11 +88,19 @@ def save_bitstream(path, blocks_coordinates, blocks_strings, blocks_shapes, bloc
 def load_bitstream(path):
     """`UnifiedModel.load_bitstream` (`model/model.py:314-385`): coordinates come back as [n,3] int32 (x,y,z)."""
     data = open(path, "rb").read()
+    if len(data) < 4:
+        raise L.PccError("bitstream file truncated")
     (nblocks,), off = struct.unpack_from("<i", data, 0), 4
+    if nblocks < 0 or nblocks * 44 > len(data):
+        raise L.PccError(f"bitstream file: implausible block count {nblocks}")
     coords, strings, shapes, ks, qs = [], [], [], [], []
     for _ in range(nblocks):
+        if off + struct.calcsize("<iiddiiiii") > len(data):
+            raise L.PccError("bitstream file truncated inside a block header")
         nz, lp, qg, qa, ly, lz, k1, k2, k3 = struct.unpack_from("<iiddiiiii", data, off)
         off += struct.calcsize("<iiddiiiii")
+        if min(nz, lp, ly, lz, k1, k2, k3) < 0 or off + lp + ly + lz > len(data):
+            raise L.PccError("bitstream file: block header with negative or oversized lengths")
         pts = data[off:off + lp]; off += lp
         ys = data[off:off + ly]; off += ly
         zs = data[off:off + lz]; off += lz

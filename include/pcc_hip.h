@@ -374,6 +374,11 @@ size_t pcc_rans_streams_ws_bytes(int64_t stream_symbols, int32_t n_streams);
  * layout [rows][cdf_stride]). */
 int pcc_rans_build_enc_table(const int32_t* h_cdf, int32_t rows, int32_t cdf_stride, const int32_t* h_sizes,
                              void* h_table /*16*rows*cdf_stride bytes*/);
+/* Payload estimate (in 1/256 bit) of a symbol matrix under the tables, independent of any stream geometry and of the
+ * order of evaluation (integer sum): the encoder sizes its stream count from it (framing <= 2 % of the payload). */
+int pcc_rans_estimate_bits(const int32_t* sym, const int32_t* idx, int64_t n, int32_t channels, const int32_t* cdf,
+                           int32_t cdf_stride, const int32_t* sizes, const int32_t* offsets, int64_t* d_bits256 /*device*/,
+                           void* stream);
 int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t channels,
                             int32_t n_groups, int32_t n_segments, const int32_t* cdf, int32_t cdf_stride,
                             const int32_t* sizes, const int32_t* offsets, const void* enc_table, uint8_t* out,

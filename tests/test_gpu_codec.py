@@ -389,3 +389,34 @@ def test_nearest_neighbour_search_exact():
         d2, nn = metrics.nearest(t(a.astype(np.int32)), t(b.astype(np.int32)))
         assert np.array_equal(n(d2), d2o)
         assert np.array_equal(n(nn), nno)
+
+
+def test_stream_count_adapts_to_the_payload_and_stays_reproducible():
+    """The encoder raises the stream count of a large symbol matrix until the 12-byte framing per stream reaches 2 % of
+    the payload it estimates from the symbols (`pcc_rans_estimate_bits`); the decoder reads the count in the container.
+    Same symbols -> same bytes; a low-rate matrix keeps the (n, c) rule's count."""
+    from unified_point_cloud_compression_amd.compressai.entropy_models import GaussianConditional, get_scale_table
+    rng = np.random.default_rng(4)
+    rows, c = 6000, 64                                             # 384 k symbols: above ADAPTIVE_MIN_SYMBOLS
+    gc = GaussianConditional(None).to(dev())
+    gc.update_scale_table(get_scale_table(), force=True)
+    st = n(gc.scale_table)
+    idx_hi = rng.integers(30, 50, (rows, c)).astype(np.int32)      # wide scales: many bits per symbol
+    sym_hi = np.rint(rng.standard_normal((rows, c)) * st[idx_hi]).astype(np.int32)
+    sym_hi[::97, 3] = 40000                                         # escapes (bypass digits) in the estimate too
+    idx_lo = np.zeros((rows, c), np.int32)                          # narrowest scale, mostly zeros: ~0.1 bit per symbol
+    sym_lo = (rng.random((rows, c)) < 0.01).astype(np.int32)
+    base_ng, base_segs = gc.n_streams(rows, c)
+    d_hi = gc.compress_rows(t(sym_hi), t(idx_hi))
+    d_lo = gc.compress_rows(t(sym_lo), t(idx_lo))
+    ns_hi, ns_lo = int(np.frombuffer(d_hi[:4], "<u4")[0]), int(np.frombuffer(d_lo[:4], "<u4")[0])
+    assert ns_lo == base_ng * base_segs                             # low rate: the (n, c) rule stands
+    assert ns_hi > base_ng * base_segs and ns_hi % base_ng == 0     # high rate: more segments
+    framing = 12 * ns_hi / len(d_hi)
+    assert framing <= 0.03, framing                                 # target 2 % of the payload (estimate within a few %)
+    assert rows * c // ns_hi >= gc.MIN_SEGMENT_SYMBOLS
+    assert np.array_equal(n(gc.decompress_rows(d_hi, rows, c, t(idx_hi))), sym_hi)
+    assert np.array_equal(n(gc.decompress_rows(d_lo, rows, c, t(idx_lo))), sym_lo)
+    assert gc.compress_rows(t(sym_hi), t(idx_hi)) == d_hi           # reproducible bytes
+    est = abs(len(d_hi) - 12 * ns_hi)                               # the estimate the count was derived from was close:
+    assert 0.6 <= (ns_hi // base_ng) * base_ng * 12 / (0.02 * est) <= 1.05 or rows * c // ns_hi <= 2 * gc.MIN_SEGMENT_SYMBOLS

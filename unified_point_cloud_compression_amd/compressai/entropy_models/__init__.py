@@ -138,6 +138,11 @@ class EntropyModel(nn.Module):
             return self._host_encode(s, np.ascontiguousarray(i, np.int32))
         lib = L.load()
         ng, segs = self.n_streams(n, c)
+        if self.FRAMING_TARGET > 0 and n * c >= self.ADAPTIVE_MIN_SYMBOLS:
+            est = L.counter()
+            L.call("pcc_rans_estimate_bits", L.ptr(sym), L.ptr(idx.contiguous()) if idx is not None else None, n, c, L.ptr(cdf),
+                   cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.cptr(est), L.stream())
+            segs = self._adaptive_segments(n, c, ng, segs, int(L.read(est)[0]) / 2048.0)
         ns = ng * segs
         per = lib.pcc_rans_stream_symbols(n, c, ng, segs)
         cap = lib.pcc_rans_container_max_bytes(per, ns)
@@ -148,6 +153,33 @@ class EntropyModel(nn.Module):
                L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._enc_table(dev)), L.ptr(out), L.cptr(nb),
                L.ptr(ws), ws.numel(), L.stream())
         return out[:int(L.read(nb)[0])].cpu().numpy().tobytes()
+
+    # Speed / rate knob of the stream container.  A stream is one GPU lane running a serial recurrence (~0.2-0.3 us per
+    # symbol) and costs 12 bytes of framing, so MORE streams is faster and FEWER is smaller.  The (n, c) rule above
+    # keeps the framing small for a trained model's ~0.5 bpp frames; a frame that codes at a high rate (the benchmark's
+    # random-weight frame: 8 bpp, 0.8 MB) can afford many more streams for the same RELATIVE overhead.  The encoder
+    # therefore raises the segment count until the framing reaches FRAMING_TARGET of the payload, which it estimates from
+    # the symbols themselves (`pcc_rans_estimate_bits`: one pass, integer sum -- the same symbols always give the same
+    # stream count, so bitstreams stay reproducible).  Never below the (n, c) rule, never streams shorter than
+    # MIN_SEGMENT_SYMBOLS; the count is written in the container, the decoder reads it there.
+    FRAMING_TARGET = 0.02
+    MIN_SEGMENT_SYMBOLS = 512
+    ADAPTIVE_MIN_SYMBOLS = 1 << 18
+
+    def _adaptive_segments(self, n, c, ng, segs, payload_bytes):
+        per = n * (c // ng)
+        want = int(payload_bytes * self.FRAMING_TARGET / 12) // ng
+        return max(segs, min(want, max(1, self.MAX_STREAMS // ng), max(1, per // self.MIN_SEGMENT_SYMBOLS)))
+
+    def _segments_of(self, data, n, c):
+        """(groups, segments) of a container: the group count follows from (n, c), the segment count from the stream count
+        in its first word (the encoder may have raised it, `_adaptive_segments`)."""
+        ng, segs = self.n_streams(n, c)
+        if len(data) >= 4:
+            ns = int.from_bytes(data[:4], "little")
+            if ns >= ng and ns % ng == 0 and ns // ng <= max(1, self.MAX_STREAMS // ng):
+                segs = ns // ng
+        return ng, segs
 
     def decompress_rows(self, data, n, c, idx=None, device=None, check=None):
         """bytes -> sym [N,C] int32 on `device`.  `check`: list collecting the status words for a deferred check
@@ -164,7 +196,7 @@ class EntropyModel(nn.Module):
         sym = torch.empty((n, c), dtype=torch.int32, device=dev)
         status = L.counter(1, torch.int32)
         L.call("pcc_rans_decode_streams", L.ptr(buf), len(data), L.ptr(idx.contiguous()) if idx is not None else None,
-               n, c, *self.n_streams(n, c), L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs),
+               n, c, *self._segments_of(data, n, c), L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs),
                L.ptr(self._dec_table(dev)), self._dec_table(dev).numel(), L.ptr(sym), L.ptr(status), L.stream())
         if check is None:                       # synchronous check (one device->host read)
             st = int(status.item())

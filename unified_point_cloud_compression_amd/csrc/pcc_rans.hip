@@ -657,6 +657,49 @@ extern "C" int64_t pcc_rans_stream_symbols(int64_t n, int32_t channels, int32_t 
   return (int64_t)g.R << g.gl;
 }
 
+// Payload estimate of a symbol matrix under the given tables, before any stream geometry is chosen: sum over the symbols
+// of round(256 * (16 - log2 freq)) (+ 256 * 8 per 4-bit bypass digit pair for escapes), an integer, so the total does not
+// depend on the order of the (integer) atomic adds -- the encoder picks its stream count from it (framing <= 2 % of the
+// payload) and must pick the same count every time it sees the same symbols.
+__global__ void __launch_bounds__(256) k_rans_estimate(const int* __restrict__ sym, const int* __restrict__ idx, long long total,
+                                                       int channels, RansTab t, unsigned long long* __restrict__ bits256) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  unsigned b = 0;
+  if (e < total) {
+    const int ci = idx ? idx[e] : (int)(e % channels);
+    const int max_value = t.sizes[ci] - 2;
+    int v = sym[e] - t.offsets[ci];
+    unsigned raw = 0;
+    if (v < 0) { raw = (unsigned)(-2 * v - 1); v = max_value; }
+    else if (v >= max_value) { raw = (unsigned)(2 * (v - max_value)); v = max_value; }
+    const int* row = t.cdf + (size_t)ci * t.stride;
+    const int freq = max(row[v + 1] - row[v], 1);
+    b = (unsigned)__float2int_rn(256.f * (16.f - __log2f((float)freq)));
+    if (v == max_value) b += 256u * 4u * (unsigned)((32 - __clz((int)(raw | 1u)) + 3) / 4 + 1);   // bypass digits, 4 bits each
+  }
+  unsigned long long w = b;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) w += __shfl_xor(w, d, 64);
+  __shared__ unsigned long long part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(bits256, part[0] + part[1] + part[2] + part[3]);
+}
+
+extern "C" int pcc_rans_estimate_bits(const int32_t* sym, const int32_t* idx, int64_t n, int32_t channels, const int32_t* cdf,
+                                      int32_t cdf_stride, const int32_t* sizes, const int32_t* offsets, int64_t* d_bits256,
+                                      void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(sym && cdf && sizes && offsets && d_bits256 && channels >= 1 && n >= 0, "pcc_rans_estimate_bits: bad arguments");
+  PCC_CHECK_HIP(hipMemsetAsync(d_bits256, 0, 8, s));
+  if (n == 0) return PCC_OK;
+  RansTab t{cdf, cdf_stride, sizes, offsets};
+  const long long total = (long long)n * channels;
+  k_rans_estimate<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(sym, idx, total, channels, t, (unsigned long long*)d_bits256);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
 extern "C" int pcc_rans_encode_streams(const int32_t* sym, const int32_t* idx, int64_t n, int32_t channels,
                                        int32_t n_groups, int32_t n_segments, const int32_t* cdf,
                                        int32_t cdf_stride, const int32_t* sizes, const int32_t* offsets,

@@ -99,6 +99,7 @@ SIGNATURES = {
     "pcc_rans_streams_ws_bytes": (_sz, [_i64, _i32]),
     "pcc_rans_build_enc_table": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "pcc_rans_stream_symbols": (_i64, [_i64, _i32, _i32, _i32]),
+    "pcc_rans_estimate_bits": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _p, _p, _p]),
     "pcc_rans_encode_streams": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_rans_dec_table_bytes": (_i64, [_i32, _p]),
     "pcc_rans_build_dec_table": (C.c_int, [_p, _i32, _i32, _p, _p]),

@@ -624,53 +624,115 @@ struct ExpandCsrArgs {
   int* pair_ids;
 };
 
-template <int KS, bool FILL>
-__global__ void __launch_bounds__(256) k_expand_csr(ExpandCsrArgs a) {
-  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= a.n_out) return;
+// The compatible source cells of an output row: per axis the offsets whose source lies on the input lattice (offset index
+// descending = source cell ascending).  They are CONSECUTIVE lattice cells per axis, so the z cells of a kernel column are
+// one bit field of <= 4 bits in the occupancy bitmap (at most two words): a column costs one field extraction instead of
+// a loop over its cells -- the per-cell loops were instruction-bound (64 divergent iterations per row, 0.9 + 2.1 ms per step
+// for the 7-wide lists of the composite convolutions in round 2).
+template <int KS>
+struct CsrCols {
+  int cell[3][KS], idx[3][KS], cnt[3];
+  int b;
+};
+
+template <int KS>
+__device__ __forceinline__ void csr_columns(const ExpandCsrArgs& a, long long o, CsrCols<KS>& c) {
   constexpr int H = (KS & 1) ? (KS - 1) / 2 : 0;
   const int64_t key = a.out_keys[o];
-  const int b = (int)(key >> 48);
-  const int c[3] = {(int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - a.in.lo[0],
+  c.b = (int)(key >> 48);
+  const int p[3] = {(int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - a.in.lo[0],
                     (int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - a.in.lo[1],
                     (int)(key & 0xFFFF) - (int)PCC_BIAS - a.in.lo[2]};
   const int tm = (1 << a.in.ts_log2) - 1;
-  // per axis: the offsets whose source lies on the input lattice, offset index descending = source cell ascending
-  int cell_ax[3][KS], idx_ax[3][KS], cnt_ax[3];
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) {
     int m = 0;
 #pragma unroll
     for (int ia = KS - 1; ia >= 0; --ia) {
-      const int rel = c[ax] - (ia - H) * a.ts_out;
+      const int rel = p[ax] - (ia - H) * a.ts_out;
       const int cc = rel >> a.in.ts_log2;
-      if (rel >= 0 && !(rel & tm) && cc < a.in.dims[ax]) { cell_ax[ax][m] = cc; idx_ax[ax][m] = ia; ++m; }
+      if (rel >= 0 && !(rel & tm) && cc < a.in.dims[ax]) { c.cell[ax][m] = cc; c.idx[ax][m] = ia; ++m; }
     }
-    cnt_ax[ax] = m;
+    c.cnt[ax] = m;
   }
+}
+
+// occupancy bits of the nz consecutive cells starting at `cell` (nz <= 8); *word = index of the first word
+__device__ __forceinline__ unsigned csr_field(const unsigned long long* __restrict__ bits, long long cell, int nz, long long* word,
+                                              unsigned long long* w0_out) {
+  const long long wi = cell >> 6;
+  const int sh = (int)(cell & 63);
+  const unsigned long long w0 = bits[wi];
+  unsigned long long f = w0 >> sh;
+  if (sh + nz > 64) f |= bits[wi + 1] << (64 - sh);
+  *word = wi;
+  *w0_out = w0;
+  return (unsigned)f & ((1u << nz) - 1u);
+}
+
+// count pass: pairs of every output row
+template <int KS>
+__global__ void __launch_bounds__(256) k_expand_csr_count(ExpandCsrArgs a) {
+  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.n_out) return;
+  CsrCols<KS> c;
+  csr_columns<KS>(a, o, c);
   int total = 0;
-  int wpos = FILL ? a.first[o] : 0;
-  if (b < a.in.nbatch) {
-    long long wi = -1;
-    unsigned long long w = 0;
-    int rk = 0;
-    for (int jx = 0; jx < cnt_ax[0]; ++jx)
-      for (int jy = 0; jy < cnt_ax[1]; ++jy) {
-        const long long row = (((long long)b * a.in.dims[0] + cell_ax[0][jx]) * a.in.dims[1] + cell_ax[1][jy]) * a.in.dims[2];
-        for (int jz = 0; jz < cnt_ax[2]; ++jz) {
-          const long long cell = row + cell_ax[2][jz];
-          if ((cell >> 6) != wi) { wi = cell >> 6; w = a.in.bits[wi]; if (FILL) rk = a.in.rank[wi]; }
-          const int bit = (int)(cell & 63);
-          if ((w >> bit) & 1ull) {
-            if (FILL) {
-              const int i = rk + __popcll(w & ((1ull << bit) - 1ull));
-              a.pair_ids[wpos++] = i * a.K + idx_ax[0][jx] + KS * idx_ax[1][jy] + KS * KS * idx_ax[2][jz];
-            } else ++total;
-          }
-        }
+  if (c.b < a.in.nbatch && c.cnt[2] > 0) {
+    for (int jx = 0; jx < c.cnt[0]; ++jx)
+      for (int jy = 0; jy < c.cnt[1]; ++jy) {
+        const long long cell = (((long long)c.b * a.in.dims[0] + c.cell[0][jx]) * a.in.dims[1] + c.cell[1][jy]) * a.in.dims[2] + c.cell[2][0];
+        long long wi; unsigned long long w0;
+        total += __popc(csr_field(a.in.bits, cell, c.cnt[2], &wi, &w0));
       }
   }
-  if (!FILL) a.first[o] = total;
+  a.first[o] = total;
+}
+
+// on_hit(i, kidx) for every existing source of row o, ascending source cell (= ascending input row)
+template <int KS, typename F>
+__device__ __forceinline__ void csr_probe(const ExpandCsrArgs& a, long long o, F&& on_hit) {
+  CsrCols<KS> c;
+  csr_columns<KS>(a, o, c);
+  if (c.b >= a.in.nbatch || c.cnt[2] == 0) return;
+  for (int jx = 0; jx < c.cnt[0]; ++jx)
+    for (int jy = 0; jy < c.cnt[1]; ++jy) {
+      const long long cell = (((long long)c.b * a.in.dims[0] + c.cell[0][jx]) * a.in.dims[1] + c.cell[1][jy]) * a.in.dims[2] + c.cell[2][0];
+      long long wi; unsigned long long w0;
+      unsigned f = csr_field(a.in.bits, cell, c.cnt[2], &wi, &w0);
+      if (!f) continue;
+      // row of the first cell's position: rank of its word + set bits below it; later hits of the field follow consecutively
+      // (the rank is cumulative across words, so a field that straddles two words needs nothing extra)
+      int i = a.in.rank[wi] + __popcll(w0 & ((1ull << (cell & 63)) - 1ull));
+      const int kxy = c.idx[0][jx] + KS * c.idx[1][jy];
+      while (f) {
+        const int t = __ffs((int)f) - 1;
+        f &= f - 1;
+        on_hit(i, kxy + KS * KS * c.idx[2][t]);
+        ++i;
+      }
+    }
+}
+
+// fill pass: the pair ids of a block's 256 rows occupy one contiguous range of pair_ids (first[] is a prefix sum), so
+// they are staged in LDS and written out coalesced.
+template <int KS>
+__global__ void __launch_bounds__(256) k_expand_csr_fill(ExpandCsrArgs a) {
+  constexpr int CAP = 256 * 20;
+  __shared__ int stage[CAP];
+  const long long o0 = (long long)blockIdx.x * blockDim.x;
+  const long long o = o0 + threadIdx.x;
+  const long long o_end = min(a.n_out, o0 + 256);
+  const int base = a.first[o0], total = a.first[o_end] - base;
+  const bool staged = total <= CAP;
+  if (o < a.n_out) {
+    int wpos = a.first[o] - base;
+    if (staged) csr_probe<KS>(a, o, [&](int i, int kidx) { stage[wpos++] = i * a.K + kidx; });
+    else { wpos += base; csr_probe<KS>(a, o, [&](int i, int kidx) { a.pair_ids[wpos++] = i * a.K + kidx; }); }
+  }
+  if (!staged) return;
+  __syncthreads();
+  for (int t = threadIdx.x; t < total; t += 256) a.pair_ids[base + t] = stage[t];
 }
 
 __global__ void k_set_int(int* p, int v) { *p = v; }
@@ -724,21 +786,21 @@ extern "C" int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out
   for (int i = 0; i < 3; ++i) { a.in.lo[i] = h_in[i]; a.in.dims[i] = h_in[3 + i]; }
   a.in.ts_log2 = ilog2(h_in[6]); a.in.nbatch = h_in[7];
   const unsigned g = (unsigned)pcc_cdiv(n_out, 256);
-#define PCC_EXPAND_CSR(FILL)                                                        \
+#define PCC_EXPAND_CSR(KERNEL)                                                      \
   do {                                                                              \
-    if (kernel_size == 2) k_expand_csr<2, FILL><<<g, 256, 0, s>>>(a);               \
-    else if (kernel_size == 3) k_expand_csr<3, FILL><<<g, 256, 0, s>>>(a);          \
-    else if (kernel_size == 5) k_expand_csr<5, FILL><<<g, 256, 0, s>>>(a);          \
-    else k_expand_csr<7, FILL><<<g, 256, 0, s>>>(a);                                \
+    if (kernel_size == 2) KERNEL<2><<<g, 256, 0, s>>>(a);                           \
+    else if (kernel_size == 3) KERNEL<3><<<g, 256, 0, s>>>(a);                      \
+    else if (kernel_size == 5) KERNEL<5><<<g, 256, 0, s>>>(a);                      \
+    else KERNEL<7><<<g, 256, 0, s>>>(a);                                            \
     PCC_LAUNCH_CHECK();                                                             \
   } while (0)
-  PCC_EXPAND_CSR(false);
+  PCC_EXPAND_CSR(k_expand_csr_count);
   // out_keys need not be the full expansion (any subset of rows, or a wider kernel restricted to a given set), so the
   // pair total is whatever the counts add up to: scan n_out + 1 entries
   k_set_int<<<1, 1, 0, s>>>(first + n_out, 0);
   PCC_LAUNCH_CHECK();
   PCC_TRY(pcc_scan_exclusive_i32(first, first, n_out + 1, ws, ws_bytes, s));
-  PCC_EXPAND_CSR(true);
+  PCC_EXPAND_CSR(k_expand_csr_fill);
 #undef PCC_EXPAND_CSR
   return PCC_OK;
 }

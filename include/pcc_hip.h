@@ -259,6 +259,19 @@ int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const flo
                       const int32_t* ex_nbr /*nullable [ex_K][n_out]*/, int32_t ex_K,
                       const float* ex_bias /*[ex_K][cout]*/, void* stream);
 
+/* pcc_convt_fwd_csr with the constant-per-existing-neighbour term (ex_bias [27][cout]) keyed on the OUTPUT set's own grid
+ * index (out_keys + pcc_grid_build arrays) instead of a [27][n_out] neighbour table; and a 3x3x3 convolution to <= 4 channels
+ * whose neighbours also come straight from the grid index (packed_w: pcc_conv_pack_weights(27, cin, cout) thin layout).
+ * Together they spare the composite up+head convolutions the 3x3x3 kernel map of their candidate set. */
+int pcc_convt_fwd_csr_grid(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias /*nullable*/,
+                           int32_t K, int32_t cout, const int32_t* first, const int32_t* pair_ids, int64_t n_out, float* T,
+                           float* out, int32_t act, float slope, const int64_t* out_keys, const uint64_t* out_bits,
+                           const int32_t* out_rank, const int32_t* h_out, const float* ex_bias, void* stream);
+size_t pcc_thin_grid_ws_bytes(int64_t n, int32_t cout);
+int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin, const float* packed_w, const float* bias /*nullable*/,
+                           int32_t cout, const int64_t* keys, const uint64_t* bits, const int32_t* rank, const int32_t* h_grid,
+                           float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* a5  fused GDN / IGDN (GDN1 form), MinkowskiGDN.forward model/blocks.py:26-57:
  *   norm = beta + |x| @ gamma^T ; out = x / norm (inverse=0) or x * norm (inverse=1)
  * beta_raw/gamma_raw are the raw (un-reparametrised) CompressAI parameters; the

@@ -107,6 +107,42 @@ __device__ inline int pcc_lookup(const PccGrid& g, const int64_t* __restrict__ k
   return g.bits ? pcc_grid_find(g, q) : pcc_find(keys, n, q);
 }
 
+// The 3x3x3 neighbourhood of a row of a set straight from the set's own grid index (pitch = the grid's pitch): the z cells
+// of a (dx,dy) column are one bit field of the occupancy bitmap, the row of its first occupied cell is rank + popcount and
+// the others follow consecutively.  Columns c = (dx+1) + 3*(dy+1) with c % nlanes == lane are handled (nlanes lanes share a
+// row); returns the presence mask of those columns (bit k = neighbour k exists, k = (dx+1) + 3(dy+1) + 9(dz+1), the kernel
+// offset enumeration) and, when rows != nullptr, rows[k] for the present ones.
+__device__ inline unsigned pcc_grid_nbr27(const PccGrid& g, int64_t key, int lane, int nlanes, int* rows) {
+  const int b = (int)(key >> 48);
+  const int cx = (((int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - g.lo[0]) >> g.ts_log2);
+  const int cy = (((int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - g.lo[1]) >> g.ts_log2);
+  const int cz = (((int)(key & 0xFFFF) - (int)PCC_BIAS - g.lo[2]) >> g.ts_log2);
+  const int z_lo = cz > 0 ? cz - 1 : 0, z_hi = cz + 1 < g.dims[2] ? cz + 1 : g.dims[2] - 1;
+  const int nz = z_hi - z_lo + 1;
+  unsigned mask = 0;
+  for (int c = lane; c < 9; c += nlanes) {
+    const int nx = cx + c % 3 - 1, ny = cy + c / 3 - 1;
+    if (nx < 0 || ny < 0 || nx >= g.dims[0] || ny >= g.dims[1]) continue;
+    const long long cell = (((long long)b * g.dims[0] + nx) * g.dims[1] + ny) * g.dims[2] + z_lo;
+    const long long wi = cell >> 6;
+    const int sh = (int)(cell & 63);
+    const unsigned long long w0 = g.bits[wi];
+    unsigned long long f64 = w0 >> sh;
+    if (sh + nz > 64) f64 |= g.bits[wi + 1] << (64 - sh);
+    unsigned f = (unsigned)f64 & ((1u << nz) - 1u);
+    if (!f) continue;
+    int r = rows ? g.rank[wi] + __popcll(w0 & ((1ull << sh) - 1ull)) : 0;
+    while (f) {
+      const int t = __ffs((int)f) - 1;
+      f &= f - 1;
+      const int k = c + 9 * (z_lo + t - cz + 1);
+      mask |= 1u << k;
+      if (rows) rows[k] = r++;
+    }
+  }
+  return mask;
+}
+
 // internal cross-file entry points
 int pcc_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, size_t ws_bytes,
                            hipStream_t s);

@@ -2503,6 +2503,7 @@ struct GatherCsrArgs {
   const float* T; const float* bias; const int* first; const int* pair_ids;
   float* out; long long n_out; int cout, act; float slope; int lpr_log2;
   const int* ex_nbr; const float* ex_bias; int ex_K;      // optional: + sum over the existing neighbours k of ex_bias[k]
+  PccGrid ex_grid; const long long* out_keys;             //   presence flags from a [K][n_out] table (ex_nbr) or the set's grid index
 };
 
 template <int VEC>
@@ -2521,7 +2522,11 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
   // flags side by side and share them by ballot (one load per lane instead of ex_K dependent loads: the serial loop cost
   // 2.1 ms on the level-2 head in round 2)
   unsigned long long present = 0;
-  if (a.ex_nbr) {
+  if (a.ex_grid.bits) {            // 3x3x3 presence straight from the output set's bitmap: the columns are dealt over the group's lanes
+    unsigned m = pcc_grid_nbr27(a.ex_grid, a.out_keys[o], cl, lpr < 9 ? lpr : 9, nullptr);
+    for (int d = lpr >> 1; d >= 1; d >>= 1) m |= __shfl_xor((int)m, d);
+    present = m;
+  } else if (a.ex_nbr) {
     for (int k0 = 0; k0 < a.ex_K; k0 += lpr) {
       const int k = k0 + cl;
       const bool v = k < a.ex_K && a.ex_nbr[(long long)k * a.n_out + o] >= 0;
@@ -2545,7 +2550,7 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
 #pragma unroll
       for (int u = 0; u < JB; ++u) thin_acc(acc, x[u]);     // fixed order: pair id ascending
     }
-    for (unsigned long long pr = present; pr;) {          // neighbour k exists -> its constant contribution, ascending k
+    for (unsigned long long pr = a.ex_bias ? present : 0ull; pr;) {          // neighbour k exists -> its constant contribution, ascending k
       const int k = __ffsll((long long)pr) - 1;
       pr &= pr - 1;
       thin_acc(acc, reinterpret_cast<const VT*>(a.ex_bias + (long long)k * a.cout)[cv]);
@@ -2558,6 +2563,10 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
     reinterpret_cast<VT*>(a.out + o * a.cout)[cv] = acc;
   }
 }
+
+// presence source for the next pcc_convt_fwd_csr call (pcc_convt_fwd_csr_grid sets it): the output set's grid index
+static PccGrid g_ex_grid = {nullptr, nullptr, {0, 0, 0}, {0, 0, 0}, 0, 0};
+static const long long* g_ex_keys = nullptr;
 
 extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                                  const float* bias, int32_t K, int32_t cout, const int32_t* first,
@@ -2585,6 +2594,8 @@ extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin
   GatherCsrArgs g;
   g.T = T; g.bias = bias; g.first = first; g.pair_ids = pair_ids; g.out = out; g.n_out = n_out; g.cout = cout;
   g.act = act; g.slope = slope; g.ex_nbr = ex_nbr; g.ex_bias = ex_bias; g.ex_K = ex_K;
+  g.ex_grid.bits = nullptr; g.out_keys = nullptr;
+  if (g_ex_grid.bits) { g.ex_grid = g_ex_grid; g.out_keys = g_ex_keys; g.ex_nbr = nullptr; g_ex_grid.bits = nullptr; }
   const int vec = (cout % 4 == 0) ? 4 : 1;
   int l = 0;
   while ((1 << l) < cout / vec && l < 6) ++l;
@@ -2592,6 +2603,110 @@ extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin
   const int64_t waves = pcc_cdiv(n_out, 64 >> l);
   if (vec == 4) k_convt_gather_csr<4><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(g);
   else k_convt_gather_csr<1><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(g);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+static int ilog2_i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static PccGrid grid_from_host(const uint64_t* bits, const int32_t* rank, const int32_t* h) {
+  PccGrid g;
+  g.bits = (const unsigned long long*)bits; g.rank = rank;
+  for (int i = 0; i < 3; ++i) { g.lo[i] = h[i]; g.dims[i] = h[3 + i]; }
+  g.ts_log2 = ilog2_i(h[6]); g.nbatch = h[7];
+  return g;
+}
+
+// pcc_convt_fwd_csr with the constant-per-existing-neighbour term taken from the OUTPUT set's own grid index instead of a
+// [27][n_out] neighbour table: the composite up+head convolutions then need no 3x3x3 kernel map of the candidate set at all
+// (1.6 GB to write and 1.6 GB to read twice on the benchmark's last level).
+extern "C" int pcc_convt_fwd_csr_grid(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                                      const float* bias, int32_t K, int32_t cout, const int32_t* first,
+                                      const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
+                                      const int64_t* out_keys, const uint64_t* out_bits, const int32_t* out_rank,
+                                      const int32_t* h_out, const float* ex_bias, void* stream) {
+  PCC_REQUIRE(out_keys && out_bits && out_rank && h_out && ex_bias, "pcc_convt_fwd_csr_grid: NULL array");
+  g_ex_grid = grid_from_host(out_bits, out_rank, h_out);
+  g_ex_keys = (const long long*)out_keys;
+  const int rc = pcc_convt_fwd_csr(feat_in, n_in, cin, packed_w, bias, K, cout, first, pair_ids, n_out, T, out, act, slope,
+                                   nullptr, 27, ex_bias, stream);
+  g_ex_grid.bits = nullptr;
+  return rc;
+}
+
+// 3x3x3 convolution to <= 4 channels on a full set, neighbours from the set's grid index (no kernel map):
+//   t[k*cout+co][i] = <feat[i], w_k[co]>  (k_thin_project),  out[o][co] = b + sum_k t[k*cout+co][nbr_k(o)]
+struct ThinGridArgs {
+  const float* t; const float* bias; const long long* keys; PccGrid g; float* out; long long n; int cout;
+};
+
+template <int COUT_MAX>
+__global__ void __launch_bounds__(256) k_thin_gather_grid(ThinGridArgs a) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n) return;
+  const PccGrid& g = a.g;
+  const long long key = a.keys[p];
+  const int b = (int)(key >> 48);
+  const int cx = (((int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - g.lo[0]) >> g.ts_log2);
+  const int cy = (((int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - g.lo[1]) >> g.ts_log2);
+  const int cz = (((int)(key & 0xFFFF) - (int)PCC_BIAS - g.lo[2]) >> g.ts_log2);
+  const int z_lo = cz > 0 ? cz - 1 : 0, z_hi = cz + 1 < g.dims[2] ? cz + 1 : g.dims[2] - 1;
+  const int nz = z_hi - z_lo + 1;
+  float acc[COUT_MAX];
+#pragma unroll
+  for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
+  // fixed order: (dx,dy) columns ascending, z ascending inside a column (no neighbour table: rows come from the bitmap + rank)
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const int nx = cx + c % 3 - 1, ny = cy + c / 3 - 1;
+    if (nx < 0 || ny < 0 || nx >= g.dims[0] || ny >= g.dims[1]) continue;
+    const long long cell = (((long long)b * g.dims[0] + nx) * g.dims[1] + ny) * g.dims[2] + z_lo;
+    const long long wi = cell >> 6;
+    const int sh = (int)(cell & 63);
+    const unsigned long long w0 = g.bits[wi];
+    unsigned long long f64 = w0 >> sh;
+    if (sh + nz > 64) f64 |= g.bits[wi + 1] << (64 - sh);
+    unsigned f = (unsigned)f64 & ((1u << nz) - 1u);
+    if (!f) continue;
+    int r = g.rank[wi] + __popcll(w0 & ((1ull << sh) - 1ull));
+    while (f) {
+      const int t = __ffs((int)f) - 1;
+      f &= f - 1;
+      const int k = c + 9 * (z_lo + t - cz + 1);
+#pragma unroll
+      for (int o = 0; o < COUT_MAX; ++o)
+        if (o < a.cout) acc[o] += a.t[(long long)(k * a.cout + o) * a.n + r];
+      ++r;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < COUT_MAX; ++o)
+    if (o < a.cout) a.out[p * a.cout + o] = acc[o] + (a.bias ? a.bias[o] : 0.f);
+}
+
+extern "C" size_t pcc_thin_grid_ws_bytes(int64_t n, int32_t cout) { return (size_t)27 * cout * (size_t)(n > 0 ? n : 1) * sizeof(float) + 256; }
+
+extern "C" int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin, const float* packed_w /*thin layout [27][cout][cin]*/,
+                                      const float* bias, int32_t cout, const int64_t* keys, const uint64_t* bits,
+                                      const int32_t* rank, const int32_t* h_grid, float* out, void* ws, size_t ws_bytes,
+                                      void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(feat && packed_w && keys && bits && rank && h_grid && out && ws, "pcc_conv_thin_grid_fwd: NULL array");
+  PCC_REQUIRE(cout >= 1 && cout <= 4 && conv_kind(27, cin, cout) == KIND_THIN_T, "pcc_conv_thin_grid_fwd: unsupported shape cin=%d cout=%d", cin, cout);
+  if (ws_bytes < pcc_thin_grid_ws_bytes(n, cout)) { pcc_set_error("pcc_conv_thin_grid_fwd: workspace too small"); return PCC_EWS; }
+  float* t = (float*)ws;
+  const int kc = 27 * cout;
+  switch (cin) {
+    case 4: PCC_TRY(launch_project<4>(feat, n, packed_w, kc, t, s)); break;
+    case 8: PCC_TRY(launch_project<8>(feat, n, packed_w, kc, t, s)); break;
+    case 16: PCC_TRY(launch_project<16>(feat, n, packed_w, kc, t, s)); break;
+    case 32: PCC_TRY(launch_project<32>(feat, n, packed_w, kc, t, s)); break;
+    default: PCC_TRY(launch_project<64>(feat, n, packed_w, kc, t, s)); break;
+  }
+  ThinGridArgs a;
+  a.t = t; a.bias = bias; a.keys = (const long long*)keys; a.g = grid_from_host(bits, rank, h_grid); a.out = out; a.n = n; a.cout = cout;
+  if (cout == 1) k_thin_gather_grid<1><<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
+  else k_thin_gather_grid<4><<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

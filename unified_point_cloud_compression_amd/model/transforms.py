@@ -211,12 +211,23 @@ class SparseSynthesisTransform(nn.Module):
         ts_out = cs_in.ts // 2
         feats = x._canonical_features()
         out_set = cs_in.expand(5, ts_out, want_csr=False)
-        kmap3 = out_set.kernel_map(out_set, 3)
         packedM, cb = self._fused_weights(gen, c0)
         csr7 = cs_in.csr_for(out_set.keys, out_set.n, 7, ts_out)
-        h = S.convt_forward_csr(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, out_set.n,
-                                act=L.ACT_RELU, ex_map=kmap3, ex_bias=cb)
-        logit = c2._apply_conv(SparseTensor._from_canonical(out_set, h), out_set, kmap3)
+        from_grid = (S.STENCIL_FROM_GRID and out_set.grid() is not None and c2.kernel_size == 3 and c2.stride == 1
+                     and c2.out_channels <= 4 and c0.out_channels in (4, 8, 16, 32, 64)
+                     and 27 * c2.out_channels * c0.out_channels * 4 <= 48 * 1024)
+        if from_grid:
+            # the candidate set's own bitmap + rank give the 27 neighbours of a row directly: no 3x3x3 kernel map of the
+            # (large) candidate set is built, written and re-read for the presence flags and for the 1-channel convolution
+            h = S.convt_forward_csr_grid(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, out_set,
+                                         L.ACT_RELU, cb)
+            w2 = c2._packed.get(c2.kernel, state_dict_order=True)
+            logit = S.conv_thin_grid_forward(h, w2, c2.bias, c0.out_channels, c2.out_channels, out_set)
+        else:
+            kmap3 = out_set.kernel_map(out_set, 3)
+            h = S.convt_forward_csr(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, out_set.n,
+                                    act=L.ACT_RELU, ex_map=kmap3, ex_bias=cb)
+            logit = c2._apply_conv(SparseTensor._from_canonical(out_set, h), out_set, kmap3)
         pred = SparseTensor._from_canonical(out_set, logit)
         mask, n_keep = self._topk_prediction(pred, k_lvl)
         if probe is not None:

@@ -103,6 +103,7 @@ GRID_MAX_BYTES = 8 << 30
 BAND_TILES = os.environ.get("PCC_BAND_TILES", "1") != "0"      # stencil kernels over large sets visit their tiles band by band (L2 locality of the dx = +-1 slabs)
 BAND_MIN_ROWS = 1 << 20
 BAND_COUNT = 16
+STENCIL_FROM_GRID = os.environ.get("PCC_STENCIL_FROM_GRID", "1") != "0"   # composite levels: 3x3x3 neighbours from the bitmap, no nbr table
 HEAD_FUSED = os.environ.get("PCC_HEAD_FUSED", "1") != "0"      # occupancy heads with <= 16 hidden channels: conv + ReLU + projection in one kernel
 
 
@@ -555,6 +556,39 @@ def convt_forward_csr(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT
     L.call("pcc_convt_fwd_csr", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first),
            L.ptr(pair_ids), n_out, L.ptr(T), L.ptr(out), act, float(slope),
            L.ptr(ex_map.nbr) if ex_map is not None else None, ex_map.K if ex_map is not None else 0, L.ptr(eb), L.stream())
+    return out
+
+
+def convt_forward_csr_grid(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope=0.01):
+    """`convt_forward_csr` with the constant-per-existing-neighbour term keyed on the output set's own grid index
+    (no 3x3x3 kernel map of the candidate set)."""
+    feats = feats.contiguous()
+    n_in, n_out = feats.shape[0], out_set.n
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    if n_out == 0 or n_in == 0:
+        return out
+    first, pair_ids = csr
+    g = out_set.grid()
+    T = torch.empty(n_in * K * cout, dtype=torch.float32, device=feats.device)
+    b = bias.detach().reshape(-1).contiguous() if bias is not None else None
+    L.call("pcc_convt_fwd_csr_grid", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first), L.ptr(pair_ids),
+           n_out, L.ptr(T), L.ptr(out), act, float(slope), L.ptr(out_set.keys), L.ptr(g[0]), L.ptr(g[1]), g[2],
+           L.ptr(ex_bias.detach().to(torch.float32).contiguous()), L.stream())
+    return out
+
+
+def conv_thin_grid_forward(feats, packed_w, bias, cin, cout, cset):
+    """3x3x3 convolution to <= 4 channels over a full set, neighbour rows from the set's grid index."""
+    feats = feats.contiguous()
+    n = feats.shape[0]
+    out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
+    if n == 0:
+        return out
+    g = cset.grid()
+    ws = L.workspace(L.load().pcc_thin_grid_ws_bytes(n, cout), feats.device)
+    b = bias.detach().reshape(-1).contiguous() if bias is not None else None
+    L.call("pcc_conv_thin_grid_fwd", L.ptr(feats), n, cin, L.ptr(packed_w), L.ptr(b), cout, L.ptr(cset.keys), L.ptr(g[0]), L.ptr(g[1]),
+           g[2], L.ptr(out), L.ptr(ws), ws.numel(), L.stream())
     return out
 
 

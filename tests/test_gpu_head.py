@@ -98,3 +98,63 @@ def test_fused_head_matches_oracle(cin, cmid, bands, small_bands):
         finally:
             S.BAND_TILES = old[0]
     assert torch.equal(again.F, got.F)
+
+
+def _two_batch_keys(seed, ts, shift):
+    C = []
+    for b, (size, p) in enumerate(((21, 0.3), (17, 0.2))):
+        c = co.unpack_keys(cloud_keys(seed + b, size, p, ts))
+        c[:, 0] = b
+        c[:, 1:] += shift * ts
+        C.append(c)
+    return np.unique(co.pack_keys(np.concatenate(C)))
+
+
+@pytest.mark.parametrize("ts,shift,cin,cout", [(1, 0, 16, 1), (2, -5, 8, 3), (1, -3, 32, 4)])
+def test_thin_conv_from_grid_matches_oracle(ts, shift, cin, cout):
+    """`pcc_conv_thin_grid_fwd`: 3x3x3 conv to <= 4 channels, neighbour rows from the bitmap + rank (no kernel map);
+    two batch entries, negative coordinates, rows on every face of the bounding lattice."""
+    from unified_point_cloud_compression_amd import sparse as S
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    rng = np.random.default_rng(cin * 7 + cout)
+    keys = _two_batch_keys(3, ts, shift)
+    C = co.unpack_keys(keys)
+    cs = S.CoordSet(t(keys), len(keys), ts, S.Bounds(1, C[:, 1:].min(0), C[:, 1:].max(0)))
+    x = rng.standard_normal((len(keys), cin)).astype(np.float32)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, bias=True, dimension=3).to(dev())
+    with torch.no_grad():
+        conv.kernel.mul_(3.0)
+        conv.bias.add_(0.5)
+        w = conv._packed.get(conv.kernel, state_dict_order=True)
+        got = S.conv_thin_grid_forward(t(x), w, conv.bias, cin, cout, cs)
+        again = S.conv_thin_grid_forward(t(x), w, conv.bias, cin, cout, cs)
+    want = ops.conv(x, n(conv.kernel), n(conv.bias), co.kernel_map(keys, keys, 3, ts))
+    assert_close(n(got), want, what="thin conv from grid vs oracle")
+    assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("ts_in,shift", [(2, 0), (4, -3)])
+def test_composite_gather_presence_from_grid_equals_table_path(ts_in, shift):
+    """`pcc_convt_fwd_csr_grid` == `pcc_convt_fwd_csr` with the 3x3x3 neighbour table, bit for bit (same pair order, same
+    presence flags), on a two-batch input."""
+    from unified_point_cloud_compression_amd import sparse as S, lib as L
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    rng = np.random.default_rng(ts_in)
+    keys = _two_batch_keys(9, ts_in, shift)
+    C = co.unpack_keys(keys)
+    cs = S.CoordSet(t(keys), len(keys), ts_in, S.Bounds(1, C[:, 1:].min(0), C[:, 1:].max(0)))
+    ts_out = ts_in // 2
+    out_set = cs.expand(5, ts_out, want_csr=False)
+    assert out_set.grid() is not None
+    csr7 = cs.csr_for(out_set.keys, out_set.n, 7, ts_out)
+    cin, cout = 16, 8
+    x = t(rng.standard_normal((len(keys), cin)).astype(np.float32))
+    gen = ME.MinkowskiGenerativeConvolutionTranspose(cin, cout, kernel_size=7, stride=2, bias=True, dimension=3).to(dev())
+    ex_bias = t(rng.standard_normal((27, cout)).astype(np.float32))
+    with torch.no_grad():
+        w = gen._packed.get(gen.kernel)
+        a = S.convt_forward_csr_grid(x, w, gen.bias, 343, cin, cout, csr7, out_set, L.ACT_RELU, ex_bias)
+        kmap3 = out_set.kernel_map(out_set, 3)
+        b = S.convt_forward_csr(x, w, gen.bias, 343, cin, cout, csr7, out_set.n, act=L.ACT_RELU, ex_map=kmap3, ex_bias=ex_bias)
+    assert torch.equal(a, b)
+    assert float(a.abs().max().item()) > 0

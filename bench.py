@@ -124,16 +124,23 @@ def account_flops(model, pc, q):
         calls.append((kmap, 27, feats.shape[1], cmid, feats.shape[0], feats.shape[0]))
         return orig_h(feats, packed_w0, bias0, cmid, w2, bias2, cset, kmap)
 
-    names = ("conv_forward", "convt_forward", "convt_forward_csr", "convt_forward_rows", "conv_head_forward")
+    orig_g = S.convt_forward_csr_grid
+
+    def spy_g(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope=0.01):
+        calls.append((int(csr[0][out_set.n].item()), K, cin, cout, out_set.n, feats.shape[0]))
+        return orig_g(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope)
+
+    names = ("conv_forward", "convt_forward", "convt_forward_csr", "convt_forward_rows", "conv_head_forward",
+             "convt_forward_csr_grid")
     S.COUNT_PAIRS = True
-    for nme, f in zip(names, (spy, spy_t, spy_c, spy_r, spy_h)):
+    for nme, f in zip(names, (spy, spy_t, spy_c, spy_r, spy_h, spy_g)):
         setattr(S, nme, f)
     try:
         step(model, pc, q)
         torch.cuda.synchronize()
     finally:
         S.COUNT_PAIRS = False
-        for nme, f in zip(names, (orig, orig_t, orig_c, orig_r, orig_h)):
+        for nme, f in zip(names, (orig, orig_t, orig_c, orig_r, orig_h, orig_g)):
             setattr(S, nme, f)
     flops, launches, pairs_total, alg_bytes = 0.0, 0, 0, 0.0
     for kmap, K, cin, cout, n_out, n_in in calls:

@@ -267,6 +267,21 @@ int pcc_convt_fwd_csr_grid(const float* feat_in, int64_t n_in, int32_t cin, cons
                            int32_t K, int32_t cout, const int32_t* first, const int32_t* pair_ids, int64_t n_out, float* T,
                            float* out, int32_t act, float slope, const int64_t* out_keys, const uint64_t* out_bits,
                            const int32_t* out_rank, const int32_t* h_out, const float* ex_bias, void* stream);
+/* Chunked form of pcc_convt_fwd_csr for 7x7x7 composite levels: the per-pair products never exist as a whole.  Parent rows
+ * are processed in chunks whose products fit the Infinity Cache (pcc_set_t_chunk_bytes, default 96 MiB; env PCC_T_CHUNK_MIB):
+ * GEMM chunk -> staging buffer T (pcc_convt_chunk_t_bytes) -> ordered gather-sum of the children that chunk reaches, partial
+ * sums carried in `out`.  Same summation order per output row as the one-pass form (bit-identical result).  in_keys/out_keys:
+ * canonical keys of the input / output rows; ts_out: output pitch; ws: pcc_convt_chunk_ws_bytes.  ex_bias (nullable) as in
+ * pcc_convt_fwd_csr_grid (then out_bits/out_rank/h_out are the output set's pcc_grid_build arrays). */
+int pcc_set_t_chunk_bytes(int64_t bytes);
+size_t pcc_convt_chunk_t_bytes(int64_t n_in, int32_t K, int32_t cout);
+size_t pcc_convt_chunk_ws_bytes(int64_t n_in, int32_t K, int32_t cout);
+int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias /*nullable*/,
+                              int32_t K, int32_t cout, const int32_t* first, const int32_t* pair_ids, int64_t n_out,
+                              const int64_t* in_keys, const int64_t* out_keys, int32_t ts_out, float* T, size_t t_bytes,
+                              float* out, int32_t act, float slope, const uint64_t* out_bits /*nullable*/,
+                              const int32_t* out_rank /*nullable*/, const int32_t* h_out /*nullable*/,
+                              const float* ex_bias /*nullable*/, void* ws, size_t ws_bytes, void* stream);
 size_t pcc_thin_grid_ws_bytes(int64_t n, int32_t cout);
 int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin, const float* packed_w, const float* bias /*nullable*/,
                            int32_t cout, const int64_t* keys, const uint64_t* bits, const int32_t* rank, const int32_t* h_grid,

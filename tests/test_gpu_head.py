@@ -158,3 +158,49 @@ def test_composite_gather_presence_from_grid_equals_table_path(ts_in, shift):
         b = S.convt_forward_csr(x, w, gen.bias, 343, cin, cout, csr7, out_set.n, act=L.ACT_RELU, ex_map=kmap3, ex_bias=ex_bias)
     assert torch.equal(a, b)
     assert float(a.abs().max().item()) > 0
+
+
+@pytest.mark.parametrize("ts_in,shift,with_ex", [(2, 0, True), (4, -3, True), (2, -2, False)])
+def test_chunked_composite_equals_one_pass_bit_for_bit(ts_in, shift, with_ex):
+    """`pcc_convt_fwd_csr_chunked` (products staged in cache-sized parent chunks, partial sums carried in the output) ==
+    the one-pass form, bit for bit: several chunks, a chunk that spans the batch boundary, output rows with an empty pair
+    list (owned by exactly one chunk), with and without the per-neighbour constant."""
+    from unified_point_cloud_compression_amd import sparse as S, lib as L
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    rng = np.random.default_rng(ts_in + 10)
+    keys = _two_batch_keys(9, ts_in, shift)
+    assert len(keys) > 3 * 1024                                             # >= 4 chunks of 1024 parents
+    C = co.unpack_keys(keys)
+    cs = S.CoordSet(t(keys), len(keys), ts_in, S.Bounds(1, C[:, 1:].min(0), C[:, 1:].max(0)))
+    ts_out = ts_in // 2
+    full = cs.expand(5, ts_out, want_csr=False)
+    ok = n(full.keys)[:full.n]
+    Co = co.unpack_keys(ok)
+    lonely = np.array([[0, Co[:, 1].max() + 40 * ts_out, 0, 0], [1, Co[:, 1].max() + 40 * ts_out, 2 * ts_out, 0],
+                       [0, Co[:, 1].min() - 20 * ts_out, 0, 0]], np.int64)   # no parent within reach: empty pair lists
+    okeys = np.unique(np.concatenate([ok, co.pack_keys(lonely)]))
+    Co = co.unpack_keys(okeys)
+    out_set = S.CoordSet(t(okeys), len(okeys), ts_out, S.Bounds(1, Co[:, 1:].min(0), Co[:, 1:].max(0)))
+    csr7 = cs.csr_for(out_set.keys, out_set.n, 7, ts_out)
+    first = n(csr7[0])
+    assert (np.diff(first[:out_set.n + 1]) == 0).sum() == 3
+    cin, cout = 32, 16
+    x = t(rng.standard_normal((len(keys), cin)).astype(np.float32))
+    gen = ME.MinkowskiGenerativeConvolutionTranspose(cin, cout, kernel_size=7, stride=2, bias=True, dimension=3).to(dev())
+    ex_bias = t(rng.standard_normal((27, cout)).astype(np.float32)) if with_ex else None
+    lib = L.load()
+    try:
+        L.call("pcc_set_t_chunk_bytes", 1 << 20)                             # -> the 1024-row minimum: 4 chunks
+        with torch.no_grad():
+            w = gen._packed.get(gen.kernel)
+            a = S.convt_forward_csr_chunked(x, w, gen.bias, 343, cin, cout, csr7, cs, out_set, L.ACT_RELU, ex_bias)
+            a2 = S.convt_forward_csr_chunked(x, w, gen.bias, 343, cin, cout, csr7, cs, out_set, L.ACT_RELU, ex_bias)
+            if with_ex:
+                b = S.convt_forward_csr_grid(x, w, gen.bias, 343, cin, cout, csr7, out_set, L.ACT_RELU, ex_bias)
+            else:
+                b = S.convt_forward_csr(x, w, gen.bias, 343, cin, cout, csr7, out_set.n, act=L.ACT_RELU)
+    finally:
+        L.call("pcc_set_t_chunk_bytes", 96 << 20)
+    assert lib.pcc_convt_chunk_t_bytes(len(keys), 343, cout) >= 1024 * 343 * cout * 4
+    assert torch.equal(a, b) and torch.equal(a, a2)
+    assert float(a.abs().max().item()) > 0

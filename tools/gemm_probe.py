@@ -26,3 +26,15 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 print(f"PCC_DBG={os.environ.get('PCC_DBG', '0')} split={os.environ.get('PCC_MFMA_SPLIT', '1')} n {n} cin {cin} ncol {ncol}: {ms:.3f} ms  "
       f"{2.0 * n * cin * ncol / ms / 1e9:.1f} TFLOP/s  out {n * ncol * 4 / ms / 1e6:.0f} GB/s")
+if os.environ.get("PCC_DBG", "0") == "0":
+    got = S.conv_forward(x, pk, None, 1, cin, ncol, None, n)
+    rows = torch.arange(0, n, max(n // 2048, 1), device=dev)
+    want = (x[rows].double() @ w.detach().double())
+    err = (got[rows].double() - want).abs()
+    print(f"   check on {len(rows)} rows: max abs err {err.max().item():.3e}  (max |want| {want.abs().max().item():.2f})")
+    if err.max().item() > 1e-3:
+        bad = err > 1e-3
+        br, bc = bad.any(1).nonzero().flatten(), bad.any(0).nonzero().flatten()
+        print("   bad rows (sampled idx):", br[:20].tolist(), "... n", len(br), " bad cols:", bc[:40].tolist(), "... n", len(bc))
+        print("   bad col blocks of 32:", sorted(set((bc // 32).tolist()))[:60])
+        print("   bad row mod 128 (of sampled rows):", sorted(set((rows[br] % 128).tolist()))[:130])

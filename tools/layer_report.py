@@ -76,6 +76,19 @@ def spy_h(feats, packed_w0, bias0, cmid, w2, bias2, cset, kmap):
     return out
 
 
+orig_g = S.convt_forward_csr_grid
+
+
+def spy_g(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope=0.01):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = orig_g(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope)
+    e1.record()
+    calls.append((int(csr[0][out_set.n].item()), -K, cin, cout, feats.shape[0], out_set.n, e0, e1))
+    return out
+
+
+S.convt_forward_csr_grid = spy_g
 S.COUNT_PAIRS, S.conv_forward, S.convt_forward, S.convt_forward_csr, S.convt_forward_rows = True, spy, spy_t, spy_c, spy_r
 S.conv_head_forward = spy_h
 

@@ -769,6 +769,150 @@ __global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Dense GEMM form of the split kernel, stripped to what the products of the generative transposed convolutions need:
+//   T[n, ncol] = X[n, cin] x W[cin, ncol],  cin = NCH * 32, no bias / activation / row list, 128 x 128 tiles.
+// Same data flow as k_conv_mfma_bf (bf16 planes -> registers -> padded LDS images -> six MFMA terms, fp32 accumulate), but a
+// tile here is only NCH = 4 chunks deep, so the fixed cost per tile decided the run time of the general kernel: with loads,
+// MFMAs and stores all switched off it still took 0.77 of 2.65 ms on the level-2 products (PCC_DBG) --
+// tile decode through the map header, per-chunk offset arithmetic for gathered rows, 64-bit address arithmetic for each of the
+// 64 stores of a lane.  Here every address is (per-tile scalar base in a buffer descriptor) + (per-lane offset computed once)
+// + (compile-time immediate or a scalar), the chunk loop is unrolled, and tail tiles take their own path.
+// ------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
+  constexpr int BM = 128, BN = 128, LDU = 13;
+  constexpr unsigned ROWB = NCH * 192u;                // bytes of a feature row's planes
+  __shared__ __attribute__((aligned(16))) uint4 As[BM * LDU];
+  __shared__ __attribute__((aligned(16))) uint4 Bs[BN * LDU];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cpx = gridDim.x >> 3;
+  const int wid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  const int gy = a.cout_pad / BN;
+  int tile_id, colblock;
+  if (gy > 8) {                                         // groups of 8 row tiles sweep the column blocks together (weights > L2)
+    const int g = wid / (8 * gy), rem = wid - g * 8 * gy;
+    colblock = (rem >> 3) * BN;
+    tile_id = g * 8 + (rem & 7);
+  } else {
+    tile_id = wid / gy;
+    colblock = (wid - tile_id * gy) * BN;
+  }
+  const long long p0 = (long long)tile_id * BM;
+  if (p0 >= a.n_out) return;
+  const int npos = (int)min((long long)BM, a.n_out - p0);
+
+  // descriptors: the tile's feature rows (rows past the end read as zero), the column block's weights, the tile's output rows
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(a.featb) + (size_t)p0 * ROWB, (short)0, (int)((unsigned)npos * ROWB), 0x00020000);
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.wp + a.wp_elems) + (size_t)colblock * 192u;
+  const unsigned b_stride = (unsigned)a.cout_pad * 192u;             // bytes between the weight planes of consecutive chunks
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(wb), (short)0, (int)((NCH - 1) * b_stride + BN * 192u), 0x00020000);
+
+  // staging roles: 16-byte unit u = j * 256 + tid of the tile's [128 rows][12 units] piece, j = 0..5
+  unsigned vA[6], ld[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const unsigned u = (unsigned)(j * 256 + tid), row = u / 12u, wu = u - row * 12u;
+    vA[j] = row * ROWB + wu * 16u;
+    ld[j] = row * LDU + wu;
+  }
+  const unsigned vB = (unsigned)tid * 16u;
+
+  uint4 av[6], bv[6];
+  auto issue = [&](int cbi) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (a.dbg & 4) ? BUF_OOB : vA[j] + (unsigned)cbi * 192u, 0, 0));
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (a.dbg & 4) ? BUF_OOB : vB, (int)((unsigned)cbi * b_stride + (unsigned)j * 4096u), 0));
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm = w >> 1, wn = w & 1;
+  const int half = lane >> 5, r31 = lane & 31;
+  const unsigned fa = (unsigned)((wm * 64 + r31) * LDU + half), fb = (unsigned)((wn * 64 + r31) * LDU + half);
+
+  issue(0);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    __syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < 6; ++j) As[ld[j]] = av[j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Bs[ld[j]] = bv[j];
+    __syncthreads();
+    if (c + 1 < NCH) issue(c + 1);            // next chunk's global loads fly during this chunk's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.dbg & 2) continue;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[3][2], bf[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[p][i] = __builtin_bit_cast(bf16x8, As[fa + i * 32 * LDU + p * 4 + ks * 2]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[p][j] = __builtin_bit_cast(bf16x8, Bs[fb + j * 32 * LDU + p * 4 + ks * 2]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {           // smallest terms first (same order as k_conv_mfma_bf: identical results)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  if (a.dbg & 1) { if (acc[0][0][0] != 12345.678f) return; }
+
+  // ---- stores: element e of acc[i][j] is row wm*64 + i*32 + (e&3) + 8*(e>>2) + 4*half, column wn*64 + j*32 + r31 of the tile
+  const unsigned ncol = (unsigned)a.cout;
+  float* const obase = a.out + (size_t)p0 * ncol + colblock;
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+      obase, (short)0, (int)(((unsigned)(npos - 1) * ncol + min((unsigned)BN, ncol - (unsigned)colblock)) * 4u), 0x00020000);
+  const unsigned vO = ((unsigned)(wm * 64 + 4 * half) * ncol + (unsigned)(wn * 64 + r31)) * 4u;
+  if (npos == BM && (unsigned)colblock + BN <= ncol) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const unsigned so = (unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * ncol * 4u;      // scalar
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float v = acc[i][j][e];          // (a bit_cast of the vector element itself compiles to element 0)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if ((unsigned)colblock + (unsigned)(wn * 64 + j * 32 + r31) >= ncol) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (r >= npos) continue;
+        obase[(size_t)r * ncol + (unsigned)(wn * 64 + j * 32 + r31)] = acc[i][j][e];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Persistent form of the split kernel for the GEMM-shaped launches -- dense [n, cin] x [cin, ncol] (generative transposed
 // convolutions, 1x1 convolutions, GDN) and the gathered pair GEMMs (one kernel offset per 128-pair tile).  Their
 // reduction is only cin deep (4 chunks at cin = 128): with one tile per workgroup the tile's first loads (full memory
@@ -1635,6 +1779,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 
 static bool g_splitk = getenv("PCC_SPLITK") ? atoi(getenv("PCC_SPLITK")) != 0 : true;
 static bool g_gemm_persistent = getenv("PCC_GEMM_PERSISTENT") ? atoi(getenv("PCC_GEMM_PERSISTENT")) != 0 : false;   // measured slower (2 workgroups per CU): off
+static bool g_gemm2 = getenv("PCC_GEMM2") ? atoi(getenv("PCC_GEMM2")) != 0 : true;
 static int g_dbg = getenv("PCC_DBG") ? atoi(getenv("PCC_DBG")) : 0;
 
 // persistent GEMM form (identity rows or pair lists; a.featb set): 2 workgroups per CU (the kernel needs ~200 VGPRs)
@@ -1687,7 +1832,9 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
       if (ksplit < 2) ksplit = 1;
     }
   }
-  if (split) {
+  if (split && a.featb) {
+    PCC_REQUIRE(ksplit == 1, "launch_mfma: caller planes with a split reduction");
+  } else if (split) {
     const size_t plane_bytes = pcc_align_up((size_t)a.n_in * a.cin * 6);
     const size_t part_bytes = ksplit > 1 ? (size_t)ksplit * (size_t)a.n_out * a.cout * 4 : 0;
     void* p = nullptr;
@@ -1701,6 +1848,21 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
   a.dbg = g_dbg;
   ksplit_grid = a.ksplit;
   if (split && !a.hdr && g_gemm_persistent) return launch_gemm_bf<MODE>(a, s);
+  // plain dense products (generative transposed convolutions): the stripped GEMM kernel
+  if (split && g_gemm2 && MODE == MODE_CONV && !a.hdr && !a.pair_in && !a.rows && !a.bias && a.act == 0 && a.ksplit == 1 &&
+      bn == 128 && tiles(128) * gy >= want && (size_t)128 * a.cout * 4 < (1ull << 31)) {
+    const dim3 g2 = grid(128);
+    bool done = true;
+    switch (a.ppo) {
+      case 1: k_gemm_bf2<1><<<g2, 256, 0, s>>>(a); break;
+      case 2: k_gemm_bf2<2><<<g2, 256, 0, s>>>(a); break;
+      case 4: k_gemm_bf2<4><<<g2, 256, 0, s>>>(a); break;
+      case 6: k_gemm_bf2<6><<<g2, 256, 0, s>>>(a); break;
+      case 8: k_gemm_bf2<8><<<g2, 256, 0, s>>>(a); break;
+      default: done = false;
+    }
+    if (done) { PCC_LAUNCH_CHECK(); return PCC_OK; }
+  }
 #define PCC_LAUNCH_MFMA(WM, WN, TM, TN, BMV)                                                     \
   do {                                                                                           \
     if (split) k_conv_mfma_bf<WM, WN, TM, TN, MODE><<<grid(BMV), 256, 0, s>>>(a);                \
@@ -2631,6 +2793,195 @@ extern "C" int pcc_convt_fwd_csr_grid(const float* feat_in, int64_t n_in, int32_
                                    nullptr, 27, ex_bias, stream);
   g_ex_grid.bits = nullptr;
   return rc;
+}
+
+// ---- chunked form of the CSR generative transposed convolution --------------------------------------------------------
+// The per-pair products T[n_in][K][cout] of a composite 7x7x7 level are 5 GB -- written by the GEMM, read once by the ordered
+// gather-sum.  Input rows are canonical (x-major), so a run of consecutive parents touches a contiguous run of children; the
+// path is therefore cut into parent chunks whose products fit the 256 MiB Infinity Cache: GEMM chunk c -> T (one staging
+// buffer, re-used by every chunk) -> gather-sum of the children chunk c reaches.  A child whose pair list straddles chunks
+// carries its partial sum in `out`; pair ids ascend with the parent row, so every child still adds its pairs in list order
+// and the result is bit-identical to the one-pass form.
+__global__ void __launch_bounds__(256) k_chunk_ranges(const long long* __restrict__ in_keys, long long n_in,
+                                                      const long long* __restrict__ out_keys, long long n_out,
+                                                      long long chunk_rows, int n_chunks, int ts_out, int4* ranges) {
+  auto lower = [&](long long q) {
+    long long lo = 0, hi = n_out;
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (out_keys[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    return (int)lo;
+  };
+  const long long reach = 3ll * ts_out;                                  // 7-wide kernel: children within +-3 output pitches
+  for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) {
+    const long long r0 = (long long)c * chunk_rows;
+    const long long r1 = r0 + chunk_rows < n_in ? r0 + chunk_rows : n_in;
+    const long long k0 = in_keys[r0], k1 = in_keys[r1 - 1];
+    const long long x0 = (k0 >> 32) & 0xFFFF, x1 = ((k1 >> 32) & 0xFFFF) + reach + 1;
+    const long long lo_key = (k0 & 0x7FFF000000000000ll) | ((x0 > reach ? x0 - reach : 0ll) << 32);
+    const long long hi_key = (k1 & 0x7FFF000000000000ll) + (x1 << 32);  // + : a carry out of the x field moves on to the next batch
+    ranges[c] = make_int4(lower(lo_key), c == n_chunks - 1 ? (int)n_out : lower(hi_key), 0, 0);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) {
+    const int prev_hi = c ? ranges[c - 1].y : 0;                          // rows below: owned (if their list is empty) by an earlier chunk
+    ranges[c].z = prev_hi;
+    if (prev_hi < ranges[c].x) ranges[c].x = prev_hi;
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_convt_gather_csr_chunk(GatherCsrArgs a, const int4* __restrict__ range, int pid_lo,
+                                                                int pid_hi) {
+  typedef typename ThinVec<VEC>::T VT;
+  constexpr int JB = 8;
+  const int4 rg = *range;
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << a.lpr_log2;
+  const int rpw = 64 >> a.lpr_log2;
+  const int cl = lane & (lpr - 1);
+  const int cvec = a.cout / VEC;
+  const long long per_block = 4ll * rpw;
+  for (long long base = rg.x + (long long)blockIdx.x * per_block; base < rg.y; base += (long long)gridDim.x * per_block) {
+    const long long o = base + (long long)(threadIdx.x >> 6) * rpw + (lane >> a.lpr_log2);
+    if (o >= rg.y) continue;
+    const int t0 = a.first[o], t1 = a.first[o + 1];
+    bool has_earlier = false, is_last = true;
+    if (t0 == t1) {
+      if (o < rg.z) continue;                                             // empty list: finished by the chunk that owns the row
+    } else {
+      const int first_pid = a.pair_ids[t0], last_pid = a.pair_ids[t1 - 1];
+      if (last_pid < pid_lo || first_pid >= pid_hi) continue;             // finished earlier / starts later
+      has_earlier = first_pid < pid_lo;
+      is_last = last_pid < pid_hi;
+    }
+    unsigned long long present = 0;
+    if (is_last && a.ex_grid.bits) {                                      // (uniform over the row's lane group)
+      unsigned m = pcc_grid_nbr27(a.ex_grid, a.out_keys[o], cl, lpr < 9 ? lpr : 9, nullptr);
+      for (int d = lpr >> 1; d >= 1; d >>= 1) m |= __shfl_xor((int)m, d, lpr);
+      present = m;
+    }
+    for (int cv = cl; cv < cvec; cv += lpr) {
+      VT acc;
+      thin_zero(acc);
+      if (has_earlier) acc = reinterpret_cast<const VT*>(a.out + o * a.cout)[cv];
+      for (int t = t0; t < t1; t += JB) {
+        int pid[JB];
+#pragma unroll
+        for (int u = 0; u < JB; ++u) {
+          const int p = (t + u < t1) ? a.pair_ids[t + u] : -1;
+          pid[u] = (p >= pid_lo && p < pid_hi) ? p - pid_lo : -1;
+        }
+        VT x[JB];
+#pragma unroll
+        for (int u = 0; u < JB; ++u) {
+          thin_zero(x[u]);
+          if (pid[u] >= 0) x[u] = reinterpret_cast<const VT*>(a.T + (long long)pid[u] * a.cout)[cv];
+        }
+#pragma unroll
+        for (int u = 0; u < JB; ++u) thin_acc(acc, x[u]);     // fixed order: pair id ascending, continued from the stored partial
+      }
+      if (is_last) {
+        for (unsigned long long pr = a.ex_bias ? present : 0ull; pr;) {
+          const int k = __ffsll((long long)pr) - 1;
+          pr &= pr - 1;
+          thin_acc(acc, reinterpret_cast<const VT*>(a.ex_bias + (long long)k * a.cout)[cv]);
+        }
+        VT b;
+        thin_zero(b);
+        if (a.bias) b = reinterpret_cast<const VT*>(a.bias)[cv];
+        thin_acc(acc, b);
+        thin_act(acc, a.act, a.slope);
+      }
+      reinterpret_cast<VT*>(a.out + o * a.cout)[cv] = acc;
+    }
+  }
+}
+
+static long long g_chunk_bytes = getenv("PCC_T_CHUNK_MIB") ? atoll(getenv("PCC_T_CHUNK_MIB")) << 20 : 96ll << 20;
+extern "C" int pcc_set_t_chunk_bytes(int64_t bytes) { g_chunk_bytes = bytes; return PCC_OK; }
+
+static long long chunk_rows_for(int64_t n_in, int32_t K, int32_t cout) {
+  long long rows = g_chunk_bytes / ((long long)K * cout * 4) / 1024 * 1024;      // whole groups of 8 row tiles of 128
+  if (rows < 1024) rows = 1024;
+  return rows < n_in ? rows : (n_in + 1023) / 1024 * 1024;
+}
+
+extern "C" size_t pcc_convt_chunk_t_bytes(int64_t n_in, int32_t K, int32_t cout) {
+  return n_in <= 0 ? 256 : pcc_align_up((size_t)chunk_rows_for(n_in, K, cout) * K * cout * 4);
+}
+extern "C" size_t pcc_convt_chunk_ws_bytes(int64_t n_in, int32_t K, int32_t cout) {
+  return n_in <= 0 ? 256 : pcc_align_up((size_t)pcc_cdiv(n_in, chunk_rows_for(n_in, K, cout)) * sizeof(int4));
+}
+
+extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                                         const float* bias, int32_t K, int32_t cout, const int32_t* first,
+                                         const int32_t* pair_ids, int64_t n_out, const int64_t* in_keys,
+                                         const int64_t* out_keys, int32_t ts_out, float* T, size_t t_bytes, float* out,
+                                         int32_t act, float slope, const uint64_t* out_bits, const int32_t* out_rank,
+                                         const int32_t* h_out, const float* ex_bias, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out <= 0 || n_in <= 0) return PCC_OK;
+  PCC_REQUIRE(feat_in && packed_w && first && pair_ids && in_keys && out_keys && T && out && ws,
+              "pcc_convt_fwd_csr_chunked: NULL array");
+  PCC_REQUIRE(K == 343, "pcc_convt_fwd_csr_chunked: 7x7x7 kernels only (K=%d)", K);
+  PCC_REQUIRE(mfma_ok(cin, K * cout), "pcc_convt_fwd_csr_chunked: unsupported shape cin=%d cout=%d", cin, cout);
+  PCC_REQUIRE(act >= 0 && act <= 2, "pcc_convt_fwd_csr_chunked: bad activation");
+  PCC_REQUIRE(n_in * K < (1ll << 31) && n_out < (1ll << 31), "pcc_convt_fwd_csr_chunked: too many rows");
+  PCC_REQUIRE(ts_out >= 1 && ts_out <= 16, "pcc_convt_fwd_csr_chunked: output pitch %d", ts_out);
+  PCC_REQUIRE(!ex_bias || (out_bits && out_rank && h_out), "pcc_convt_fwd_csr_chunked: ex_bias needs the output set's grid index");
+  const long long chunk_rows = chunk_rows_for(n_in, K, cout);
+  const int n_chunks = (int)pcc_cdiv(n_in, chunk_rows);
+  PCC_REQUIRE(t_bytes >= pcc_convt_chunk_t_bytes(n_in, K, cout) && ws_bytes >= pcc_convt_chunk_ws_bytes(n_in, K, cout),
+              "pcc_convt_fwd_csr_chunked: staging buffer or workspace too small");
+  int4* ranges = (int4*)ws;
+  k_chunk_ranges<<<1, 256, 0, s>>>((const long long*)in_keys, n_in, (const long long*)out_keys, n_out, chunk_rows, n_chunks,
+                                   ts_out, ranges);
+  PCC_LAUNCH_CHECK();
+  ConvArgs a;
+  a.wp = packed_w; a.bias = nullptr; a.hdr = nullptr; a.nbr = nullptr; a.rows = nullptr; a.out = T;
+  a.cin = cin; a.cout = K * cout; a.cout_pad = cout_pad_for(K * cout);
+  a.wp_elems = (long long)cin * a.cout_pad;
+  a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
+  a.feat = feat_in; a.n_in = n_in; a.n_out = n_in;
+  const bool split = split_ok(a);
+  const unsigned char* planes = nullptr;
+  if (split) {                                                           // bf16 planes of every input row, once
+    PCC_TRY(make_planes(a, false, s));
+    planes = a.featb;
+  }
+  GatherCsrArgs g;
+  g.T = T; g.bias = bias; g.first = first; g.pair_ids = pair_ids; g.out = out; g.n_out = n_out; g.cout = cout;
+  g.act = act; g.slope = slope; g.ex_nbr = nullptr; g.ex_bias = ex_bias; g.ex_K = 27;
+  g.ex_grid.bits = nullptr; g.out_keys = nullptr;
+  if (ex_bias) { g.ex_grid = grid_from_host(out_bits, out_rank, h_out); g.out_keys = (const long long*)out_keys; }
+  const int vec = (cout % 4 == 0) ? 4 : 1;
+  int l = 0;
+  while ((1 << l) < cout / vec && l < 6) ++l;
+  g.lpr_log2 = l;
+  int dev = 0, cus = 0;
+  PCC_CHECK_HIP(hipGetDevice(&dev));
+  PCC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const unsigned ggrid = (unsigned)cus * 8;
+  for (int c = 0; c < n_chunks; ++c) {
+    const long long r0 = (long long)c * chunk_rows;
+    const long long rows = r0 + chunk_rows < n_in ? chunk_rows : n_in - r0;
+    a.feat = feat_in + r0 * cin; a.n_in = rows; a.n_out = rows;
+    a.featb = planes ? planes + (size_t)r0 * cin * 6 : nullptr;
+    hipEvent_t e0, e1;
+    if (g_prof_on) PCC_TRY(prof_event(&e0, s));
+    PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));
+    if (g_prof_on) {
+      PCC_TRY(prof_event(&e1, s));
+      ++g_launches;
+    }
+    const int pid_lo = (int)(r0 * K), pid_hi = (int)((r0 + rows) * K);
+    if (vec == 4) k_convt_gather_csr_chunk<4><<<ggrid, 256, 0, s>>>(g, ranges + c, pid_lo, pid_hi);
+    else k_convt_gather_csr_chunk<1><<<ggrid, 256, 0, s>>>(g, ranges + c, pid_lo, pid_hi);
+    PCC_LAUNCH_CHECK();
+  }
+  return PCC_OK;
 }
 
 // 3x3x3 convolution to <= 4 channels on a full set, neighbours from the set's grid index (no kernel map):

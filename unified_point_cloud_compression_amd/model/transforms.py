@@ -219,8 +219,12 @@ class SparseSynthesisTransform(nn.Module):
         if from_grid:
             # the candidate set's own bitmap + rank give the 27 neighbours of a row directly: no 3x3x3 kernel map of the
             # (large) candidate set is built, written and re-read for the presence flags and for the 1-channel convolution
-            h = S.convt_forward_csr_grid(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, out_set,
-                                         L.ACT_RELU, cb)
+            if S.T_CHUNKED and cs_in.n * 343 * c0.out_channels * 4 >= S.T_CHUNKED_MIN_BYTES:
+                h = S.convt_forward_csr_chunked(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, cs_in,
+                                                out_set, L.ACT_RELU, cb)
+            else:
+                h = S.convt_forward_csr_grid(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, out_set,
+                                             L.ACT_RELU, cb)
             w2 = c2._packed.get(c2.kernel, state_dict_order=True)
             logit = S.conv_thin_grid_forward(h, w2, c2.bias, c0.out_channels, c2.out_channels, out_set)
         else:

@@ -103,6 +103,10 @@ GRID_MAX_BYTES = 8 << 30
 BAND_TILES = os.environ.get("PCC_BAND_TILES", "1") != "0"      # stencil kernels over large sets visit their tiles band by band (L2 locality of the dx = +-1 slabs)
 BAND_MIN_ROWS = 1 << 20
 BAND_COUNT = 16
+T_CHUNKED = os.environ.get("PCC_T_CHUNKED", "0") != "0"            # composite levels: per-pair products staged in cache-sized chunks
+#   (measured round 2: bit-identical, 10 GB less memory, but +3.5 ms per step -- 125 chunk pairs of launches, children near
+#   chunk borders visited twice, and the Infinity Cache does not speed the gather up enough to pay for it: off)
+T_CHUNKED_MIN_BYTES = 256 << 20
 STENCIL_FROM_GRID = os.environ.get("PCC_STENCIL_FROM_GRID", "1") != "0"   # composite levels: 3x3x3 neighbours from the bitmap, no nbr table
 HEAD_FUSED = os.environ.get("PCC_HEAD_FUSED", "1") != "0"      # occupancy heads with <= 16 hidden channels: conv + ReLU + projection in one kernel
 
@@ -574,6 +578,29 @@ def convt_forward_csr_grid(feats, packed_w, bias, K, cin, cout, csr, out_set, ac
     L.call("pcc_convt_fwd_csr_grid", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first), L.ptr(pair_ids),
            n_out, L.ptr(T), L.ptr(out), act, float(slope), L.ptr(out_set.keys), L.ptr(g[0]), L.ptr(g[1]), g[2],
            L.ptr(ex_bias.detach().to(torch.float32).contiguous()), L.stream())
+    return out
+
+
+def convt_forward_csr_chunked(feats, packed_w, bias, K, cin, cout, csr, in_set, out_set, act, ex_bias=None, slope=0.01):
+    """`convt_forward_csr` / `convt_forward_csr_grid` without the whole per-pair buffer: parent rows go through in chunks
+    whose products fit the Infinity Cache (staging buffer in the shared workspace), partial sums carried in the output."""
+    feats = feats.contiguous()
+    n_in, n_out = feats.shape[0], out_set.n
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    if n_out == 0 or n_in == 0:
+        return out
+    first, pair_ids = csr
+    lib = L.load()
+    tb, wb = lib.pcc_convt_chunk_t_bytes(n_in, K, cout), lib.pcc_convt_chunk_ws_bytes(n_in, K, cout)
+    ws = L.workspace(tb + wb, feats.device)
+    g = out_set.grid() if ex_bias is not None else None
+    if ex_bias is not None and g is None:
+        raise L.PccError("convt_forward_csr_chunked: ex_bias needs the grid index of the output set")
+    b = bias.detach().reshape(-1).contiguous() if bias is not None else None
+    eb = ex_bias.detach().to(torch.float32).contiguous() if ex_bias is not None else None
+    L.call("pcc_convt_fwd_csr_chunked", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first), L.ptr(pair_ids),
+           n_out, L.ptr(in_set.keys), L.ptr(out_set.keys), out_set.ts, ws.data_ptr() + wb, tb, L.ptr(out), act, float(slope),
+           L.ptr(g[0]) if g else None, L.ptr(g[1]) if g else None, g[2] if g else None, L.ptr(eb), ws.data_ptr(), wb, L.stream())
     return out
 
 

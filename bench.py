@@ -107,11 +107,11 @@ def account_flops(model, pc, q):
         return orig(feats, packed_w, bias, K, cin, cout, kmap, n_out, act, slope)
 
     def spy_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=0, slope=0.01):
-        calls.append((kmap, K, cin, cout, n_out, feats.shape[0]))     # pairs = n_in*K: the dense GEMM does exactly the algorithmic FLOPs
+        calls.append((kmap, -K, cin, cout, n_out, feats.shape[0]))    # pairs = n_in*K: the dense GEMM does exactly the algorithmic FLOPs
         return orig_t(feats, packed_w, bias, K, cin, cout, kmap, n_out, act, slope)
 
     def spy_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01, **kw):
-        calls.append((int(csr[0][n_out].item()), K, cin, cout, n_out, feats.shape[0]))  # pairs of the map (full expansion: n_in*K)
+        calls.append((int(csr[0][n_out].item()), -K, cin, cout, n_out, feats.shape[0]))  # pairs of the map (full expansion: n_in*K)
         return orig_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope, **kw)
 
     orig_r, orig_h = S.convt_forward_rows, S.conv_head_forward
@@ -127,7 +127,7 @@ def account_flops(model, pc, q):
     orig_g = S.convt_forward_csr_grid
 
     def spy_g(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope=0.01):
-        calls.append((int(csr[0][out_set.n].item()), K, cin, cout, out_set.n, feats.shape[0]))
+        calls.append((int(csr[0][out_set.n].item()), -K, cin, cout, out_set.n, feats.shape[0]))
         return orig_g(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope)
 
     names = ("conv_forward", "convt_forward", "convt_forward_csr", "convt_forward_rows", "conv_head_forward",
@@ -142,17 +142,31 @@ def account_flops(model, pc, q):
         S.COUNT_PAIRS = False
         for nme, f in zip(names, (orig, orig_t, orig_c, orig_r, orig_h, orig_g)):
             setattr(S, nme, f)
-    flops, launches, pairs_total, alg_bytes = 0.0, 0, 0, 0.0
+    flops, launches, pairs_total, alg_bytes, exec_flops = 0.0, 0, 0, 0.0, 0.0
+    split_on = os.environ.get("PCC_MFMA_SPLIT", "1") != "0"
+    h_on = os.environ.get("PCC_GEMM_H", "1") != "0"
     for kmap, K, cin, cout, n_out, n_in in calls:
+        dense, K = K < 0, abs(K)                          # K < 0: dense products of a generative transposed convolution
         if not mfma_shape(cin, cout):
             continue
         p = kmap if isinstance(kmap, int) else (kmap.pairs() if kmap is not None else n_out)
-        flops += 2.0 * p * cin * cout
+        fl = 2.0 * p * cin * cout
+        flops += fl
+        # 16-bit MFMA FLOPs executed per algorithmic FLOP: 3 (dense products, scaled fp16 pairs: k_gemm_h2), 6 (bf16 split:
+        # k_conv_mfma_bf), or the fp32-input MFMA kernels priced at their own peak (2500 / 157.3)
+        if cin % 32 != 0 or not split_on:
+            terms = PEAK_BF16_MFMA_TFLOPS / PEAK_FP32_MFMA_TFLOPS
+        elif (dense and h_on and cin <= 256 and cin // 32 in (1, 2, 4, 6, 8) and K * cout >= 128 and
+              (-(-n_in // 128) + 7) // 8 * 8 * (-(-(K * cout) // 128)) >= 512):
+            terms = 3.0
+        else:
+            terms = float(SPLIT_TERMS)
+        exec_flops += fl * terms
         # compulsory traffic of the layer: every feature row, weight, map entry, coordinate touched once
         alg_bytes += 4.0 * (n_in * cin + n_out * cout + K * cin * cout) + 8.0 * p + 16.0 * (n_in + n_out)
         pairs_total += p
         launches += 1
-    return flops, launches, pairs_total, alg_bytes
+    return flops, launches, pairs_total, alg_bytes, exec_flops
 
 
 def cpu_baseline(threads=None):
@@ -351,7 +365,8 @@ def main():
     for _ in range(args.warmup):
         step(model, pc, q)
     torch.cuda.synchronize()
-    flops_step, launches_step, pairs_step, alg_bytes_step = account_flops(model, pc, q) if rank == 0 else (0.0, 0, 0, 0.0)
+    flops_step, launches_step, pairs_step, alg_bytes_step, exec_flops_step = (account_flops(model, pc, q) if rank == 0
+                                                                              else (0.0, 0, 0, 0.0, 0.0))
 
     lib.call("pcc_prof_enable", 1 if rank == 0 else 0)
     barrier()
@@ -418,7 +433,9 @@ def main():
     if rank == 0:
         traffic, traffic_note = pmc_traffic()
         split_on = os.environ.get("PCC_MFMA_SPLIT", "1") != "0"
-        peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if split_on else PEAK_FP32_MFMA_TFLOPS
+        # roof of the ALGORITHMIC FLOPs of this mix of launches: the dense 16-bit MFMA peak divided by the 16-bit MFMA FLOPs
+        # executed per algorithmic FLOP (3 for the dense products, 6 for the gathered convolutions, see account_flops)
+        peak = PEAK_BF16_MFMA_TFLOPS * flops_step / exec_flops_step if exec_flops_step else PEAK_FP32_MFMA_TFLOPS
         ms_step = dt_max / args.steps * 1e3
         # conv launches: only MFMA-shaped ones are event-timed inside the library
         ach = (flops_step * args.steps / (conv_ms.value * 1e-3) / 1e12) if conv_ms.value > 0 else None
@@ -433,9 +450,11 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: one synthetic longdress-like vox{args.bits} frame per GPU "
                                    f"({n_points} points on rank 0), R2 architecture, random-init weights, q=[[0.5,0.5]], "
                                    f"1 block; entropy coder in the timed region: {args.coder}",
-                       "arithmetic": ("fp32 features and accumulation; matrix products evaluated on the bf16 MFMA pipe from an exact "
-                                      "3-way bf16 split of both fp32 operands (6 cross terms; error at fp32 rounding level, "
-                                      "tests/test_gpu_map_conv.py::test_split_path_accuracy)") if split_on else "fp32-input MFMA",
+                       "arithmetic": ("fp32 features and accumulation; matrix products on the 16-bit MFMA pipe at fp32 accuracy: "
+                                      "gathered convolutions from an exact 3-way bf16 split of both operands (6 terms, "
+                                      "tests/test_gpu_map_conv.py::test_split_path_accuracy), dense products of the generative "
+                                      "convolutions from row/column-scaled fp16 pairs (3 terms, ::test_dense_products_accuracy)")
+                       if split_on else "fp32-input MFMA",
                        "bpp_y_z_strings": bpp, "bpp_likelihood": rd["bpp_likelihood"], "d1_psnr": rd["d1_psnr_sym"],
                        "rate_distortion": rd, "ms_per_step_without_entropy_coder": hot_ms,
                        "frames_per_step": world, "encode_ms": recs[0][2] * 1e3, "decode_ms": recs[0][3] * 1e3,
@@ -449,11 +468,12 @@ def main():
                          "frac": (ach / peak) if ach else None, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
                          "alg_bytes_per_launch": (alg_bytes_step / launches_step) if launches_step else None,
-                         "kernel": "k_conv_mfma_bf (pcc_conv_fwd / pcc_conv_fwd_pairs / pcc_convt_fwd_csr GEMM): fp32 products as "
-                                   "6 bf16 MFMA terms" if split_on else "k_conv_mfma (fp32-input MFMA)",
-                         "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 split terms per fp32 product" if split_on
+                         "kernel": "k_gemm_h2 (dense products of pcc_convt_fwd_csr*, 3 fp16 MFMA terms) + k_conv_mfma_bf (pcc_conv_fwd / "
+                                   "pcc_conv_fwd_pairs, 6 bf16 MFMA terms)" if split_on else "k_conv_mfma (fp32-input MFMA)",
+                         "peak_note": ("dense 16-bit MFMA peak 2500 TFLOP/s / executed 16-bit FLOPs per algorithmic FLOP "
+                                       f"({exec_flops_step / flops_step:.2f} for this mix of launches)" if (split_on and flops_step)
                                        else "dense fp32-input MFMA peak"),
-                         "executed_bf16_tflops": (ach * SPLIT_TERMS) if (ach and split_on) else None,
+                         "executed_16bit_tflops": (ach * exec_flops_step / flops_step) if (ach and flops_step) else None,
                          "vs_fp32_mfma_peak": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
                          "flop_per_step": flops_step, "pairs_per_step": pairs_step, "launches_per_step": launches_step,
                          "avg_launch_ms": (conv_ms.value / conv_launches.value) if conv_launches.value else None,

@@ -190,6 +190,9 @@ int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows
  * exact three-way bf16 split of both operands (six cross terms, fp32 accumulation: fp32 accuracy at 2.67x the fp32-MFMA
  * rate); 0 selects the fp32-input MFMA kernels.  Process-wide switch (tests compare both). */
 int pcc_set_mfma_split(int32_t on);
+/* dense products of the generative transposed convolutions in scaled fp16 pairs (three MFMA terms; default on) or the
+ * six-term bf16 form (0); both at fp32 accuracy, tests/test_gpu_map_conv.py::test_dense_products_accuracy. */
+int pcc_set_gemm_h(int32_t on);
 int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
 /* W: ME layout [K, cin, cout] row-major (state_dict `kernel`).  packed_cap: floats available at
  * `packed`; a buffer smaller than pcc_conv_packed_elems(K, cin, cout) is refused (PCC_EWS), never written past. */

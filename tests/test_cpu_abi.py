@@ -35,7 +35,7 @@ def test_size_queries_are_pure_host_functions():
     assert L.pcc_conv_packed_elems(27, 192, 192) == 27 * 192 * 256 * 5 // 2     # padded to the 128-wide column tile
     assert L.pcc_conv_packed_elems(125, 4, 128) == 125 * 4 * 128                # narrow inputs: fp32 image only
     assert L.pcc_conv_packed_elems(27, 24, 24) == 0                           # unsupported shape is reported, not guessed
-    assert L.pcc_convt_packed_elems(125, 128, 32) == 128 * 4096 * 5 // 2
+    assert L.pcc_convt_packed_elems(125, 128, 32) == 128 * 4096 * 5 // 2 + 128 * 4096 + 4096   # + fp16 planes + column scales
     assert L.pcc_gdn_packed_elems(128) == 128 * 128 * 5 // 2 and L.pcc_gdn_packed_elems(24) == 0
 
 
@@ -108,6 +108,8 @@ def test_packed_size_queries_cover_what_the_pack_kernels_write():
                     checked += 1
                 # generative transpose, input-stationary: one flat [cin, K*cout] GEMM operand
                 wt = _mfma_total(cin * _cout_pad(K * cout), cin) if _mfma_ok(cin, K * cout) else 0
+                if wt and cin % 32 == 0 and cin <= 256:                     # dense products: + two scaled fp16 planes + 1/scale per column
+                    wt += cin * _cout_pad(K * cout) + _cout_pad(K * cout)
                 assert L.pcc_convt_packed_elems(K, cin, cout) == wt, (K, cin, cout)
                 if wt > 0:
                     assert L.pcc_convt_pack_weights(ptr, K, cin, cout, ptr, wt - 1, None) == EWS

@@ -308,3 +308,42 @@ def test_split_path_accuracy(cin, cout, ks):
     assert_close(got_split, want64, what="split path vs float64")
     assert not np.array_equal(got_split, got_fp32) or cin < 32   # the two paths really are different kernels
 
+
+
+@pytest.mark.parametrize("spread", ["normal", "rows", "elements", "weights"])
+def test_dense_products_accuracy(spread):
+    """Dense products of the generative transposed convolutions in scaled fp16 pairs (three MFMA terms, `k_gemm_h2`): error
+    against a float64 evaluation at the level of the fp32 accumulation itself -- not above the six-term bf16 form's by more
+    than 3x, and below 4e-6 of the row's largest output -- for plain data and for rows / elements / weights whose
+    magnitudes spread over e^+-12 (the scales are per feature row and per weight column)."""
+    from unified_point_cloud_compression_amd import sparse as S, lib as L
+    rng = np.random.default_rng(5)
+    n_rows, cin, ncol = 4096 + 77, 128, 2048 + 64                              # 33 row tiles (the last one ragged), 17 column blocks (the last one half)
+    x = rng.standard_normal((n_rows, cin)).astype(np.float32)
+    w = (rng.standard_normal((cin, ncol)) / np.sqrt(cin)).astype(np.float32)
+    if spread == "rows":
+        x = (np.maximum(x, 0) * np.exp(rng.standard_normal((n_rows, 1)) * 4)).astype(np.float32)
+        x[5] = 0.0                                                           # an all-zero row
+    elif spread == "elements":
+        x = (x * np.exp(rng.standard_normal(x.shape) * 4)).astype(np.float32)
+    elif spread == "weights":
+        w = (w * np.exp(rng.standard_normal(w.shape) * 3)).astype(np.float32)
+        w[:, 7] = 0.0
+    want = x.astype(np.float64) @ w.astype(np.float64)
+    K, cout = 8, ncol // 8                                                     # [cin, K*cout] flat operand of a k2-s2 transposed conv
+    W = torch.nn.Parameter(t(np.ascontiguousarray(w.reshape(cin, K, cout).transpose(1, 0, 2))))
+    first = torch.arange(0, n_rows * K + 1, dtype=torch.int32, device=dev())   # one pair per output row: T itself comes back
+    pair_ids = torch.arange(0, n_rows * K, dtype=torch.int32, device=dev())
+    res = {}
+    for name, env in (("h", 1), ("bf", 0)):
+        L.call("pcc_set_gemm_h", env)
+        try:
+            pk = S.PackedConv(True).get(W)
+            got = S.convt_forward_csr(t(x), pk, None, K, cin, cout, (first, pair_ids), n_rows * K)
+        finally:
+            L.call("pcc_set_gemm_h", 1)
+        res[name] = n(got).reshape(n_rows, ncol).astype(np.float64)
+    scale = np.abs(want).max(1, keepdims=True) + 1e-300
+    err = {k: (np.abs(v - want) / scale).max() for k, v in res.items()}
+    assert err["h"] <= 4e-6, err
+    assert err["h"] <= 3 * err["bf"] + 1e-7, err

@@ -20,21 +20,23 @@ calls = json.load(open(sys.argv[2]))
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
 # convolution launches of the family: MODE_CONV instantiations only (the GDN / IGDN modes of the same kernel are not calls of
 # the list), and only the calls that take the MFMA path (thin heads with <= 4 output channels run VALU kernels)
-fam = [r for r in rows if re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>|k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0>|k_conv_wave16|k_gemm_bf<\d+, \d+, \d+, \d+, 0>",
+fam = [r for r in rows if re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>|k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0>|k_conv_wave16|k_gemm_bf<\d+, \d+, \d+, \d+, 0>|k_gemm_bf2<\d+>|k_gemm_h2<\d+>",
                                  r["Kernel_Name"])]
 calls = [c for c in calls if c["cout"] > 4 and (c["cin"] in (4, 8, 16) or c["cin"] % 32 == 0)]
 assert len(fam) >= len(calls), (len(fam), len(calls))
 fam = fam[-len(calls):]
 print("# one encode+decode step of bench.py's frame (tools/layer_report.py under rocprofv3 --kernel-trace); K < 0: generative")
 print("# transposed convolution (GEMM half; its gather-sum is not an MFMA kernel).  peak: fp32-input MFMA 157.3 TFLOP/s; split")
-print("# path (k_conv_mfma_bf: 6 bf16 MFMA terms per fp32 product) 2500 / 6 = 416.7 TFLOP/s of algorithmic FLOPs.")
+print("# path (k_conv_mfma_bf / k_gemm_bf2: 6 bf16 MFMA terms per fp32 product) 2500 / 6 = 416.7 TFLOP/s of algorithmic FLOPs; dense")
+print("# products in scaled fp16 pairs (k_gemm_h2: 3 MFMA terms) 2500 / 3 = 833.3.  The chip holds ~1.3-1.5 GHz of its 2.4 GHz on")
+print("# these kernels (DESIGN.md section 8), so 0.55-0.6 of these peaks is a saturated matrix pipe.")
 print(f"{'#':>2s} {'K':>4s} {'cin':>4s} {'cout':>4s} {'n_out':>9s} {'pairs':>10s} {'GFLOP':>8s} {'kernel ms':>9s} {'TFLOP/s':>8s} {'of peak':>7s}  kernel")
 tot_f = tot_t = 0.0
 by = {}
 for i, (c, r) in enumerate(zip(calls, fam)):
     ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
-    peak = 416.7 if "_bf" in name else 157.3
+    peak = 833.3 if "_h2" in name else (416.7 if "_bf" in name else 157.3)
     tf = c["gflop"] / ms
     print(f"{i:2d} {c['K']:4d} {c['cin']:4d} {c['cout']:4d} {c['n_out']:9d} {c['pairs']:10d} {c['gflop']:8.1f} {ms:9.3f} {tf:8.1f} {tf / peak:7.2f}  {name}")
     tot_f += c["gflop"]

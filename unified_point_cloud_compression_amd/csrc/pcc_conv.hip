@@ -46,6 +46,9 @@ struct ConvArgs {
   int ksplit = 1;                       // split path, map mode: the (offset, channel-block) reduction cut over ksplit workgroups
   float* part = nullptr;                //   partial tiles [ksplit][n_out][cout], summed in fixed order by k_splitk_reduce
   int dbg = 0;                          // diagnostics (env PCC_DBG): 1 = no output stores, 2 = no MFMA phase, 4 = no staging loads
+  bool wh_ok = false;                   // dense products: the pack carries scaled fp16 planes + column scales (split_planes_h)
+  const unsigned char* feath = nullptr; //   scaled fp16 planes of feat, [n_in][cin/32][2][32] (k_feat_split_h)
+  const float* frow_inv = nullptr;      //   and 1 / (power-of-two scale) of every feature row
   int cin, cout, cout_pad;
   int cb_log2;            // log2(CB), CB = min(cin, 32)
   int ppo;                // pieces per offset = cin / CB
@@ -441,6 +444,98 @@ __global__ void k_feat_split(const float* __restrict__ x, long long pairs, int c
   d[0] = h; d[16] = m; d[32] = l;
 }
 
+// ---- scaled fp16 pairs (dense products of the generative transposed convolutions) ----------------------------------
+// T = X W with every fp32 operand written as s^-1 (h + l): s a power of two that brings the row's (X) or column's (W)
+// largest magnitude into [2^14, 2^15), h = fp16(s x), l = fp16(s x - h).  h + l carries >= 22 significant bits of every
+// element within 2^-18 of its row / column maximum (smaller ones lose bits they could not contribute to an fp32 sum anyway),
+// and the three products l*h, h*l, h*h (fp32 accumulate, v_mfma_f32_32x32x16_f16) leave out only l*l < 2^-22 of a term: the
+// error stays at the level of the fp32 accumulation itself (tests/test_gpu_map_conv.py::test_dense_products_accuracy), at
+// HALF the matrix instructions of the six-term bf16 form and 2/3 of its operand bytes.  Row scales factor out of a dense
+// product (one input row per output row) but not out of a gathered convolution, which is why only the dense products take
+// this form.  The kernels are bound by energy, not by issue slots: the chip holds ~1.3 GHz on them (GRBM_GUI_ACTIVE / 8 /
+// wall), and every phase's cost adds up whether or not it overlaps, so fewer MFMAs is what pays.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float pow2_scale_exp(float mx, int& e) {      // s = 2^(14 - e), e = floor(log2 mx) (0 for mx = 0)
+  e = mx > 0.f ? ilogbf(mx) : 0;
+  e = e < -100 ? -100 : (e > 120 ? 120 : e);
+  return ldexpf(1.f, 14 - e);
+}
+__device__ __forceinline__ void h_split4(const float4 v, float s, f16x4& h, f16x4& l) {
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = (_Float16)x[i];
+    l[i] = (_Float16)(x[i] - (float)h[i]);
+  }
+}
+
+// fp32 packed GEMM image [piece][cout_pad][32] -> fp16 planes [piece][cout_pad][2][32] scaled per column, and 1/scale per column
+__global__ void k_split_packed_h(const float* __restrict__ src, int ppo, int cout_pad, unsigned char* __restrict__ dst,
+                                 float* __restrict__ cinv) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= cout_pad) return;
+  float mx = 0.f;
+  for (int pc = 0; pc < ppo; ++pc) {
+    const float4* r = reinterpret_cast<const float4*>(src + ((size_t)pc * cout_pad + col) * 32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 v = r[q];
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+  }
+  int e;
+  const float sc = pow2_scale_exp(mx, e);
+  for (int pc = 0; pc < ppo; ++pc) {
+    const float4* r = reinterpret_cast<const float4*>(src + ((size_t)pc * cout_pad + col) * 32);
+    unsigned char* d = dst + ((size_t)pc * cout_pad + col) * 128;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      f16x4 h, l;
+      h_split4(r[q], sc, h, l);
+      *reinterpret_cast<f16x4*>(d + q * 8) = h;
+      *reinterpret_cast<f16x4*>(d + 64 + q * 8) = l;
+    }
+  }
+  cinv[col] = ldexpf(1.f, e - 14);
+}
+
+// feature rows fp32 [n][c] -> fp16 planes [n][c/32][2][32] scaled per row, and 1/scale per row.  G = 2^g_log2 lanes per row.
+__global__ void __launch_bounds__(256) k_feat_split_h(const float* __restrict__ x, long long n, int cin, int g_log2,
+                                                      unsigned char* __restrict__ dst, float* __restrict__ rinv) {
+  const int lane = threadIdx.x & 63;
+  const int G = 1 << g_log2, lg = lane & (G - 1);
+  const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 >> g_log2) + (lane >> g_log2);
+  const bool live = row < n;
+  const int c4 = cin >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x) + (live ? row : 0) * c4;
+  float4 v[2];
+  float mx = 0.f;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int q = lg + it * G;
+    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && q < c4) v[it] = xr[q];
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[it].x), fabsf(v[it].y)), fmaxf(fabsf(v[it].z), fabsf(v[it].w))));
+  }
+  for (int d = G >> 1; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+  int e;
+  const float sc = pow2_scale_exp(mx, e);
+  if (!live) return;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int q = lg + it * G;
+    if (q >= c4) continue;
+    f16x4 h, l;
+    h_split4(v[it], sc, h, l);
+    unsigned char* d = dst + ((size_t)row * (cin >> 5) + (q >> 3)) * 128 + (q & 7) * 8;
+    *reinterpret_cast<f16x4*>(d) = h;
+    *reinterpret_cast<f16x4*>(d + 64) = l;
+  }
+  if (lg == 0) rinv[row] = ldexpf(1.f, e - 14);
+}
+
 // Grow-only device scratch of the library (per device; stream-ordered reuse on the caller's stream): the bf16 planes of
 // the current convolution's input.  The only memory libpcc_hip owns.
 static void* g_scratch[64];
@@ -465,6 +560,22 @@ static int make_planes(ConvArgs& a, bool take_abs, hipStream_t s) {
   k_feat_split<<<(unsigned)pcc_cdiv(pairs, 256), 256, 0, s>>>(a.feat, pairs, a.cin / 2, take_abs ? 1 : 0, (unsigned*)p);
   PCC_LAUNCH_CHECK();
   a.featb = (const unsigned char*)p;
+  return PCC_OK;
+}
+
+static int make_planes_h(ConvArgs& a, hipStream_t s) {
+  PCC_REQUIRE(a.cin % 32 == 0 && a.cin <= 512, "dense products: cin=%d (needs a multiple of 32 up to 512)", a.cin);
+  void* p = nullptr;
+  const size_t plane_bytes = pcc_align_up((size_t)a.n_in * a.cin * 4);
+  PCC_TRY(lib_scratch(plane_bytes + pcc_align_up((size_t)a.n_in * 4), &p));
+  int g = 0;
+  while ((1 << g) < a.cin / 4 && g < 6) ++g;
+  const long long rows_per_block = 4ll * (64 >> g);
+  k_feat_split_h<<<(unsigned)pcc_cdiv(a.n_in, rows_per_block), 256, 0, s>>>(a.feat, a.n_in, a.cin, g, (unsigned char*)p,
+                                                                         (float*)((char*)p + plane_bytes));
+  PCC_LAUNCH_CHECK();
+  a.feath = (const unsigned char*)p;
+  a.frow_inv = (const float*)((char*)p + plane_bytes);
   return PCC_OK;
 }
 
@@ -867,9 +978,11 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {           // smallest terms first (same order as k_conv_mfma_bf: identical results)
+          if (!(a.dbg & 8)) {                  // (timing experiment: three of the six terms)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
@@ -909,6 +1022,320 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
         if (r >= npos) continue;
         obase[(size_t)r * ncol + (unsigned)(wn * 64 + j * 32 + r31)] = acc[i][j][e];
       }
+  }
+}
+
+// The dense products in scaled fp16 pairs (see k_feat_split_h): the structure of k_gemm_bf2 with two planes per operand
+// (8 units of 16 bytes per 32-channel piece, LDS rows of 9 units: 9 is odd, so a fragment read's 16 rows fall on 16 different
+// bank quads), three MFMA terms, and the row and column scales applied to the accumulators on the way out.
+template <int NCH>
+__global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
+  constexpr int BM = 128, BN = 128, LDU = 9;
+  constexpr unsigned ROWB = NCH * 128u;                // bytes of a feature row's planes
+  __shared__ __attribute__((aligned(16))) uint4 As[BM * LDU];
+  __shared__ __attribute__((aligned(16))) uint4 Bs[BN * LDU];
+  __shared__ __attribute__((aligned(16))) float rs[BM];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cpx = gridDim.x >> 3;
+  const int wid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  const int gy = a.cout_pad / BN;
+  int tile_id, colblock;
+  if (gy > 8) {
+    const int g = wid / (8 * gy), rem = wid - g * 8 * gy;
+    colblock = (rem >> 3) * BN;
+    tile_id = g * 8 + (rem & 7);
+  } else {
+    tile_id = wid / gy;
+    colblock = (wid - tile_id * gy) * BN;
+  }
+  const long long p0 = (long long)tile_id * BM;
+  if (p0 >= a.n_out) return;
+  const int npos = (int)min((long long)BM, a.n_out - p0);
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(a.feath) + (size_t)p0 * ROWB, (short)0, (int)((unsigned)npos * ROWB), 0x00020000);
+  const float* const wplanes = a.wp + a.wp_elems + bf_plane_elems(a.wp_elems);      // fp16 planes behind the bf16 planes
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(wplanes) + (size_t)colblock * 128u;
+  const float* const cinv = wplanes + a.wp_elems;                                    // [cout_pad] column 1/scale
+  const unsigned b_stride = (unsigned)a.cout_pad * 128u;
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(wb), (short)0, (int)((NCH - 1) * b_stride + BN * 128u), 0x00020000);
+
+  unsigned vA[4], ld[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned u = (unsigned)(j * 256 + tid), row = u >> 3, wu = u & 7u;
+    vA[j] = row * ROWB + wu * 16u;
+    ld[j] = row * LDU + wu;
+  }
+  const unsigned vB = (unsigned)tid * 16u;
+
+  uint4 av[4], bv[4];
+  auto issue = [&](int cbi) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (a.dbg & 4) ? BUF_OOB : vA[j] + (unsigned)cbi * 128u, 0, 0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (a.dbg & 4) ? BUF_OOB : vB, (int)((unsigned)cbi * b_stride + (unsigned)j * 4096u), 0));
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm = w >> 1, wn = w & 1;
+  const int half = lane >> 5, r31 = lane & 31;
+  const unsigned fa = (unsigned)((wm * 64 + r31) * LDU + half), fb = (unsigned)((wn * 64 + r31) * LDU + half);
+
+  issue(0);
+  if (tid < BM) rs[tid] = tid < npos ? a.frow_inv[p0 + tid] : 0.f;
+  float cs[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) cs[j] = cinv[colblock + wn * 64 + j * 32 + r31];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    __syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < 4; ++j) As[ld[j]] = av[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bs[ld[j]] = bv[j];
+    __syncthreads();
+    if (c + 1 < NCH) issue(c + 1);            // next chunk's global loads fly during this chunk's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.dbg & 2) continue;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 af[2][2], bf[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[p][i] = __builtin_bit_cast(f16x8, As[fa + i * 32 * LDU + p * 4 + ks * 2]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[p][j] = __builtin_bit_cast(f16x8, Bs[fb + j * 32 * LDU + p * 4 + ks * 2]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {           // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  if (a.dbg & 1) { if (acc[0][0][0] != 12345.678f) return; }
+
+  // ---- stores: element e of acc[i][j] is row wm*64 + i*32 + (e&3) + 8*(e>>2) + 4*half, column wn*64 + j*32 + r31 of the tile
+  const unsigned ncol = (unsigned)a.cout;
+  float* const obase = a.out + (size_t)p0 * ncol + colblock;
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+      obase, (short)0, (int)(((unsigned)(npos - 1) * ncol + min((unsigned)BN, ncol - (unsigned)colblock)) * 4u), 0x00020000);
+  const unsigned vO = ((unsigned)(wm * 64 + 4 * half) * ncol + (unsigned)(wn * 64 + r31)) * 4u;
+  const bool full = npos == BM && (unsigned)colblock + BN <= ncol;
+  const int row_lim = npos - wm * 64 - 4 * half;
+  const int col_lim = (int)ncol - colblock - wn * 64 - r31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const float4 r4 = *reinterpret_cast<const float4*>(&rs[wm * 64 + i * 32 + 8 * e4 + 4 * half]);
+      const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+      for (int e1 = 0; e1 < 4; ++e1) {
+        const int e = e4 * 4 + e1;
+        const int rrow = i * 32 + e1 + 8 * e4;
+        const unsigned so = (unsigned)rrow * ncol * 4u;      // scalar
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float v = acc[i][j][e] * (rr[e1] * cs[j]);
+          if (full) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
+          } else {                                           // last row tile / column block: invalid elements go out of range
+            const unsigned off = (rrow < row_lim && j * 32 < col_lim) ? vO + (unsigned)j * 128u + so : BUF_OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, off, 0, 0);
+          }
+        }
+      }
+    }
+}
+
+// Persistent form of k_gemm_bf2: a workgroup walks a strided sequence of tiles as one chunk stream.  With one tile per
+// workgroup the three resident workgroups of a CU ran in step -- all loading, then all multiplying, then all storing -- and
+// the phases added up (PCC_DBG: 0.48 skeleton + 0.25 loads + 0.81 MFMA + 0.59 stores = 2.3 ms on the level-2 products).
+// Here a tile's 64 stores per lane are issued and left to drain while the next tile's first chunk (already in flight when
+// the last MFMAs ran) is staged and multiplied.  Work ids are dealt in contiguous ranges per XCD, in the order of the grid
+// of k_gemm_bf2 (groups of 8 row tiles per column block), so the weights' L2 reuse is the same.
+template <int NCH>
+__global__ void __launch_bounds__(256, 3) k_gemm_bf2p(ConvArgs a) {
+  constexpr int BM = 128, BN = 128, LDU = 13;
+  constexpr unsigned ROWB = NCH * 192u;
+  __shared__ __attribute__((aligned(16))) uint4 As[BM * LDU];
+  __shared__ __attribute__((aligned(16))) uint4 Bs[BN * LDU];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int gy = a.cout_pad / BN;
+  const long long n_tiles = (a.n_out + BM - 1) / BM;
+  const bool groups = gy > 8;
+  const long long total = (groups ? (n_tiles + 7) / 8 * 8 : n_tiles) * gy;
+  const long long per = (total + 7) / 8;                                  // ids of one XCD: [lo, hi)
+  const long long lo = (long long)(blockIdx.x & 7) * per, hi = min(total, lo + per);
+  const int step = gridDim.x >> 3;
+  long long id = lo + (blockIdx.x >> 3);
+
+  unsigned vA[6], ld[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const unsigned u = (unsigned)(j * 256 + tid), row = u / 12u, wu = u - row * 12u;
+    vA[j] = row * ROWB + wu * 16u;
+    ld[j] = row * LDU + wu;
+  }
+  const unsigned vB = (unsigned)tid * 16u;
+  const unsigned b_stride = (unsigned)a.cout_pad * 192u;
+  const int wm = w >> 1, wn = w & 1;
+  const int half = lane >> 5, r31 = lane & 31;
+  const unsigned fa = (unsigned)((wm * 64 + r31) * LDU + half), fb = (unsigned)((wn * 64 + r31) * LDU + half);
+  const unsigned ncol = (unsigned)a.cout;
+  const unsigned vO = ((unsigned)(wm * 64 + 4 * half) * ncol + (unsigned)(wn * 64 + r31)) * 4u;
+  const unsigned char* const wplanes = reinterpret_cast<const unsigned char*>(a.wp + a.wp_elems);
+
+  // tile of a work id (scalar): row tile, column block; row tiles past the end (group padding) are skipped
+  auto decode = [&](long long wid, long long& p0, int& colblock) {
+    long long tile_id;
+    if (groups) {
+      const long long g = wid / (8 * gy), rem = wid - g * 8 * gy;
+      colblock = (int)(rem >> 3) * BN;
+      tile_id = g * 8 + (rem & 7);
+    } else {
+      tile_id = wid / gy;
+      colblock = (int)(wid - tile_id * gy) * BN;
+    }
+    p0 = tile_id * BM;
+  };
+  auto next_valid = [&](long long from, long long& p0, int& colblock) {     // first id >= from (stride `step`) with rows
+    for (long long i = from; i < hi; i += step) {
+      decode(i, p0, colblock);
+      if (p0 < a.n_out) return i;
+    }
+    return hi;
+  };
+
+  uint4 av[6], bv[6];
+  auto issue = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int cbi) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vA[j] + (unsigned)cbi * 192u, 0, 0));
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vB, (int)((unsigned)cbi * b_stride + (unsigned)j * 4096u), 0));
+  };
+  auto rsrc_a = [&](long long p0) {
+    const int npos = (int)min((long long)BM, a.n_out - p0);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.featb) + (size_t)p0 * ROWB, (short)0,
+                                             (int)((unsigned)npos * ROWB), 0x00020000);
+  };
+  auto rsrc_b = [&](int colblock) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wplanes) + (size_t)colblock * 192u, (short)0,
+                                             (int)((NCH - 1) * b_stride + BN * 192u), 0x00020000);
+  };
+
+  long long p0;
+  int colblock;
+  id = next_valid(id, p0, colblock);
+  if (id >= hi) return;
+  {
+    const __amdgpu_buffer_rsrc_t rsA = rsrc_a(p0), rsB = rsrc_b(colblock);
+    issue(rsA, rsB, 0);
+  }
+  while (id < hi) {
+    const __amdgpu_buffer_rsrc_t rsA = rsrc_a(p0), rsB = rsrc_b(colblock);
+    long long p0n = 0;
+    int colblockn = 0;
+    const long long idn = next_valid(id + step, p0n, colblockn);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      __syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+      for (int j = 0; j < 6; ++j) As[ld[j]] = av[j];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) Bs[ld[j]] = bv[j];
+      __syncthreads();
+      if (c + 1 < NCH) issue(rsA, rsB, c + 1);            // next chunk's global loads fly during this chunk's MFMAs
+      else if (idn < hi) {                                // ... or the next tile's first chunk
+        const __amdgpu_buffer_rsrc_t rsAn = rsrc_a(p0n), rsBn = rsrc_b(colblockn);
+        issue(rsAn, rsBn, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[3][2], bf[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[p][i] = __builtin_bit_cast(bf16x8, As[fa + i * 32 * LDU + p * 4 + ks * 2]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[p][j] = __builtin_bit_cast(bf16x8, Bs[fb + j * 32 * LDU + p * 4 + ks * 2]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {           // smallest terms first (same order as k_conv_mfma_bf: identical results)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+    // ---- stores (left to drain under the next tile)
+    {
+      const int npos = (int)min((long long)BM, a.n_out - p0);
+      float* const obase = a.out + (size_t)p0 * ncol + colblock;
+      const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+          obase, (short)0, (int)(((unsigned)(npos - 1) * ncol + min((unsigned)BN, ncol - (unsigned)colblock)) * 4u), 0x00020000);
+      if (npos == BM && (unsigned)colblock + BN <= ncol) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const unsigned so = (unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * ncol * 4u;      // scalar
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float v = acc[i][j][e];
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
+            }
+          }
+      } else {                                            // last row tile / last column block: invalid elements go out of range
+        const int row_lim = npos - wm * 64 - 4 * half;
+        const int col_lim = (int)ncol - colblock - wn * 64 - r31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int rr = i * 32 + (e & 3) + 8 * (e >> 2);
+            const unsigned so = (unsigned)rr * ncol * 4u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float v = acc[i][j][e];
+              const unsigned off = (rr < row_lim && j * 32 < col_lim) ? vO + (unsigned)j * 128u + so : BUF_OOB;
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, off, 0, 0);
+            }
+          }
+      }
+    }
+    id = idn; p0 = p0n; colblock = colblockn;
   }
 }
 
@@ -1754,6 +2181,8 @@ static bool g_mfma_buf = getenv("PCC_MFMA_BUF") ? atoi(getenv("PCC_MFMA_BUF")) !
 // split path (fp32 products as six bf16 MFMA terms, k_conv_mfma_bf); PCC_MFMA_SPLIT=0 selects the fp32-input MFMA kernels
 static bool g_mfma_split = getenv("PCC_MFMA_SPLIT") ? atoi(getenv("PCC_MFMA_SPLIT")) != 0 : true;
 extern "C" int pcc_set_mfma_split(int32_t on) { g_mfma_split = on != 0; return PCC_OK; }
+static bool g_gemm_h = getenv("PCC_GEMM_H") ? atoi(getenv("PCC_GEMM_H")) != 0 : true;   // dense products in scaled fp16 pairs (k_gemm_h2)
+extern "C" int pcc_set_gemm_h(int32_t on) { g_gemm_h = on != 0; return PCC_OK; }
 static bool split_ok(const ConvArgs& a) {
   return g_mfma_split && g_mfma_buf && a.cb_log2 == 5 && a.n_in > 0 && a.n_in * a.cin * 6 <= BUF_MAX_BYTES && a.wp_elems > 0 &&
          bf_plane_elems(a.wp_elems) * 4 <= BUF_MAX_BYTES;
@@ -1779,7 +2208,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 
 static bool g_splitk = getenv("PCC_SPLITK") ? atoi(getenv("PCC_SPLITK")) != 0 : true;
 static bool g_gemm_persistent = getenv("PCC_GEMM_PERSISTENT") ? atoi(getenv("PCC_GEMM_PERSISTENT")) != 0 : false;   // measured slower (2 workgroups per CU): off
-static bool g_gemm2 = getenv("PCC_GEMM2") ? atoi(getenv("PCC_GEMM2")) != 0 : true;
+static int g_gemm2 = getenv("PCC_GEMM2") ? atoi(getenv("PCC_GEMM2")) : 1;       // 0: general kernel, 1: one tile per workgroup, 2: persistent
 static int g_dbg = getenv("PCC_DBG") ? atoi(getenv("PCC_DBG")) : 0;
 
 // persistent GEMM form (identity rows or pair lists; a.featb set): 2 workgroups per CU (the kernel needs ~200 VGPRs)
@@ -1832,6 +2261,23 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
       if (ksplit < 2) ksplit = 1;
     }
   }
+  // dense products of the generative transposed convolutions whose pack carries fp16 planes: three-term fp16 form
+  if (split && g_gemm_h && a.wh_ok && MODE == MODE_CONV && !a.hdr && !a.pair_in && !a.rows && !a.bias && a.act == 0 && ksplit == 1 &&
+      bn == 128 && (tiles(128) * gy >= want || a.feath) && (size_t)128 * a.cout * 4 < (1ull << 31) &&
+      (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8)) {      // (caller's planes: the caller chose the form)
+    if (!a.feath) PCC_TRY(make_planes_h(a, s));
+    a.dbg = g_dbg;
+    const dim3 g2 = grid(128);
+    switch (a.ppo) {
+      case 1: k_gemm_h2<1><<<g2, 256, 0, s>>>(a); break;
+      case 2: k_gemm_h2<2><<<g2, 256, 0, s>>>(a); break;
+      case 4: k_gemm_h2<4><<<g2, 256, 0, s>>>(a); break;
+      case 6: k_gemm_h2<6><<<g2, 256, 0, s>>>(a); break;
+      default: k_gemm_h2<8><<<g2, 256, 0, s>>>(a); break;
+    }
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+  }
   if (split && a.featb) {
     PCC_REQUIRE(ksplit == 1, "launch_mfma: caller planes with a split reduction");
   } else if (split) {
@@ -1853,6 +2299,23 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
       bn == 128 && tiles(128) * gy >= want && (size_t)128 * a.cout * 4 < (1ull << 31)) {
     const dim3 g2 = grid(128);
     bool done = true;
+    if (g_gemm2 == 2) {                                   // persistent: 2 workgroups per CU
+      int dev = 0, cus = 0;
+      PCC_CHECK_HIP(hipGetDevice(&dev));
+      PCC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      unsigned gp = (unsigned)cus * 3u / 8u * 8u;
+      if (gp > g2.x) gp = g2.x;
+      switch (a.ppo) {
+        case 1: k_gemm_bf2p<1><<<gp, 256, 0, s>>>(a); break;
+        case 2: k_gemm_bf2p<2><<<gp, 256, 0, s>>>(a); break;
+        case 4: k_gemm_bf2p<4><<<gp, 256, 0, s>>>(a); break;
+        case 6: k_gemm_bf2p<6><<<gp, 256, 0, s>>>(a); break;
+        case 8: k_gemm_bf2p<8><<<gp, 256, 0, s>>>(a); break;
+        default: done = false;
+      }
+      if (done) { PCC_LAUNCH_CHECK(); return PCC_OK; }
+      done = true;
+    }
     switch (a.ppo) {
       case 1: k_gemm_bf2<1><<<g2, 256, 0, s>>>(a); break;
       case 2: k_gemm_bf2<2><<<g2, 256, 0, s>>>(a); break;
@@ -2544,9 +3007,12 @@ __global__ void k_pack_convt(const float* __restrict__ W, int K, int cin, int co
   out[t] = v;
 }
 
+// dense-product packs (cin a multiple of 32): fp32 image | three bf16 planes | two scaled fp16 planes | 1/scale per column
+static bool convt_has_h(int cin) { return cin % 32 == 0 && cin <= 256; }
 extern "C" int64_t pcc_convt_packed_elems(int32_t K, int32_t cin, int32_t cout) {
   if (K <= 0 || cin <= 0 || cout <= 0 || !mfma_ok(cin, K * cout)) return 0;
-  return mfma_packed_total((int64_t)cin * cout_pad_for(K * cout), cin);
+  const int64_t base = (int64_t)cin * cout_pad_for(K * cout);
+  return mfma_packed_total(base, cin) + (convt_has_h(cin) ? base + cout_pad_for(K * cout) : 0);
 }
 
 extern "C" int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
@@ -2563,7 +3029,14 @@ extern "C" int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, in
   k_pack_convt<<<(unsigned)pcc_cdiv(base, 256), 256, 0, s>>>(W, K, cin, cout, K * cout, cout_pad_for(K * cout),
                                                             cb_log2_for(cin), packed);
   PCC_LAUNCH_CHECK();
-  return split_planes(packed, base, cin, s);
+  PCC_TRY(split_planes(packed, base, cin, s));
+  if (convt_has_h(cin)) {
+    const int cp = cout_pad_for(K * cout);
+    float* const planes = packed + base + bf_plane_elems(base);
+    k_split_packed_h<<<(unsigned)pcc_cdiv(cp, 128), 128, 0, s>>>(packed, cin >> 5, cp, (unsigned char*)planes, planes + base);
+    PCC_LAUNCH_CHECK();
+  }
+  return PCC_OK;
 }
 
 struct GatherArgs {
@@ -2637,6 +3110,7 @@ extern "C" int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, co
   a.n_out = n_in; a.cin = cin; a.cout = K * cout; a.cout_pad = cout_pad_for(K * cout);
   a.n_in = n_in; a.wp_elems = (long long)cin * a.cout_pad;
   a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
+  a.wh_ok = convt_has_h(cin);
   hipEvent_t e0, e1;
   if (g_prof_on) PCC_TRY(prof_event(&e0, s));
   PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));
@@ -2746,6 +3220,7 @@ extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin
   a.n_out = n_in; a.cin = cin; a.cout = K * cout; a.cout_pad = cout_pad_for(K * cout);
   a.n_in = n_in; a.wp_elems = (long long)cin * a.cout_pad;
   a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
+  a.wh_ok = convt_has_h(cin);
   hipEvent_t e0, e1;
   if (g_prof_on) PCC_TRY(prof_event(&e0, s));
   PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));
@@ -2946,8 +3421,17 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
   a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
   a.feat = feat_in; a.n_in = n_in; a.n_out = n_in;
   const bool split = split_ok(a);
+  // the form the one-pass call would take for all rows (so that both give the same bits)
+  const long long t128 = (pcc_cdiv(n_in, 128) + 7) / 8 * 8;
+  const bool use_h = split && g_gemm_h && convt_has_h(cin) && (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8) &&
+                     bn_for(a.cout) == 128 && t128 * (a.cout_pad / 128) >= 512;
   const unsigned char* planes = nullptr;
-  if (split) {                                                           // bf16 planes of every input row, once
+  const float* row_inv = nullptr;
+  if (use_h) {                                                           // planes of every input row, once
+    PCC_TRY(make_planes_h(a, s));
+    planes = a.feath; row_inv = a.frow_inv;
+    a.wh_ok = true;
+  } else if (split) {
     PCC_TRY(make_planes(a, false, s));
     planes = a.featb;
   }
@@ -2968,7 +3452,8 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
     const long long r0 = (long long)c * chunk_rows;
     const long long rows = r0 + chunk_rows < n_in ? chunk_rows : n_in - r0;
     a.feat = feat_in + r0 * cin; a.n_in = rows; a.n_out = rows;
-    a.featb = planes ? planes + (size_t)r0 * cin * 6 : nullptr;
+    if (use_h) { a.feath = planes + (size_t)r0 * cin * 4; a.frow_inv = row_inv + r0; }
+    else a.featb = planes ? planes + (size_t)r0 * cin * 6 : nullptr;
     hipEvent_t e0, e1;
     if (g_prof_on) PCC_TRY(prof_event(&e0, s));
     PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));

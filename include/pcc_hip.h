@@ -175,6 +175,11 @@ size_t pcc_expand_grid_csr_ws_bytes(int64_t n_out);
 int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
                                const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in, int64_t n_in,
                                int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes, void* stream);
+/* the same lists, kernel offsets of the pair ids numbered z fastest (iz + KS*iy + KS*KS*ix) -- for product buffers laid out
+ * [input row][kx][ky][kz][c]: the composite levels gather z-runs of output rows from adjacent memory */
+int pcc_coords_expand_grid_csr_zk(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
+                               const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in, int64_t n_in,
+                               int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes, void* stream);
 /* dense [K][n_out] view of any map (testing / inspection): -1 where no pair */
 int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows, int64_t n_out,
                      int32_t K, int32_t* dense, void* stream);

@@ -553,6 +553,22 @@ static int lib_scratch(size_t bytes, void** out) {
   *out = g_scratch[dev];
   return PCC_OK;
 }
+// a second, small grow-only scratch (tables that live beside the planes of the same call)
+static void* g_scratch_small[64];
+static size_t g_scratch_small_bytes[64];
+static int lib_scratch_small(size_t bytes, void** out) {
+  int dev = 0;
+  PCC_CHECK_HIP(hipGetDevice(&dev));
+  dev &= 63;
+  if (g_scratch_small_bytes[dev] < bytes) {
+    if (g_scratch_small[dev]) { PCC_CHECK_HIP(hipDeviceSynchronize()); PCC_CHECK_HIP(hipFree(g_scratch_small[dev])); g_scratch_small[dev] = nullptr; g_scratch_small_bytes[dev] = 0; }
+    const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    PCC_CHECK_HIP(hipMalloc(&g_scratch_small[dev], want));
+    g_scratch_small_bytes[dev] = want;
+  }
+  *out = g_scratch_small[dev];
+  return PCC_OK;
+}
 static int make_planes(ConvArgs& a, bool take_abs, hipStream_t s) {
   void* p = nullptr;
   PCC_TRY(lib_scratch((size_t)a.n_in * a.cin * 6, &p));
@@ -1162,181 +1178,6 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
         }
       }
     }
-}
-
-// Persistent form of k_gemm_bf2: a workgroup walks a strided sequence of tiles as one chunk stream.  With one tile per
-// workgroup the three resident workgroups of a CU ran in step -- all loading, then all multiplying, then all storing -- and
-// the phases added up (PCC_DBG: 0.48 skeleton + 0.25 loads + 0.81 MFMA + 0.59 stores = 2.3 ms on the level-2 products).
-// Here a tile's 64 stores per lane are issued and left to drain while the next tile's first chunk (already in flight when
-// the last MFMAs ran) is staged and multiplied.  Work ids are dealt in contiguous ranges per XCD, in the order of the grid
-// of k_gemm_bf2 (groups of 8 row tiles per column block), so the weights' L2 reuse is the same.
-template <int NCH>
-__global__ void __launch_bounds__(256, 3) k_gemm_bf2p(ConvArgs a) {
-  constexpr int BM = 128, BN = 128, LDU = 13;
-  constexpr unsigned ROWB = NCH * 192u;
-  __shared__ __attribute__((aligned(16))) uint4 As[BM * LDU];
-  __shared__ __attribute__((aligned(16))) uint4 Bs[BN * LDU];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int gy = a.cout_pad / BN;
-  const long long n_tiles = (a.n_out + BM - 1) / BM;
-  const bool groups = gy > 8;
-  const long long total = (groups ? (n_tiles + 7) / 8 * 8 : n_tiles) * gy;
-  const long long per = (total + 7) / 8;                                  // ids of one XCD: [lo, hi)
-  const long long lo = (long long)(blockIdx.x & 7) * per, hi = min(total, lo + per);
-  const int step = gridDim.x >> 3;
-  long long id = lo + (blockIdx.x >> 3);
-
-  unsigned vA[6], ld[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const unsigned u = (unsigned)(j * 256 + tid), row = u / 12u, wu = u - row * 12u;
-    vA[j] = row * ROWB + wu * 16u;
-    ld[j] = row * LDU + wu;
-  }
-  const unsigned vB = (unsigned)tid * 16u;
-  const unsigned b_stride = (unsigned)a.cout_pad * 192u;
-  const int wm = w >> 1, wn = w & 1;
-  const int half = lane >> 5, r31 = lane & 31;
-  const unsigned fa = (unsigned)((wm * 64 + r31) * LDU + half), fb = (unsigned)((wn * 64 + r31) * LDU + half);
-  const unsigned ncol = (unsigned)a.cout;
-  const unsigned vO = ((unsigned)(wm * 64 + 4 * half) * ncol + (unsigned)(wn * 64 + r31)) * 4u;
-  const unsigned char* const wplanes = reinterpret_cast<const unsigned char*>(a.wp + a.wp_elems);
-
-  // tile of a work id (scalar): row tile, column block; row tiles past the end (group padding) are skipped
-  auto decode = [&](long long wid, long long& p0, int& colblock) {
-    long long tile_id;
-    if (groups) {
-      const long long g = wid / (8 * gy), rem = wid - g * 8 * gy;
-      colblock = (int)(rem >> 3) * BN;
-      tile_id = g * 8 + (rem & 7);
-    } else {
-      tile_id = wid / gy;
-      colblock = (int)(wid - tile_id * gy) * BN;
-    }
-    p0 = tile_id * BM;
-  };
-  auto next_valid = [&](long long from, long long& p0, int& colblock) {     // first id >= from (stride `step`) with rows
-    for (long long i = from; i < hi; i += step) {
-      decode(i, p0, colblock);
-      if (p0 < a.n_out) return i;
-    }
-    return hi;
-  };
-
-  uint4 av[6], bv[6];
-  auto issue = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int cbi) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vA[j] + (unsigned)cbi * 192u, 0, 0));
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vB, (int)((unsigned)cbi * b_stride + (unsigned)j * 4096u), 0));
-  };
-  auto rsrc_a = [&](long long p0) {
-    const int npos = (int)min((long long)BM, a.n_out - p0);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.featb) + (size_t)p0 * ROWB, (short)0,
-                                             (int)((unsigned)npos * ROWB), 0x00020000);
-  };
-  auto rsrc_b = [&](int colblock) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wplanes) + (size_t)colblock * 192u, (short)0,
-                                             (int)((NCH - 1) * b_stride + BN * 192u), 0x00020000);
-  };
-
-  long long p0;
-  int colblock;
-  id = next_valid(id, p0, colblock);
-  if (id >= hi) return;
-  {
-    const __amdgpu_buffer_rsrc_t rsA = rsrc_a(p0), rsB = rsrc_b(colblock);
-    issue(rsA, rsB, 0);
-  }
-  while (id < hi) {
-    const __amdgpu_buffer_rsrc_t rsA = rsrc_a(p0), rsB = rsrc_b(colblock);
-    long long p0n = 0;
-    int colblockn = 0;
-    const long long idn = next_valid(id + step, p0n, colblockn);
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      __syncthreads();   // previous chunk's fragment reads are done
-#pragma unroll
-      for (int j = 0; j < 6; ++j) As[ld[j]] = av[j];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) Bs[ld[j]] = bv[j];
-      __syncthreads();
-      if (c + 1 < NCH) issue(rsA, rsB, c + 1);            // next chunk's global loads fly during this chunk's MFMAs
-      else if (idn < hi) {                                // ... or the next tile's first chunk
-        const __amdgpu_buffer_rsrc_t rsAn = rsrc_a(p0n), rsBn = rsrc_b(colblockn);
-        issue(rsAn, rsBn, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[3][2], bf[3][2];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) af[p][i] = __builtin_bit_cast(bf16x8, As[fa + i * 32 * LDU + p * 4 + ks * 2]);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) bf[p][j] = __builtin_bit_cast(bf16x8, Bs[fb + j * 32 * LDU + p * 4 + ks * 2]);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {           // smallest terms first (same order as k_conv_mfma_bf: identical results)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
-          }
-      }
-    }
-    // ---- stores (left to drain under the next tile)
-    {
-      const int npos = (int)min((long long)BM, a.n_out - p0);
-      float* const obase = a.out + (size_t)p0 * ncol + colblock;
-      const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
-          obase, (short)0, (int)(((unsigned)(npos - 1) * ncol + min((unsigned)BN, ncol - (unsigned)colblock)) * 4u), 0x00020000);
-      if (npos == BM && (unsigned)colblock + BN <= ncol) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const unsigned so = (unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * ncol * 4u;      // scalar
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const float v = acc[i][j][e];
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
-            }
-          }
-      } else {                                            // last row tile / last column block: invalid elements go out of range
-        const int row_lim = npos - wm * 64 - 4 * half;
-        const int col_lim = (int)ncol - colblock - wn * 64 - r31;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int rr = i * 32 + (e & 3) + 8 * (e >> 2);
-            const unsigned so = (unsigned)rr * ncol * 4u;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const float v = acc[i][j][e];
-              const unsigned off = (rr < row_lim && j * 32 < col_lim) ? vO + (unsigned)j * 128u + so : BUF_OOB;
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, off, 0, 0);
-            }
-          }
-      }
-    }
-    id = idn; p0 = p0n; colblock = colblockn;
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2208,7 +2049,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 
 static bool g_splitk = getenv("PCC_SPLITK") ? atoi(getenv("PCC_SPLITK")) != 0 : true;
 static bool g_gemm_persistent = getenv("PCC_GEMM_PERSISTENT") ? atoi(getenv("PCC_GEMM_PERSISTENT")) != 0 : false;   // measured slower (2 workgroups per CU): off
-static int g_gemm2 = getenv("PCC_GEMM2") ? atoi(getenv("PCC_GEMM2")) : 1;       // 0: general kernel, 1: one tile per workgroup, 2: persistent
+static int g_gemm2 = getenv("PCC_GEMM2") ? atoi(getenv("PCC_GEMM2")) : 1;       // 0: general kernel, 1: stripped dense-GEMM kernel
 static int g_dbg = getenv("PCC_DBG") ? atoi(getenv("PCC_DBG")) : 0;
 
 // persistent GEMM form (identity rows or pair lists; a.featb set): 2 workgroups per CU (the kernel needs ~200 VGPRs)
@@ -2299,23 +2140,6 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
       bn == 128 && tiles(128) * gy >= want && (size_t)128 * a.cout * 4 < (1ull << 31)) {
     const dim3 g2 = grid(128);
     bool done = true;
-    if (g_gemm2 == 2) {                                   // persistent: 2 workgroups per CU
-      int dev = 0, cus = 0;
-      PCC_CHECK_HIP(hipGetDevice(&dev));
-      PCC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      unsigned gp = (unsigned)cus * 3u / 8u * 8u;
-      if (gp > g2.x) gp = g2.x;
-      switch (a.ppo) {
-        case 1: k_gemm_bf2p<1><<<gp, 256, 0, s>>>(a); break;
-        case 2: k_gemm_bf2p<2><<<gp, 256, 0, s>>>(a); break;
-        case 4: k_gemm_bf2p<4><<<gp, 256, 0, s>>>(a); break;
-        case 6: k_gemm_bf2p<6><<<gp, 256, 0, s>>>(a); break;
-        case 8: k_gemm_bf2p<8><<<gp, 256, 0, s>>>(a); break;
-        default: done = false;
-      }
-      if (done) { PCC_LAUNCH_CHECK(); return PCC_OK; }
-      done = true;
-    }
     switch (a.ppo) {
       case 1: k_gemm_bf2<1><<<g2, 256, 0, s>>>(a); break;
       case 2: k_gemm_bf2<2><<<g2, 256, 0, s>>>(a); break;
@@ -3135,17 +2959,32 @@ extern "C" int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, co
 
 // CSR form of the generative transposed convolution: out[o] = act(bias + sum_{t in [first[o], first[o+1])} T[pair_ids[t]])
 // (pair lists from pcc_coords_expand_csr; outputs are written in canonical row order, no `rows` indirection).
+// Subset sums of the per-neighbour constants: tab[j][m][c] = sum over the set bits b of m (ascending) of ex_bias[7j + b][c].
+// A row's 27-bit neighbour mask then costs four table rows instead of a loop over its ~22 set bits (the loop was a third of the
+// gather-sum's VALU instructions, and the kernel is VALU-bound: 6.6e8 wave instructions on the last level, SQ counters).
+__global__ void k_presence_tables(const float* __restrict__ ex_bias, int cout, float* __restrict__ tab) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 512 * cout) return;
+  const int c = t % cout, m = (t / cout) & 127, j = t / (128 * cout);
+  float sum = 0.f;
+  for (int b = 0; b < 7; ++b) {
+    const int k = 7 * j + b;
+    if (k < 27 && ((m >> b) & 1)) sum += ex_bias[k * cout + c];
+  }
+  tab[t] = sum;
+}
+
 struct GatherCsrArgs {
   const float* T; const float* bias; const int* first; const int* pair_ids;
   float* out; long long n_out; int cout, act; float slope; int lpr_log2;
   const int* ex_nbr; const float* ex_bias; int ex_K;      // optional: + sum over the existing neighbours k of ex_bias[k]
+  const float* ex_tab;                                    //   as subset-sum tables [4][128][cout] over 7+7+7+6 neighbour bits (k_presence_tables)
   PccGrid ex_grid; const long long* out_keys;             //   presence flags from a [K][n_out] table (ex_nbr) or the set's grid index
 };
 
-template <int VEC>
+template <int VEC, int JB>
 __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
   typedef typename ThinVec<VEC>::T VT;
-  constexpr int JB = 8;
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << a.lpr_log2;
   const int rpw = 64 >> a.lpr_log2;
@@ -3186,10 +3025,13 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
 #pragma unroll
       for (int u = 0; u < JB; ++u) thin_acc(acc, x[u]);     // fixed order: pair id ascending
     }
-    for (unsigned long long pr = a.ex_bias ? present : 0ull; pr;) {          // neighbour k exists -> its constant contribution, ascending k
-      const int k = __ffsll((long long)pr) - 1;
-      pr &= pr - 1;
-      thin_acc(acc, reinterpret_cast<const VT*>(a.ex_bias + (long long)k * a.cout)[cv]);
+    if (a.ex_tab) {                                                        // constants of the existing neighbours: four subset sums
+      const VT* tb = reinterpret_cast<const VT*>(a.ex_tab);
+      const unsigned m = (unsigned)present;
+      thin_acc(acc, tb[(m & 127u) * cvec + cv]);
+      thin_acc(acc, tb[(128u + ((m >> 7) & 127u)) * cvec + cv]);
+      thin_acc(acc, tb[(256u + ((m >> 14) & 127u)) * cvec + cv]);
+      thin_acc(acc, tb[(384u + ((m >> 21) & 63u)) * cvec + cv]);
     }
     VT b;
     thin_zero(b);
@@ -3198,6 +3040,15 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
     thin_act(acc, a.act, a.slope);
     reinterpret_cast<VT*>(a.out + o * a.cout)[cv] = acc;
   }
+}
+
+static int presence_tables(const float* ex_bias, int cout, const float** tab, hipStream_t s) {
+  void* p = nullptr;
+  PCC_TRY(lib_scratch_small((size_t)512 * cout * 4, &p));
+  k_presence_tables<<<(unsigned)pcc_cdiv(512 * cout, 256), 256, 0, s>>>(ex_bias, cout, (float*)p);
+  PCC_LAUNCH_CHECK();
+  *tab = (const float*)p;
+  return PCC_OK;
 }
 
 // presence source for the next pcc_convt_fwd_csr call (pcc_convt_fwd_csr_grid sets it): the output set's grid index
@@ -3233,13 +3084,21 @@ extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin
   g.act = act; g.slope = slope; g.ex_nbr = ex_nbr; g.ex_bias = ex_bias; g.ex_K = ex_K;
   g.ex_grid.bits = nullptr; g.out_keys = nullptr;
   if (g_ex_grid.bits) { g.ex_grid = g_ex_grid; g.out_keys = g_ex_keys; g.ex_nbr = nullptr; g_ex_grid.bits = nullptr; }
+  g.ex_tab = nullptr;
+  if (ex_bias) {
+    PCC_REQUIRE(ex_K == 27, "pcc_convt_fwd_csr: the per-neighbour constants are those of a 3x3x3 neighbourhood (ex_K=%d)", ex_K);
+    PCC_TRY(presence_tables(ex_bias, cout, &g.ex_tab, s));
+  }
   const int vec = (cout % 4 == 0) ? 4 : 1;
   int l = 0;
   while ((1 << l) < cout / vec && l < 6) ++l;
   g.lpr_log2 = l;
   const int64_t waves = pcc_cdiv(n_out, 64 >> l);
-  if (vec == 4) k_convt_gather_csr<4><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(g);
-  else k_convt_gather_csr<1><<<(unsigned)pcc_cdiv(waves, 4), 256, 0, s>>>(g);
+  const unsigned gg = (unsigned)pcc_cdiv(waves, 4);
+  // pair slots per batch of independent loads: narrow outputs (the last level, ~4 pairs per row) take 4, the others 8
+  if (vec == 4 && l <= 2) k_convt_gather_csr<4, 4><<<gg, 256, 0, s>>>(g);
+  else if (vec == 4) k_convt_gather_csr<4, 8><<<gg, 256, 0, s>>>(g);
+  else k_convt_gather_csr<1, 8><<<gg, 256, 0, s>>>(g);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
@@ -3358,10 +3217,13 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr_chunk(GatherCsrArgs a,
         for (int u = 0; u < JB; ++u) thin_acc(acc, x[u]);     // fixed order: pair id ascending, continued from the stored partial
       }
       if (is_last) {
-        for (unsigned long long pr = a.ex_bias ? present : 0ull; pr;) {
-          const int k = __ffsll((long long)pr) - 1;
-          pr &= pr - 1;
-          thin_acc(acc, reinterpret_cast<const VT*>(a.ex_bias + (long long)k * a.cout)[cv]);
+        if (a.ex_tab) {
+          const VT* tb = reinterpret_cast<const VT*>(a.ex_tab);
+          const unsigned m = (unsigned)present;
+          thin_acc(acc, tb[(m & 127u) * cvec + cv]);
+          thin_acc(acc, tb[(128u + ((m >> 7) & 127u)) * cvec + cv]);
+          thin_acc(acc, tb[(256u + ((m >> 14) & 127u)) * cvec + cv]);
+          thin_acc(acc, tb[(384u + ((m >> 21) & 63u)) * cvec + cv]);
         }
         VT b;
         thin_zero(b);
@@ -3439,7 +3301,11 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
   g.T = T; g.bias = bias; g.first = first; g.pair_ids = pair_ids; g.out = out; g.n_out = n_out; g.cout = cout;
   g.act = act; g.slope = slope; g.ex_nbr = nullptr; g.ex_bias = ex_bias; g.ex_K = 27;
   g.ex_grid.bits = nullptr; g.out_keys = nullptr;
-  if (ex_bias) { g.ex_grid = grid_from_host(out_bits, out_rank, h_out); g.out_keys = (const long long*)out_keys; }
+  g.ex_tab = nullptr;
+  if (ex_bias) {
+    g.ex_grid = grid_from_host(out_bits, out_rank, h_out); g.out_keys = (const long long*)out_keys;
+    PCC_TRY(presence_tables(ex_bias, cout, &g.ex_tab, s));
+  }
   const int vec = (cout % 4 == 0) ? 4 : 1;
   int l = 0;
   while ((1 << l) < cout / vec && l < 6) ++l;

@@ -622,6 +622,7 @@ struct ExpandCsrArgs {
   int ts_out; int K;
   int* first;                 // FILL=false: first[o] = pairs of row o;  FILL=true: exclusive prefix (read)
   int* pair_ids;
+  int zk;                     // kernel-offset index of a pair: 0 = x fastest (ix + KS*iy + KS*KS*iz, the native order), 1 = z fastest
 };
 
 // The compatible source cells of an output row: per axis the offsets whose source lies on the input lattice (offset index
@@ -704,11 +705,12 @@ __device__ __forceinline__ void csr_probe(const ExpandCsrArgs& a, long long o, F
       // row of the first cell's position: rank of its word + set bits below it; later hits of the field follow consecutively
       // (the rank is cumulative across words, so a field that straddles two words needs nothing extra)
       int i = a.in.rank[wi] + __popcll(w0 & ((1ull << (cell & 63)) - 1ull));
-      const int kxy = c.idx[0][jx] + KS * c.idx[1][jy];
+      const int kxy = a.zk ? KS * (c.idx[1][jy] + KS * c.idx[0][jx]) : c.idx[0][jx] + KS * c.idx[1][jy];
+      const int kzs = a.zk ? 1 : KS * KS;
       while (f) {
         const int t = __ffs((int)f) - 1;
         f &= f - 1;
-        on_hit(i, kxy + KS * KS * c.idx[2][t]);
+        on_hit(i, kxy + kzs * c.idx[2][t]);
         ++i;
       }
     }
@@ -769,10 +771,26 @@ extern "C" int pcc_coords_expand_grid(const int64_t* keys, int64_t n, int32_t ke
 extern "C" size_t pcc_expand_grid_csr_ws_bytes(int64_t n_out) { return pcc_scan_ws_bytes(n_out + 1) + 256; }
 
 // phase 2 (n_out known to the host): CSR pair lists of the transposed map: first[n_out+1], pair_ids[n_in*K]
+static int expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
+                           const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in,
+                           int64_t n_in, int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes, int zk, void* stream);
 extern "C" int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
                                           const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in,
                                           int64_t n_in, int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes,
                                           void* stream) {
+  return expand_grid_csr(out_keys, n_out, kernel_size, ts_out, in_bits, in_rank, h_in, n_in, first, pair_ids, ws, ws_bytes, 0, stream);
+}
+// the same lists with the kernel offsets of the pair ids numbered z fastest (iz + KS*iy + KS*KS*ix): for a per-pair product
+// buffer laid out [input row][kx][ky][kz][c], where the z-neighbours of a canonical (z-fastest) run of output rows are adjacent
+extern "C" int pcc_coords_expand_grid_csr_zk(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
+                                             const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in,
+                                             int64_t n_in, int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes,
+                                             void* stream) {
+  return expand_grid_csr(out_keys, n_out, kernel_size, ts_out, in_bits, in_rank, h_in, n_in, first, pair_ids, ws, ws_bytes, 1, stream);
+}
+static int expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
+                           const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in,
+                           int64_t n_in, int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes, int zk, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(out_keys && in_bits && in_rank && h_in && first && pair_ids && n_out > 0, "pcc_coords_expand_grid_csr: bad arguments");
   PCC_REQUIRE(kernel_size == 2 || kernel_size == 3 || kernel_size == 5 || kernel_size == 7,
@@ -781,7 +799,7 @@ extern "C" int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out
   PCC_REQUIRE(n_in * K < (1ll << 31), "pcc_coords_expand_grid_csr: too many pairs");
   if (ws_bytes < pcc_expand_grid_csr_ws_bytes(n_out)) { pcc_set_error("pcc_coords_expand_grid_csr: workspace too small"); return PCC_EWS; }
   ExpandCsrArgs a;
-  a.out_keys = out_keys; a.n_out = n_out; a.ts_out = ts_out; a.K = K; a.first = first; a.pair_ids = pair_ids;
+  a.out_keys = out_keys; a.n_out = n_out; a.ts_out = ts_out; a.K = K; a.first = first; a.pair_ids = pair_ids; a.zk = zk;
   a.in.bits = (const unsigned long long*)in_bits; a.in.rank = in_rank;
   for (int i = 0; i < 3; ++i) { a.in.lo[i] = h_in[i]; a.in.dims[i] = h_in[3 + i]; }
   a.in.ts_log2 = ilog2(h_in[6]); a.in.nbatch = h_in[7];

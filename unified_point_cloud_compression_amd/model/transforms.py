@@ -161,7 +161,7 @@ class SparseSynthesisTransform(nn.Module):
         """(packed composite kernel [343, Cin, Ch], neighbour-existence bias [27, Ch]) of head_conv0(genT(.)), cached per
         parameter version.  Offsets: genT writes parent + off_k, the head reads row + off_j, so parent -> row
         displacement is off_k - off_j, index (ix - jx + 2) per axis in the 7-wide composite."""
-        tag = tuple((p.data_ptr(), p._version) for p in (gen.kernel, gen.bias, c0.kernel)) + (S.WEIGHT_OFFSET_ORDER,)
+        tag = tuple((p.data_ptr(), p._version) for p in (gen.kernel, gen.bias, c0.kernel)) + (S.WEIGHT_OFFSET_ORDER, S.T_Z_FASTEST)
         cache = self.__dict__.setdefault("_fused_cache", {})
         hit = cache.get(id(gen))
         if hit is None or hit[0] != tag:
@@ -177,6 +177,8 @@ class SparseSynthesisTransform(nn.Module):
                     for jy in range(3):
                         for jx in range(3):
                             M[2 - jz:7 - jz, 2 - jy:7 - jy, 2 - jx:7 - jx] += W5 @ V3[jz, jy, jx]
+                if S.T_Z_FASTEST:                                    # offsets numbered z fastest, to match csr_for(zk=True)
+                    M = M.permute(2, 1, 0, 3, 4).contiguous()
                 Mf = torch.nn.Parameter(M.view(343, cin, ch).float(), requires_grad=False)
                 packed = S.PackedConv(transposed=True).get(Mf)
                 cb = (gen.bias.detach().double().reshape(1, cm) @ V.reshape(27 * cm, ch).view(27, cm, ch)).reshape(27, ch)
@@ -212,7 +214,7 @@ class SparseSynthesisTransform(nn.Module):
         feats = x._canonical_features()
         out_set = cs_in.expand(5, ts_out, want_csr=False)
         packedM, cb = self._fused_weights(gen, c0)
-        csr7 = cs_in.csr_for(out_set.keys, out_set.n, 7, ts_out)
+        csr7 = cs_in.csr_for(out_set.keys, out_set.n, 7, ts_out, zk=S.T_Z_FASTEST)
         from_grid = (S.STENCIL_FROM_GRID and out_set.grid() is not None and c2.kernel_size == 3 and c2.stride == 1
                      and c2.out_channels <= 4 and c0.out_channels in (4, 8, 16, 32, 64)
                      and 27 * c2.out_channels * c0.out_channels * 4 <= 48 * 1024)

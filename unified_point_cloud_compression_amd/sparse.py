@@ -103,6 +103,7 @@ GRID_MAX_BYTES = 8 << 30
 BAND_TILES = os.environ.get("PCC_BAND_TILES", "1") != "0"      # stencil kernels over large sets visit their tiles band by band (L2 locality of the dx = +-1 slabs)
 BAND_MIN_ROWS = 1 << 20
 BAND_COUNT = 16
+T_Z_FASTEST = os.environ.get("PCC_T_Z_FASTEST", "1") != "0"        # composite levels: products laid out [row][kx][ky][kz][c]
 T_CHUNKED = os.environ.get("PCC_T_CHUNKED", "0") != "0"            # composite levels: per-pair products staged in cache-sized chunks
 #   (measured round 2: bit-identical, 10 GB less memory, but +3.5 ms per step -- 125 chunk pairs of launches, children near
 #   chunk borders visited twice, and the Infinity Cache does not speed the gather up enough to pay for it: off)
@@ -218,7 +219,7 @@ class CoordSet:
             self._derived[key] = CoordSet(out[:n].clone() if n < self.n // 2 else out, n, new_stride, nb)
         return self._derived[key]
 
-    def csr_for(self, out_keys, n_out, ksize, ts_out):
+    def csr_for(self, out_keys, n_out, ksize, ts_out, zk=False):
         """CSR pair lists (first[n_out+1], pair_ids) of the transposed conv from this set onto the GIVEN output rows
         (any canonical subset of the lattice at pitch ts_out), built by probing this set's grid index."""
         g = self.grid()
@@ -231,8 +232,9 @@ class CoordSet:
         first = torch.empty(n_out + 1, dtype=torch.int32, device=dev)
         pair_ids = torch.empty(max(self.n * K, 1), dtype=torch.int32, device=dev)
         ws = L.workspace(L.load().pcc_expand_grid_csr_ws_bytes(n_out), dev)
-        L.call("pcc_coords_expand_grid_csr", L.ptr(out_keys), n_out, ksize, ts_out, L.ptr(g[0]), L.ptr(g[1]), g[2],
-               self.n, L.ptr(first), L.ptr(pair_ids), L.ptr(ws), ws.numel(), L.stream())
+        # zk: pair ids number the kernel offsets z fastest (for product buffers laid out [row][kx][ky][kz][c])
+        L.call("pcc_coords_expand_grid_csr_zk" if zk else "pcc_coords_expand_grid_csr", L.ptr(out_keys), n_out, ksize, ts_out,
+               L.ptr(g[0]), L.ptr(g[1]), g[2], self.n, L.ptr(first), L.ptr(pair_ids), L.ptr(ws), ws.numel(), L.stream())
         return first, pair_ids
 
     def expand(self, ksize, ts_out, want_csr=True):

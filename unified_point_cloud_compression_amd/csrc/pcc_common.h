@@ -131,13 +131,17 @@ __device__ inline unsigned pcc_grid_nbr27(const PccGrid& g, int64_t key, int lan
     if (sh + nz > 64) f64 |= g.bits[wi + 1] << (64 - sh);
     unsigned f = (unsigned)f64 & ((1u << nz) - 1u);
     if (!f) continue;
-    int r = rows ? g.rank[wi] + __popcll(w0 & ((1ull << sh) - 1ull)) : 0;
+    if (!rows) {                         // presence only: the field's bits go to k = c + 9 * (first dz + t), t = 0..2
+      mask |= ((f & 1u) | ((f & 2u) << 8) | ((f & 4u) << 16)) << (c + 9 * (z_lo - cz + 1));
+      continue;
+    }
+    int r = g.rank[wi] + __popcll(w0 & ((1ull << sh) - 1ull));
     while (f) {
       const int t = __ffs((int)f) - 1;
       f &= f - 1;
       const int k = c + 9 * (z_lo + t - cz + 1);
       mask |= 1u << k;
-      if (rows) rows[k] = r++;
+      rows[k] = r++;
     }
   }
   return mask;

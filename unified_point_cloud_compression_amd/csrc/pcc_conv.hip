@@ -1380,6 +1380,9 @@ __device__ inline void thin_zero(float4& v) { v = make_float4(0.f, 0.f, 0.f, 0.f
 __device__ inline void thin_zero(float& v) { v = 0.f; }
 __device__ inline void thin_acc(float4& a, const float4 x) { a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
 __device__ inline void thin_acc(float& a, const float x) { a += x; }
+// a += x * m with m = 1 or 0 (one rounding, so m = 1 gives exactly a + x)
+__device__ inline void thin_fma(float4& a, const float4 x, float m) { a.x = fmaf(x.x, m, a.x); a.y = fmaf(x.y, m, a.y); a.z = fmaf(x.z, m, a.z); a.w = fmaf(x.w, m, a.w); }
+__device__ inline void thin_fma(float& a, const float x, float m) { a = fmaf(x, m, a); }
 __device__ inline float act1(float v, int act, float slope) {
   if (act == PCC_ACT_RELU) return fmaxf(v, 0.f);
   if (act == PCC_ACT_LEAKY) return v >= 0.f ? v : v * slope;
@@ -3012,18 +3015,17 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
   for (int cv = cl; cv < cvec; cv += lpr) {
     VT acc;
     thin_zero(acc);
+    // branch-free batches: slots past the end of the list re-read the last pair (same cache line) and are weighted 0, so the
+    // JB index loads and then the JB product loads of a batch are independent and in flight together
     for (int t = t0; t < t1; t += JB) {
       int pid[JB];
 #pragma unroll
-      for (int u = 0; u < JB; ++u) pid[u] = (t + u < t1) ? a.pair_ids[t + u] : -1;
+      for (int u = 0; u < JB; ++u) pid[u] = a.pair_ids[min(t + u, t1 - 1)];
       VT x[JB];
 #pragma unroll
-      for (int u = 0; u < JB; ++u) {
-        thin_zero(x[u]);
-        if (pid[u] >= 0) x[u] = reinterpret_cast<const VT*>(a.T + (long long)pid[u] * a.cout)[cv];
-      }
+      for (int u = 0; u < JB; ++u) x[u] = reinterpret_cast<const VT*>(a.T + (long long)pid[u] * a.cout)[cv];
 #pragma unroll
-      for (int u = 0; u < JB; ++u) thin_acc(acc, x[u]);     // fixed order: pair id ascending
+      for (int u = 0; u < JB; ++u) thin_fma(acc, x[u], (t + u < t1) ? 1.f : 0.f);     // fixed order: pair id ascending
     }
     if (a.ex_tab) {                                                        // constants of the existing neighbours: four subset sums
       const VT* tb = reinterpret_cast<const VT*>(a.ex_tab);

@@ -31,7 +31,8 @@ def test_size_queries_are_pure_host_functions():
     L = lib.load()
     assert L.pcc_sort_ws_bytes(1000) > 8000 and L.pcc_map_nbr_elems(1000, 5, 1, 0) == 125000
     assert L.pcc_map_nbr_elems(1000, 5, 2, 1) == 27000 and L.pcc_map_nbr_elems(1000, 2, 2, 1) == 1000
-    assert L.pcc_conv_packed_elems(125, 128, 128) == 125 * 128 * 128 * 5 // 2   # fp32 image + three bf16 planes
+    # fp32 image + three bf16 planes + (pair-GEMM convolutions) two scaled fp16 planes + a scale per (offset, column)
+    assert L.pcc_conv_packed_elems(125, 128, 128) == 125 * 128 * 128 * 5 // 2 + 125 * 128 * 128 + 125 * 128
     assert L.pcc_conv_packed_elems(27, 192, 192) == 27 * 192 * 256 * 5 // 2     # padded to the 128-wide column tile
     assert L.pcc_conv_packed_elems(125, 4, 128) == 125 * 4 * 128                # narrow inputs: fp32 image only
     assert L.pcc_conv_packed_elems(27, 24, 24) == 0                           # unsupported shape is reported, not guessed
@@ -78,7 +79,12 @@ def _layout_extent(K, cin, cout):
         return K * cin * cout
     if cout <= 16 and cin in (16, 32, 64) and K * 16 * (cin + 4) * 4 <= 64 * 1024:
         return K * 16 * cin
-    return _mfma_total(K * cin * _cout_pad(cout), cin) if _mfma_ok(cin, cout) else 0
+    if not _mfma_ok(cin, cout):
+        return 0
+    total = _mfma_total(K * cin * _cout_pad(cout), cin)
+    if K >= 64 and cin % 32 == 0 and cin <= 256 and cout % 4 == 0 and cout >= 128:
+        total += K * cin * _cout_pad(cout) + K * _cout_pad(cout)       # pair-GEMM convolutions: + fp16 planes + (offset, column) scales
+    return total
 
 
 def _mfma_total(fp32_elems, cin):

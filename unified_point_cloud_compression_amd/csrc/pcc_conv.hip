@@ -472,10 +472,14 @@ __device__ __forceinline__ void h_split4(const float4 v, float s, f16x4& h, f16x
 }
 
 // fp32 packed GEMM image [piece][cout_pad][32] -> fp16 planes [piece][cout_pad][2][32] scaled per column, and 1/scale per column
+// (blockIdx.y: kernel offset of a convolution pack [K*ppo][cout_pad][32]; 0 for the flat operand of a dense product)
 __global__ void k_split_packed_h(const float* __restrict__ src, int ppo, int cout_pad, unsigned char* __restrict__ dst,
                                  float* __restrict__ cinv) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= cout_pad) return;
+  src += (size_t)blockIdx.y * ppo * cout_pad * 32;
+  dst += (size_t)blockIdx.y * ppo * cout_pad * 128;
+  cinv += (size_t)blockIdx.y * cout_pad;
   float mx = 0.f;
   for (int pc = 0; pc < ppo; ++pc) {
     const float4* r = reinterpret_cast<const float4*>(src + ((size_t)pc * cout_pad + col) * 32);
@@ -1173,6 +1177,136 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
           } else {                                           // last row tile / column block: invalid elements go out of range
             const unsigned off = (rrow < row_lim && j * 32 < col_lim) ? vO + (unsigned)j * 128u + so : BUF_OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, off, 0, 0);
+          }
+        }
+      }
+    }
+}
+
+// The gathered pair GEMM (pcc_conv_fwd_pairs, pcc_convt_fwd_rows: one kernel offset per 128-pair tile, T[pair] = x[in(pair)] W[k])
+// in the scaled fp16 form of k_gemm_h2: a pair's product row is scaled like its input row, the weights per (offset, column).
+template <int NCH>
+__global__ void __launch_bounds__(256, 3) k_pair_h2(ConvArgs a) {
+  constexpr int BM = 128, BN = 128, LDU = 9;
+  constexpr unsigned ROWB = NCH * 128u;
+  __shared__ __attribute__((aligned(16))) uint4 As[BM * LDU];
+  __shared__ __attribute__((aligned(16))) uint4 Bs[BN * LDU];
+  __shared__ __attribute__((aligned(16))) float rs[BM];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cpx = gridDim.x >> 3;
+  const int wid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  const int gy = a.cout_pad / BN;
+  const int tile_id = wid / gy;
+  const int colblock = (wid - tile_id * gy) * BN;
+  if (tile_id >= *a.n_tiles) return;
+  const long long p0 = (long long)tile_id * BM;
+  const int kid = a.tile_k[tile_id];
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(a.feath), (short)0, (int)(unsigned)((size_t)a.n_in * ROWB), 0x00020000);
+  const float* const wplanes = a.wp + a.wp_elems + bf_plane_elems(a.wp_elems);
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(wplanes) + ((size_t)kid * NCH * a.cout_pad + colblock) * 128u;
+  const float* const cinv = wplanes + a.wp_elems + (size_t)kid * a.cout_pad;
+  const unsigned b_stride = (unsigned)a.cout_pad * 128u;
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(wb), (short)0, (int)((NCH - 1) * b_stride + BN * 128u), 0x00020000);
+
+  unsigned vA[4], ld[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned u = (unsigned)(j * 256 + tid), row = u >> 3, wu = u & 7u;
+    const int g = a.pair_in[p0 + row];                                       // input row of the pair (-1: padding, reads zeros)
+    vA[j] = g >= 0 ? (unsigned)g * ROWB + wu * 16u : BUF_OOB;
+    ld[j] = row * LDU + wu;
+  }
+  const unsigned vB = (unsigned)tid * 16u;
+
+  uint4 av[4], bv[4];
+  auto issue = [&](int cbi) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vA[j] == BUF_OOB ? BUF_OOB : vA[j] + (unsigned)cbi * 128u, 0, 0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vB, (int)((unsigned)cbi * b_stride + (unsigned)j * 4096u), 0));
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm = w >> 1, wn = w & 1;
+  const int half = lane >> 5, r31 = lane & 31;
+  const unsigned fa = (unsigned)((wm * 64 + r31) * LDU + half), fb = (unsigned)((wn * 64 + r31) * LDU + half);
+
+  issue(0);
+  if (tid < BM) {
+    const int g = a.pair_in[p0 + tid];
+    rs[tid] = g >= 0 ? a.frow_inv[g] : 0.f;
+  }
+  float cs[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) cs[j] = cinv[colblock + wn * 64 + j * 32 + r31];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) As[ld[j]] = av[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bs[ld[j]] = bv[j];
+    __syncthreads();
+    if (c + 1 < NCH) issue(c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 af[2][2], bf[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[p][i] = __builtin_bit_cast(f16x8, As[fa + i * 32 * LDU + p * 4 + ks * 2]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[p][j] = __builtin_bit_cast(f16x8, Bs[fb + j * 32 * LDU + p * 4 + ks * 2]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // ---- stores: the tile's 128 product rows are consecutive rows of T (padding pairs included: they are zero)
+  const unsigned ncol = (unsigned)a.cout;
+  float* const obase = a.out + (size_t)p0 * ncol + colblock;
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+      obase, (short)0, (int)(((unsigned)(BM - 1) * ncol + min((unsigned)BN, ncol - (unsigned)colblock)) * 4u), 0x00020000);
+  const unsigned vO = ((unsigned)(wm * 64 + 4 * half) * ncol + (unsigned)(wn * 64 + r31)) * 4u;
+  const bool full = (unsigned)colblock + BN <= ncol;
+  const int col_lim = (int)ncol - colblock - wn * 64 - r31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const float4 r4 = *reinterpret_cast<const float4*>(&rs[wm * 64 + i * 32 + 8 * e4 + 4 * half]);
+      const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+      for (int e1 = 0; e1 < 4; ++e1) {
+        const int e = e4 * 4 + e1;
+        const unsigned so = (unsigned)(i * 32 + e1 + 8 * e4) * ncol * 4u;      // scalar
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float v = acc[i][j][e] * (rr[e1] * cs[j]);
+          if (full) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
+          } else {
+            const unsigned off = (j * 32 < col_lim) ? vO + (unsigned)j * 128u + so : BUF_OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, off, 0, 0);
           }
         }
@@ -1898,10 +2032,18 @@ static int conv_kind(int K, int cin, int cout) {
   return mfma_ok(cin, cout) ? KIND_MFMA : KIND_NONE;
 }
 
+// convolutions that run as gathered pair GEMMs (5x5x5 and wider, 128+ output channels): the pack also carries the scaled fp16
+// planes and the 1/scale of every (offset, column), fp32 image | bf16 planes | fp16 planes | K*cout_pad scales
+static bool conv_has_h(int K, int cin, int cout) {
+  return K >= 64 && cin % 32 == 0 && cin <= 256 && cout % 4 == 0 && bn_for(cout) == 128;
+}
 extern "C" int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout) {
   if (K <= 0 || cin <= 0 || cout <= 0) return 0;
   switch (conv_kind(K, cin, cout)) {
-    case KIND_MFMA: return mfma_packed_total((int64_t)K * cin * cout_pad_for(cout), cin);
+    case KIND_MFMA: {
+      const int64_t base = (int64_t)K * cin * cout_pad_for(cout);
+      return mfma_packed_total(base, cin) + (conv_has_h(K, cin, cout) ? base + (int64_t)K * cout_pad_for(cout) : 0);
+    }
     case KIND_WAVE16: return (int64_t)K * 16 * cin;
     case KIND_THIN_T: case KIND_THIN: return (int64_t)K * cin * cout;
     default: return 0;
@@ -1970,6 +2112,12 @@ extern "C" int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int
       k_pack_mfma<<<(unsigned)pcc_cdiv(base, 256), 256, 0, s>>>(W, K, cin, cout, cout_pad_for(cout), cb_log2_for(cin), packed);
       PCC_LAUNCH_CHECK();
       PCC_TRY(split_planes(packed, base, cin, s));
+      if (conv_has_h(K, cin, cout)) {
+        const int cp = cout_pad_for(cout);
+        float* const planes = packed + base + bf_plane_elems(base);
+        k_split_packed_h<<<dim3((unsigned)pcc_cdiv(cp, 128), (unsigned)K), 128, 0, s>>>(packed, cin >> 5, cp, (unsigned char*)planes, planes + base);
+        PCC_LAUNCH_CHECK();
+      }
       break;
     }
     case KIND_WAVE16: k_pack_wave16<<<g, 256, 0, s>>>(W, K, cin, cout, packed); break;
@@ -2597,8 +2745,20 @@ extern "C" int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t ci
     const dim3 grid((unsigned)((padded_pairs / PAIR_BM * gy + 7) / 8 * 8));
     const bool buf = g_mfma_buf && n_in * cin * 4 <= BUF_MAX_BYTES && a.wp_elems * 4 <= BUF_MAX_BYTES;
     const bool split = split_ok(a);
-    if (split) PCC_TRY(make_planes(a, false, s));
-    if (split && g_gemm_persistent) PCC_TRY(launch_gemm_bf<MODE_CONV>(a, s));
+    const bool pair_h = split && g_gemm_h && conv_has_h(K, cin, cout) && (size_t)n_in * cin * 4 <= (size_t)BUF_MAX_BYTES &&
+                        (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8);
+    if (pair_h) {                                   // scaled fp16 pairs, three MFMA terms (k_pair_h2)
+      PCC_TRY(make_planes_h(a, s));
+      switch (a.ppo) {
+        case 1: k_pair_h2<1><<<grid, 256, 0, s>>>(a); break;
+        case 2: k_pair_h2<2><<<grid, 256, 0, s>>>(a); break;
+        case 4: k_pair_h2<4><<<grid, 256, 0, s>>>(a); break;
+        case 6: k_pair_h2<6><<<grid, 256, 0, s>>>(a); break;
+        default: k_pair_h2<8><<<grid, 256, 0, s>>>(a); break;
+      }
+    } else if (split) PCC_TRY(make_planes(a, false, s));
+    if (pair_h) {}
+    else if (split && g_gemm_persistent) PCC_TRY(launch_gemm_bf<MODE_CONV>(a, s));
     else if (bn == 128) { if (split) k_conv_mfma_bf<2, 2, 2, 2, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     else if (bn == 64) { if (split) k_conv_mfma_bf<2, 2, 2, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     else { if (split) k_conv_mfma_bf<4, 1, 1, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<4, 1, 1, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<4, 1, 1, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
@@ -2786,8 +2946,20 @@ extern "C" int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t ci
     const dim3 grid((unsigned)((tiles_cap * gy + 7) / 8 * 8));
     const bool buf = g_mfma_buf && n_in * cin * 4 <= BUF_MAX_BYTES && a.wp_elems * 4 <= BUF_MAX_BYTES;
     const bool split = split_ok(a);
-    if (split) PCC_TRY(make_planes(a, false, s));
-    if (split && g_gemm_persistent) PCC_TRY(launch_gemm_bf<MODE_CONV>(a, s));
+    const bool pair_h = split && g_gemm_h && conv_has_h(K, cin, cout) && (size_t)n_in * cin * 4 <= (size_t)BUF_MAX_BYTES &&
+                        (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8);
+    if (pair_h) {                                   // scaled fp16 pairs, three MFMA terms (k_pair_h2)
+      PCC_TRY(make_planes_h(a, s));
+      switch (a.ppo) {
+        case 1: k_pair_h2<1><<<grid, 256, 0, s>>>(a); break;
+        case 2: k_pair_h2<2><<<grid, 256, 0, s>>>(a); break;
+        case 4: k_pair_h2<4><<<grid, 256, 0, s>>>(a); break;
+        case 6: k_pair_h2<6><<<grid, 256, 0, s>>>(a); break;
+        default: k_pair_h2<8><<<grid, 256, 0, s>>>(a); break;
+      }
+    } else if (split) PCC_TRY(make_planes(a, false, s));
+    if (pair_h) {}
+    else if (split && g_gemm_persistent) PCC_TRY(launch_gemm_bf<MODE_CONV>(a, s));
     else if (bn == 128) { if (split) k_conv_mfma_bf<2, 2, 2, 2, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 2, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 2, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     else if (bn == 64) { if (split) k_conv_mfma_bf<2, 2, 2, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<2, 2, 2, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<2, 2, 2, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }
     else { if (split) k_conv_mfma_bf<4, 1, 1, 1, MODE_CONV><<<grid, 256, 0, s>>>(a); else if (buf) k_conv_mfma<4, 1, 1, 1, MODE_CONV, true><<<grid, 256, 0, s>>>(a); else k_conv_mfma<4, 1, 1, 1, MODE_CONV, false><<<grid, 256, 0, s>>>(a); }

@@ -117,7 +117,7 @@ def account_flops(model, pc, q):
     orig_r, orig_h = S.convt_forward_rows, S.conv_head_forward
 
     def spy_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
-        calls.append((int(csr[0][n_out].item()), K, cin, cout, n_out, feats.shape[0]))
+        calls.append((int(csr[0][n_out].item()), float(K), cin, cout, n_out, feats.shape[0]))
         return orig_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope)
 
     def spy_h(feats, packed_w0, bias0, cmid, w2, bias2, cset, kmap):    # fused head: the cin -> cmid convolution is the MFMA launch
@@ -146,6 +146,9 @@ def account_flops(model, pc, q):
     split_on = os.environ.get("PCC_MFMA_SPLIT", "1") != "0"
     h_on = os.environ.get("PCC_GEMM_H", "1") != "0"
     for kmap, K, cin, cout, n_out, n_in in calls:
+        pair_rows = isinstance(K, float)                  # K given as a float: kept-row transposed convolution (pair GEMM)
+        K = int(K)
+        kmap_is_map = not isinstance(kmap, int) and kmap is not None
         dense, K = K < 0, abs(K)                          # K < 0: dense products of a generative transposed convolution
         if not mfma_shape(cin, cout):
             continue
@@ -159,6 +162,9 @@ def account_flops(model, pc, q):
         elif (dense and h_on and cin <= 256 and cin // 32 in (1, 2, 4, 6, 8) and K * cout >= 128 and
               (-(-n_in // 128) + 7) // 8 * 8 * (-(-(K * cout) // 128)) >= 512):
             terms = 3.0
+        elif (h_on and K >= max(64, S.PAIR_MIN_K) and cin >= S.PAIR_MIN_CIN and cin <= 256 and cin // 32 in (1, 2, 4, 6, 8)
+              and cout >= 128 and cout % 4 == 0 and (pair_rows or kmap_is_map)):
+            terms = 3.0                                   # gathered pair GEMM (k_pair_h2)
         else:
             terms = float(SPLIT_TERMS)
         exec_flops += fl * terms

@@ -20,7 +20,7 @@ calls = json.load(open(sys.argv[2]))
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
 # convolution launches of the family: MODE_CONV instantiations only (the GDN / IGDN modes of the same kernel are not calls of
 # the list), and only the calls that take the MFMA path (thin heads with <= 4 output channels run VALU kernels)
-fam = [r for r in rows if re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>|k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0>|k_conv_wave16|k_gemm_bf<\d+, \d+, \d+, \d+, 0>|k_gemm_bf2<\d+>|k_gemm_h2<\d+>",
+fam = [r for r in rows if re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>|k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0>|k_conv_wave16|k_gemm_bf<\d+, \d+, \d+, \d+, 0>|k_gemm_bf2<\d+>|k_gemm_h2<\d+>|k_pair_h2<\d+>",
                                  r["Kernel_Name"])]
 calls = [c for c in calls if c["cout"] > 4 and (c["cin"] in (4, 8, 16) or c["cin"] % 32 == 0)]
 assert len(fam) >= len(calls), (len(fam), len(calls))

@@ -1,0 +1,17 @@
+#!/bin/bash
+# The round's measurement batch on the GPU box (run from the repo root): kernel stats, launch attribution, layer report,
+# PMC traffic, the bench line.  Outputs under gpurun_out/meas/; copy what is to be judged into profiles/.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/meas; mkdir -p $O
+echo "kernel stats" > $O/progress.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-aux > $O/ks_bench.json 2> $O/ks.err && python profiles/summarize.py $O/ks 13 > $O/kernel_stats.txt 2>&1
+echo "attribution" >> $O/progress.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/attr -- python3 tools/layer_report.py 10 $O/attr_calls.json > $O/layer_report_profiled.txt 2>&1 && python tools/kernel_attribution.py $O/attr $O/attr_calls.json > $O/kernel_attribution.txt 2>&1
+echo "layer report" >> $O/progress.txt
+timeout -k 10 200 python tools/layer_report.py 10 > $O/layer_report.txt 2>&1
+echo "pmc" >> $O/progress.txt
+timeout -k 10 400 python tools/pmc_traffic.py collect $O/pmc > $O/pmc.log 2>&1 && python tools/pmc_traffic.py parse $O/pmc $O/pmc_traffic.json >> $O/pmc.log 2>&1 && python tools/pmc_by_kernel.py $O/pmc > $O/pmc_by_kernel.txt 2>&1
+echo "bench" >> $O/progress.txt
+timeout -k 10 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+echo "done" >> $O/progress.txt
+tail -c 600 $O/bench.json

@@ -21,7 +21,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_sha  # noqa: E402
 
-KERNELS = ("k_conv_mfma", "k_conv_wave16", "k_gemm_bf2", "k_gemm_h2")
+KERNELS = ("k_conv_mfma", "k_conv_wave16", "k_gemm_bf2", "k_gemm_h2", "k_pair_h2")
 BENCH = ["python3", "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-aux", "--coder", "symbols"]
 
 
@@ -44,7 +44,7 @@ def parse(out, dst):
         for r in csv.DictReader(open(files[0])):
             name = r["Kernel_Name"]
             conv = ("k_conv_wave16" in name or re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>", name)
-                    or re.search(r"k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0>", name) or re.search(r"k_gemm_(bf2|h2)<\d+>", name))                                   # MODE_CONV only
+                    or re.search(r"k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0>", name) or re.search(r"k_gemm_(bf2|h2)<\d+>|k_pair_h2<\d+>", name))                                   # MODE_CONV only
             if r["Counter_Name"] == ctr and conv:
                 tot += float(r["Counter_Value"])
                 launches += 1
@@ -53,7 +53,7 @@ def parse(out, dst):
     assert n == res["WRITE_SIZE"]["launches"] and n > 0
     read = 2.0 * res["FETCH_SIZE"]["kib_total"] * 1024 / n      # gfx950: FETCH_SIZE reads half of wide streaming reads
     write = res["WRITE_SIZE"]["kib_total"] * 1024 / n
-    rec = {"kernel": "k_gemm_h2 / k_gemm_bf2 + k_conv_mfma_bf<*,MODE_CONV> + k_conv_mfma<*,MODE_CONV> + k_conv_wave16* (the event-timed MFMA launches)", "launches": n,
+    rec = {"kernel": "k_gemm_h2 / k_pair_h2 / k_gemm_bf2 + k_conv_mfma_bf<*,MODE_CONV> + k_conv_mfma<*,MODE_CONV> + k_conv_wave16* (the event-timed MFMA launches)", "launches": n,
            "hbm_read_bytes_per_launch": read, "hbm_write_bytes_per_launch": write,
            "hbm_bytes_per_launch": read + write,
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), KiB*1024, FETCH x2 (gfx950)",

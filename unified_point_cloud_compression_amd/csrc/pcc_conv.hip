@@ -3511,6 +3511,7 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
 
 // 3x3x3 convolution to <= 4 channels on a full set, neighbours from the set's grid index (no kernel map):
 //   t[k*cout+co][i] = <feat[i], w_k[co]>  (k_thin_project),  out[o][co] = b + sum_k t[k*cout+co][nbr_k(o)]
+static bool g_thin_grid1 = getenv("PCC_THIN_GRID1") ? atoi(getenv("PCC_THIN_GRID1")) != 0 : true;
 struct ThinGridArgs {
   const float* t; const float* bias; const long long* keys; PccGrid g; float* out; long long n; int cout;
 };
@@ -3559,6 +3560,58 @@ __global__ void __launch_bounds__(256) k_thin_gather_grid(ThinGridArgs a) {
     if (o < a.cout) a.out[p * a.cout + o] = acc[o] + (a.bias ? a.bias[o] : 0.f);
 }
 
+// one output channel, branch-free: the 9 (bitmap word, rank) pairs of a row are fetched together, then its 27 projected
+// values with buffer loads whose offset is out of range for an absent neighbour (27 independent loads in flight per row,
+// where the loop form above serialised column after column behind its branches).  t must stay below 4 GB.
+__global__ void __launch_bounds__(256) k_thin_gather_grid1(ThinGridArgs a) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n) return;
+  const PccGrid& g = a.g;
+  const long long key = a.keys[p];
+  const int b = (int)(key >> 48);
+  const int cx = (((int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - g.lo[0]) >> g.ts_log2);
+  const int cy = (((int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - g.lo[1]) >> g.ts_log2);
+  const int cz = (((int)(key & 0xFFFF) - (int)PCC_BIAS - g.lo[2]) >> g.ts_log2);
+  const int z_lo = cz > 0 ? cz - 1 : 0, z_hi = cz + 1 < g.dims[2] ? cz + 1 : g.dims[2] - 1;
+  const int nz = z_hi - z_lo + 1;
+  const int dz0 = z_lo - cz + 1;
+  unsigned long long w0[9], w1[9];
+  int rk[9], sh[9];
+  bool ok[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const int nx = cx + c % 3 - 1, ny = cy + c / 3 - 1;
+    ok[c] = !(nx < 0 || ny < 0 || nx >= g.dims[0] || ny >= g.dims[1]);
+    const long long cell = ok[c] ? (((long long)b * g.dims[0] + nx) * g.dims[1] + ny) * g.dims[2] + z_lo : 0ll;
+    const long long wi = cell >> 6;
+    sh[c] = (int)(cell & 63);
+    w0[c] = g.bits[wi];
+    rk[c] = g.rank[wi];
+    w1[c] = (sh[c] + nz > 64) ? g.bits[wi + 1] : 0ull;        // (rare: the field straddles two words)
+  }
+  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.t), (short)0,
+                                                                       (int)(unsigned)((size_t)27 * a.n * 4), 0x00020000);
+  float v[27];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    unsigned long long f64 = w0[c] >> sh[c];
+    if (sh[c] + nz > 64) f64 |= w1[c] << (64 - sh[c]);
+    const unsigned f = ok[c] ? ((unsigned)f64 & ((1u << nz) - 1u)) : 0u;
+    const int r = rk[c] + __popcll(w0[c] & ((1ull << sh[c]) - 1ull));
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int k = c + 9 * (dz0 + t);                         // (k < 27 whenever bit t can be set: t < nz)
+      const unsigned row = (unsigned)(r + __popc(f & ((1u << t) - 1u)));
+      const unsigned off = ((f >> t) & 1u) ? ((unsigned)k * (unsigned)a.n + row) * 4u : BUF_OOB;
+      v[c * 3 + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, off, 0, 0));
+    }
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc += v[i];                    // fixed order: columns ascending, z ascending (absent: + 0)
+  a.out[p] = acc + (a.bias ? a.bias[0] : 0.f);
+}
+
 extern "C" size_t pcc_thin_grid_ws_bytes(int64_t n, int32_t cout) { return (size_t)27 * cout * (size_t)(n > 0 ? n : 1) * sizeof(float) + 256; }
 
 extern "C" int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin, const float* packed_w /*thin layout [27][cout][cin]*/,
@@ -3581,7 +3634,8 @@ extern "C" int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin,
   }
   ThinGridArgs a;
   a.t = t; a.bias = bias; a.keys = (const long long*)keys; a.g = grid_from_host(bits, rank, h_grid); a.out = out; a.n = n; a.cout = cout;
-  if (cout == 1) k_thin_gather_grid<1><<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
+  if (cout == 1 && (size_t)27 * n * 4 <= (size_t)BUF_MAX_BYTES && g_thin_grid1) k_thin_gather_grid1<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
+  else if (cout == 1) k_thin_gather_grid<1><<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
   else k_thin_gather_grid<4><<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
   PCC_LAUNCH_CHECK();
   return PCC_OK;

@@ -680,12 +680,29 @@ __global__ void __launch_bounds__(256) k_expand_csr_count(ExpandCsrArgs a) {
   csr_columns<KS>(a, o, c);
   int total = 0;
   if (c.b < a.in.nbatch && c.cnt[2] > 0) {
-    for (int jx = 0; jx < c.cnt[0]; ++jx)
-      for (int jy = 0; jy < c.cnt[1]; ++jy) {
-        const long long cell = (((long long)c.b * a.in.dims[0] + c.cell[0][jx]) * a.in.dims[1] + c.cell[1][jy]) * a.in.dims[2] + c.cell[2][0];
-        long long wi; unsigned long long w0;
-        total += __popc(csr_field(a.in.bits, cell, c.cnt[2], &wi, &w0));
+    // All (x, y) columns at once: a column's z field (<= 4 bits) is cut out of the 64-bit window that starts at the 32-bit
+    // word holding its first cell -- it never straddles, so a column is ONE unconditional load (absent columns re-read cell 0
+    // and are masked) and the <= 16 loads of a row are in flight together.  (The loop form waited for each column's word.)
+    constexpr int M = (KS + 1) / 2;                      // compatible offsets per axis (consecutive source cells)
+    const unsigned* const bits32 = reinterpret_cast<const unsigned*>(a.in.bits);
+    const long long cells = (long long)a.in.nbatch * a.in.dims[0] * a.in.dims[1] * a.in.dims[2];
+    const long long last_dw = 2 * ((cells + 63) >> 6) - 2;       // last 32-bit word a 64-bit window may start at
+    const unsigned fmask = (1u << c.cnt[2]) - 1u;
+    unsigned long long w[M * M];
+    int sh[M * M];
+#pragma unroll
+    for (int jx = 0; jx < M; ++jx)
+#pragma unroll
+      for (int jy = 0; jy < M; ++jy) {
+        const bool ok = jx < c.cnt[0] && jy < c.cnt[1];
+        const long long cell = ok ? (((long long)c.b * a.in.dims[0] + c.cell[0][jx]) * a.in.dims[1] + c.cell[1][jy]) * a.in.dims[2] + c.cell[2][0] : 0ll;
+        const long long dw = cell >> 5, dw2 = dw < last_dw ? dw : last_dw;
+        sh[jx * M + jy] = ok ? (int)(cell & 31) + 32 * (int)(dw - dw2) : 64;
+        const unsigned lo = bits32[dw2], hi = bits32[dw2 + 1];
+        w[jx * M + jy] = (unsigned long long)lo | ((unsigned long long)hi << 32);
       }
+#pragma unroll
+    for (int i = 0; i < M * M; ++i) total += sh[i] < 64 ? __popc((unsigned)(w[i] >> (sh[i] & 63)) & fmask) : 0;
   }
   a.first[o] = total;
 }

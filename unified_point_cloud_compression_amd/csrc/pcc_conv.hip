@@ -2200,6 +2200,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 
 static bool g_splitk = getenv("PCC_SPLITK") ? atoi(getenv("PCC_SPLITK")) != 0 : true;
 static bool g_gemm_persistent = getenv("PCC_GEMM_PERSISTENT") ? atoi(getenv("PCC_GEMM_PERSISTENT")) != 0 : false;   // measured slower (2 workgroups per CU): off
+static bool g_splitk_tiles = getenv("PCC_SPLITK_TILES") ? atoi(getenv("PCC_SPLITK_TILES")) != 0 : true;
 static int g_gemm2 = getenv("PCC_GEMM2") ? atoi(getenv("PCC_GEMM2")) : 1;       // 0: general kernel, 1: stripped dense-GEMM kernel
 static int g_dbg = getenv("PCC_DBG") ? atoi(getenv("PCC_DBG")) : 0;
 
@@ -2307,9 +2308,11 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
     else if (buf) k_conv_mfma<WM, WN, TM, TN, MODE, true><<<grid(BMV), 256, 0, s>>>(a);          \
     else k_conv_mfma<WM, WN, TM, TN, MODE, false><<<grid(BMV), 256, 0, s>>>(a);                  \
   } while (0)
+  // (a split reduction multiplies the grid: count it, so that split layers keep the large row tile and its weight reuse)
+  const long long ksg = g_splitk_tiles ? a.ksplit : 1;
   if (bn == 128) {
-    if (tiles(128) * gy >= want) PCC_LAUNCH_MFMA(2, 2, 2, 2, 128);
-    else if (tiles(64) * gy >= want) PCC_LAUNCH_MFMA(2, 2, 1, 2, 64);
+    if (tiles(128) * gy * ksg >= want) PCC_LAUNCH_MFMA(2, 2, 2, 2, 128);
+    else if (tiles(64) * gy * ksg >= want) PCC_LAUNCH_MFMA(2, 2, 1, 2, 64);
     else PCC_LAUNCH_MFMA(1, 4, 1, 1, 32);
   } else if (bn == 64) {
     if (tiles(128) * gy >= want) PCC_LAUNCH_MFMA(2, 2, 2, 1, 128);

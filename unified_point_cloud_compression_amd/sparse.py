@@ -360,18 +360,24 @@ def pack_keys(coords):
     return keys
 
 
-def bounds_of(coords):
+def bounds_of(coords, canon_keys=None):
+    """Bounds of user coordinates; with canon_keys (their packed keys) also whether those already are canonical, in the
+    same device->host read: returns Bounds, or (Bounds, is_canonical)."""
     if coords.shape[0] == 0:
-        return Bounds(0, (0, 0, 0), (0, 0, 0))
+        b = Bounds(0, (0, 0, 0), (0, 0, 0))
+        return b if canon_keys is None else (b, True)
     c = coords.contiguous()
     if c.dtype not in (torch.float32, torch.int32):
         c = c.to(torch.float32) if c.dtype.is_floating_point else c.to(torch.int32)
-    out = torch.empty(8, dtype=torch.int32, device=c.device)
+    out = torch.empty(12, dtype=torch.int32, device=c.device)
     L.call("pcc_coords_bounds", L.ptr(c), 1 if c.dtype.is_floating_point else 0, c.shape[0], L.ptr(out), L.stream())
+    if canon_keys is not None:
+        L.call("pcc_keys_is_canonical", L.ptr(canon_keys), c.shape[0], out.data_ptr() + 32, L.stream())
     v = out.tolist()                                      # one device->host read
     if v[0] < 0:
         raise L.PccError("negative batch index")
-    return Bounds(v[4], v[1:4], v[5:8])
+    b = Bounds(v[4], v[1:4], v[5:8])
+    return b if canon_keys is None else (b, bool(v[8]))
 
 
 def coordset_from_coords(coords, tensor_stride):
@@ -381,8 +387,8 @@ def coordset_from_coords(coords, tensor_stride):
     keep  None, or int64 indices of the user rows that survive de-duplication (first wins, A.1)."""
     n = coords.shape[0]
     keys = pack_keys(coords)
-    b = bounds_of(coords)
-    if n <= 1 or _canon_check(keys, n):
+    b, canonical = bounds_of(coords, canon_keys=keys if n > 1 else None) if n > 1 else (bounds_of(coords), True)
+    if n <= 1 or canonical:
         return CoordSet(keys, n, tensor_stride, b), None, None
     dev = coords.device
     lib = L.load()

@@ -57,10 +57,11 @@ class UnifiedModel(CompressionModel):
         return order, counts.tolist()
 
     @staticmethod
-    def block_input(x_block):
+    def block_input(x_block, coords=None):
         """floor -> int32, de-duplicate (first wins), features [1, r, g, b] (`model/model.py:141-161`)."""
         n = x_block.shape[0]
-        coords = torch.cat([torch.zeros((n, 1), device=x_block.device, dtype=x_block.dtype), x_block[:, :3]], dim=1)
+        if coords is None:
+            coords = torch.cat([torch.zeros((n, 1), device=x_block.device, dtype=x_block.dtype), x_block[:, :3]], dim=1)
         feats = torch.cat([torch.ones((n, 1), device=x_block.device, dtype=torch.float32),
                            x_block[:, 3:6].to(torch.float32)], dim=1)
         return SparseTensor(coordinates=coords, features=feats, device=x_block.device)
@@ -89,12 +90,24 @@ class UnifiedModel(CompressionModel):
         if scaling_factor != 1.0:
             pointcloud = pointcloud.clone()
             pointcloud[:, :3] = torch.round(pointcloud[:, :3] / scaling_factor).int()
-        order, counts = self.partition(pointcloud, block_size)
+        # one block (the usual case: `block_size` 1024 against vox10 frames)?  The bounds the coordinate set needs anyway
+        # answer that: floor(max) - floor(min) < block_size on every axis implies a single block of `partition`, so its two
+        # reductions and its host read are skipped and the read below also serves the SparseTensor constructor.
+        single = None
+        n_pts = pointcloud.shape[0]
+        if n_pts > 1:
+            c4 = torch.cat([torch.zeros((n_pts, 1), device=pointcloud.device, dtype=pointcloud.dtype), pointcloud[:, :3]], dim=1)
+            keys = S.pack_keys(c4)
+            b, canonical = S.bounds_of(c4, canon_keys=keys)
+            if max(b.hi[i] - b.lo[i] for i in range(3)) < block_size:
+                c4._pcc_hint = (keys, b, canonical)
+                single = c4
+        order, counts = (None, [n_pts]) if single is not None else self.partition(pointcloud, block_size)
         xs = pointcloud if order is None else pointcloud[order]
         bitstreams, block_shapes, block_coordinates, block_q_vals, block_k = [], [], [], [], []
         start = 0
         for count in counts:
-            x = self.block_input(xs[start:start + count])
+            x = self.block_input(xs[start:start + count], coords=single)
             y, k = self.g_a(x)
             _, symbols, shape = self.entropy_model.compress(y, q)
             block_q_vals.append(q)

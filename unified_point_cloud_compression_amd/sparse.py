@@ -386,8 +386,12 @@ def coordset_from_coords(coords, tensor_stride):
           canonical position -> row of the (de-duplicated) user-order tensor;
     keep  None, or int64 indices of the user rows that survive de-duplication (first wins, A.1)."""
     n = coords.shape[0]
-    keys = pack_keys(coords)
-    b, canonical = bounds_of(coords, canon_keys=keys if n > 1 else None) if n > 1 else (bounds_of(coords), True)
+    hint = getattr(coords, "_pcc_hint", None)             # (keys, bounds, canonical) already read by the caller (compress)
+    if hint is not None:
+        keys, b, canonical = hint
+    else:
+        keys = pack_keys(coords)
+        b, canonical = bounds_of(coords, canon_keys=keys if n > 1 else None) if n > 1 else (bounds_of(coords), True)
     if n <= 1 or canonical:
         return CoordSet(keys, n, tensor_stride, b), None, None
     dev = coords.device

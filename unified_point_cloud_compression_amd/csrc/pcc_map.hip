@@ -645,6 +645,24 @@ __device__ __forceinline__ void csr_columns(const ExpandCsrArgs& a, long long o,
                     (int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - a.in.lo[1],
                     (int)(key & 0xFFFF) - (int)PCC_BIAS - a.in.lo[2]};
   const int tm = (1 << a.in.ts_log2) - 1;
+  if ((KS & 1) && a.ts_out * 2 == (1 << a.in.ts_log2)) {
+    // up-sampling by 2 with an odd kernel (the generative convolutions of the codec): in units of the output pitch the
+    // source cell cc holds offset index ia = P + H - 2 cc, so the compatible cells are the run
+    // [ceil((P - H) / 2), floor((P + H) / 2)] cut to the lattice -- closed form instead of a scan over the KS offsets
+    const int tl = a.in.ts_log2 - 1;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      const int P = p[ax] >> tl;                         // (p is a multiple of the output pitch)
+      int c0 = (P - H + 1) >> 1, c1 = (P + H) >> 1;
+      c0 = c0 < 0 ? 0 : c0;
+      c1 = c1 >= a.in.dims[ax] ? a.in.dims[ax] - 1 : c1;
+      const int m = c1 - c0 + 1;
+      c.cnt[ax] = (m > 0 && !(p[ax] & (a.ts_out - 1))) ? m : 0;      // (rows off the output lattice have no source)
+#pragma unroll
+      for (int i = 0; i < (KS + 1) / 2; ++i) { c.cell[ax][i] = c0 + i; c.idx[ax][i] = P + H - 2 * (c0 + i); }
+    }
+    return;
+  }
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) {
     int m = 0;

@@ -630,10 +630,15 @@ struct ExpandCsrArgs {
 // one bit field of <= 4 bits in the occupancy bitmap (at most two words): a column costs one field extraction instead of
 // a loop over its cells -- the per-cell loops were instruction-bound (64 divergent iterations per row, 0.9 + 2.1 ms per step
 // for the 7-wide lists of the composite convolutions in round 2).
+// (Scalars, not per-cell arrays: the cells of an axis are consecutive and their offset indices step down by the pitch ratio,
+// so cell j is c0 + j with index i0 - step * j.  Arrays indexed by a loop counter went to scratch memory -- 188 bytes per
+// thread, 2.7 GB of scratch traffic per pass over the last level's 14.5 M rows.)
 template <int KS>
 struct CsrCols {
-  int cell[3][KS], idx[3][KS], cnt[3];
-  int b;
+  int c0[3], i0[3], cnt[3];
+  int step, b;
+  __device__ __forceinline__ int cell(int ax, int j) const { return c0[ax] + j; }
+  __device__ __forceinline__ int idx(int ax, int j) const { return i0[ax] - step * j; }
 };
 
 template <int KS>
@@ -645,6 +650,7 @@ __device__ __forceinline__ void csr_columns(const ExpandCsrArgs& a, long long o,
                     (int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - a.in.lo[1],
                     (int)(key & 0xFFFF) - (int)PCC_BIAS - a.in.lo[2]};
   const int tm = (1 << a.in.ts_log2) - 1;
+  c.step = (1 << a.in.ts_log2) / a.ts_out;
   if ((KS & 1) && a.ts_out * 2 == (1 << a.in.ts_log2)) {
     // up-sampling by 2 with an odd kernel (the generative convolutions of the codec): in units of the output pitch the
     // source cell cc holds offset index ia = P + H - 2 cc, so the compatible cells are the run
@@ -658,19 +664,23 @@ __device__ __forceinline__ void csr_columns(const ExpandCsrArgs& a, long long o,
       c1 = c1 >= a.in.dims[ax] ? a.in.dims[ax] - 1 : c1;
       const int m = c1 - c0 + 1;
       c.cnt[ax] = (m > 0 && !(p[ax] & (a.ts_out - 1))) ? m : 0;      // (rows off the output lattice have no source)
-#pragma unroll
-      for (int i = 0; i < (KS + 1) / 2; ++i) { c.cell[ax][i] = c0 + i; c.idx[ax][i] = P + H - 2 * (c0 + i); }
+      c.c0[ax] = c0;
+      c.i0[ax] = P + H - 2 * c0;
     }
     return;
   }
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) {
     int m = 0;
+    c.c0[ax] = 0; c.i0[ax] = 0;
 #pragma unroll
     for (int ia = KS - 1; ia >= 0; --ia) {
       const int rel = p[ax] - (ia - H) * a.ts_out;
       const int cc = rel >> a.in.ts_log2;
-      if (rel >= 0 && !(rel & tm) && cc < a.in.dims[ax]) { c.cell[ax][m] = cc; c.idx[ax][m] = ia; ++m; }
+      if (rel >= 0 && !(rel & tm) && cc < a.in.dims[ax]) {
+        if (m == 0) { c.c0[ax] = cc; c.i0[ax] = ia; }
+        ++m;
+      }
     }
     c.cnt[ax] = m;
   }
@@ -713,7 +723,7 @@ __global__ void __launch_bounds__(256) k_expand_csr_count(ExpandCsrArgs a) {
 #pragma unroll
       for (int jy = 0; jy < M; ++jy) {
         const bool ok = jx < c.cnt[0] && jy < c.cnt[1];
-        const long long cell = ok ? (((long long)c.b * a.in.dims[0] + c.cell[0][jx]) * a.in.dims[1] + c.cell[1][jy]) * a.in.dims[2] + c.cell[2][0] : 0ll;
+        const long long cell = ok ? (((long long)c.b * a.in.dims[0] + c.cell(0, jx)) * a.in.dims[1] + c.cell(1, jy)) * a.in.dims[2] + c.cell(2, 0) : 0ll;
         const long long dw = cell >> 5, dw2 = dw < last_dw ? dw : last_dw;
         sh[jx * M + jy] = ok ? (int)(cell & 31) + 32 * (int)(dw - dw2) : 64;
         const unsigned lo = bits32[dw2], hi = bits32[dw2 + 1];
@@ -733,19 +743,19 @@ __device__ __forceinline__ void csr_probe(const ExpandCsrArgs& a, long long o, F
   if (c.b >= a.in.nbatch || c.cnt[2] == 0) return;
   for (int jx = 0; jx < c.cnt[0]; ++jx)
     for (int jy = 0; jy < c.cnt[1]; ++jy) {
-      const long long cell = (((long long)c.b * a.in.dims[0] + c.cell[0][jx]) * a.in.dims[1] + c.cell[1][jy]) * a.in.dims[2] + c.cell[2][0];
+      const long long cell = (((long long)c.b * a.in.dims[0] + c.cell(0, jx)) * a.in.dims[1] + c.cell(1, jy)) * a.in.dims[2] + c.cell(2, 0);
       long long wi; unsigned long long w0;
       unsigned f = csr_field(a.in.bits, cell, c.cnt[2], &wi, &w0);
       if (!f) continue;
       // row of the first cell's position: rank of its word + set bits below it; later hits of the field follow consecutively
       // (the rank is cumulative across words, so a field that straddles two words needs nothing extra)
       int i = a.in.rank[wi] + __popcll(w0 & ((1ull << (cell & 63)) - 1ull));
-      const int kxy = a.zk ? KS * (c.idx[1][jy] + KS * c.idx[0][jx]) : c.idx[0][jx] + KS * c.idx[1][jy];
+      const int kxy = a.zk ? KS * (c.idx(1, jy) + KS * c.idx(0, jx)) : c.idx(0, jx) + KS * c.idx(1, jy);
       const int kzs = a.zk ? 1 : KS * KS;
       while (f) {
         const int t = __ffs((int)f) - 1;
         f &= f - 1;
-        on_hit(i, kxy + kzs * c.idx[2][t]);
+        on_hit(i, kxy + kzs * c.idx(2, t));
         ++i;
       }
     }

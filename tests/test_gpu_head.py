@@ -204,3 +204,23 @@ def test_chunked_composite_equals_one_pass_bit_for_bit(ts_in, shift, with_ex):
     assert lib.pcc_convt_chunk_t_bytes(len(keys), 343, cout) >= 1024 * 343 * cout * 4
     assert torch.equal(a, b) and torch.equal(a, a2)
     assert float(a.abs().max().item()) > 0
+
+
+def test_pair_lists_with_z_fastest_offset_numbering():
+    """`pcc_coords_expand_grid_csr_zk` = the lists of `pcc_coords_expand_grid_csr` with every pair's kernel offset renumbered
+    iz + 7 iy + 49 ix (same rows, same order inside a row)."""
+    from unified_point_cloud_compression_amd import sparse as S
+    keys = _two_batch_keys(4, 2, -3)
+    C = co.unpack_keys(keys)
+    cs = S.CoordSet(t(keys), len(keys), 2, S.Bounds(1, C[:, 1:].min(0), C[:, 1:].max(0)))
+    out_set = cs.expand(5, 1, want_csr=False)
+    fa, pa = cs.csr_for(out_set.keys, out_set.n, 7, 1)
+    fb, pb = cs.csr_for(out_set.keys, out_set.n, 7, 1, zk=True)
+    fa, fb = n(fa), n(fb)
+    assert np.array_equal(fa, fb)
+    P = int(fa[out_set.n])
+    pa, pb = n(pa)[:P].astype(np.int64), n(pb)[:P].astype(np.int64)
+    row_a, k_a = pa // 343, pa % 343
+    ix, iy, iz = k_a % 7, (k_a // 7) % 7, k_a // 49
+    assert np.array_equal(pb // 343, row_a) and np.array_equal(pb % 343, iz + 7 * iy + 49 * ix)
+    assert P > out_set.n                                   # several parents per child on average

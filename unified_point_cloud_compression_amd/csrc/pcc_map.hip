@@ -481,14 +481,22 @@ __global__ void k_grid_enumerate(const unsigned long long* __restrict__ bits, co
   unsigned long long w = bits[wi];
   int r = rank[wi];
   if (wi == words - 1) *count = (int64_t)r + __popcll(w);
+  if (!w) return;
+  // cell of the word's first bit, decomposed once (three 64-bit divisions per WORD, not per set bit); a bit's z may run past
+  // the end of the z axis and carry into y / x / batch
+  long long cell = wi * 64;
+  const int z0 = (int)(cell % d2); cell /= d2;
+  const int y0 = (int)(cell % d1); cell /= d1;
+  const int x0 = (int)(cell % d0);
+  const int b0 = (int)(cell / d0);
   while (w) {
     const int bit = __ffsll((long long)w) - 1;
     w &= w - 1;
-    long long cell = wi * 64 + bit;
-    const int cz = (int)(cell % d2); cell /= d2;
-    const int cy = (int)(cell % d1); cell /= d1;
-    const int cx = (int)(cell % d0);
-    const int b = (int)(cell / d0);
+    int cz = z0 + bit, cy = y0, cx = x0, b = b0;
+    while (cz >= d2) {
+      cz -= d2;
+      if (++cy == d1) { cy = 0; if (++cx == d0) { cx = 0; ++b; } }
+    }
     const int64_t x = (int64_t)(lo0 + (cx << tsl)) + PCC_BIAS, y = (int64_t)(lo1 + (cy << tsl)) + PCC_BIAS,
                   z = (int64_t)(lo2 + (cz << tsl)) + PCC_BIAS;
     keys[r++] = ((int64_t)b << 48) | (x << 32) | (y << 16) | z;

@@ -292,6 +292,7 @@ def test_split_path_accuracy(cin, cout, ks):
     old_pair = S.PAIR_MIN_K
     S.PAIR_MIN_K = 1 << 30
     try:
+        L.call("pcc_set_mfma_split", 1)                               # (explicit: the environment may have selected the other path)
         got_split = n(S.conv_forward(t(f), pk, t(b), K, cin, cout, m, cs.n))
         L.call("pcc_set_mfma_split", 0)
         got_fp32 = n(S.conv_forward(t(f), pk, t(b), K, cin, cout, m, cs.n))

@@ -348,3 +348,40 @@ def test_dense_products_accuracy(spread):
     err = {k: (np.abs(v - want) / scale).max() for k, v in res.items()}
     assert err["h"] <= 4e-6, err
     assert err["h"] <= 3 * err["bf"] + 1e-7, err
+
+
+def test_pair_list_products_accuracy_with_spread_rows():
+    """5x5x5 convolution in the pair-list form on scaled fp16 pairs (`k_pair_h2`): rows whose magnitudes spread over
+    e^+-12 -- the scale is per input row and per (offset, column) of the weights -- against float64 and against the
+    six-term bf16 form (`pcc_set_gemm_h(0)`)."""
+    from unified_point_cloud_compression_amd import sparse as S, lib as L
+    rng = np.random.default_rng(17)
+    keys = cloud_keys(5, 40, 0.08, 1)
+    cs = _cs(keys, 1)
+    cin = cout = 128
+    K = 125
+    f = (np.maximum(rng.standard_normal((len(keys), cin)), 0) * np.exp(rng.standard_normal((len(keys), 1)) * 4)).astype(np.float32)
+    W = (rng.standard_normal((K, cin, cout)) / np.sqrt(cin * 8) * np.exp(rng.standard_normal((K, 1, cout)))).astype(np.float32)
+    m = cs.kernel_map(cs, 5)
+    nbr = co.kernel_map(keys, keys, 5, 1)
+    want = np.zeros((len(keys), cout))
+    f64, W64 = f.astype(np.float64), W.astype(np.float64)
+    mag = np.zeros((len(keys), 1))                                             # largest input-row magnitude feeding an output row
+    rowmax = np.abs(f64).max(1)
+    for k in range(K):
+        o = np.nonzero(nbr[k] >= 0)[0]
+        want[o] += f64[nbr[k, o]] @ W64[k]
+        mag[o, 0] = np.maximum(mag[o, 0], rowmax[nbr[k, o]])
+    res = {}
+    for name, h in (("h", 1), ("bf", 0)):
+        L.call("pcc_set_gemm_h", h)
+        try:
+            pk = S.PackedConv().get(torch.nn.Parameter(t(W)))
+            assert m.pair_plan() is not None                                   # sparse 5x5x5 map: the pair-list form runs
+            res[name] = n(S.conv_forward(t(f), pk, None, K, cin, cout, m, cs.n)).astype(np.float64)
+        finally:
+            L.call("pcc_set_gemm_h", 1)
+    scale = mag * np.abs(W64).max() * np.sqrt(cin) + 1e-300                    # size of one neighbour's contribution
+    err = {k: (np.abs(v - want) / scale).max() for k, v in res.items()}
+    assert err["h"] <= 2e-5 and err["h"] <= 4 * err["bf"] + 1e-7, err
+    assert not np.array_equal(res["h"], res["bf"])                             # the two forms really are different kernels

@@ -384,4 +384,6 @@ def test_pair_list_products_accuracy_with_spread_rows():
     scale = mag * np.abs(W64).max() * np.sqrt(cin) + 1e-300                    # size of one neighbour's contribution
     err = {k: (np.abs(v - want) / scale).max() for k, v in res.items()}
     assert err["h"] <= 2e-5 and err["h"] <= 4 * err["bf"] + 1e-7, err
-    assert not np.array_equal(res["h"], res["bf"])                             # the two forms really are different kernels
+    import os
+    if not os.environ.get("PCC_TEST_CHILD"):                                   # (the child run switches the fast paths off)
+        assert not np.array_equal(res["h"], res["bf"])                         # the two forms really are different kernels

@@ -21,6 +21,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32-input matrix peak (= the vector rate)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA peak (~2.5 PF)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md, HBM3E ~8 TB/s
 SPLIT_TERMS = 6                 # bf16 MFMA terms per fp32 product on the split path (k_conv_mfma_bf)
 BITS = 10
 
@@ -55,9 +56,16 @@ def build_model(device, seed=0, gain=3.0, coder="pcc_streams"):
     return model
 
 
-def step(model, pc, q):
+def plain(coords):
+    """What a decoder receives (`utils.py:461-465` hands `decompress` plain tensors): copies of the latent coordinates
+    WITHOUT the encoder's coordinate set / cached maps that `y.C` carries as Python attributes."""
+    return [c.clone() for c in coords]
+
+
+def step(model, pc, q, reuse_encoder_sets=False):
     out = model.compress(pc, q, block_size=1024)
-    rec = model.decompress(coordinates=out[3], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
+    coords = out[3] if reuse_encoder_sets else plain(out[3])
+    rec = model.decompress(coordinates=coords, strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
     return out, rec
 
 
@@ -78,8 +86,8 @@ def csrc_sha():
 PMC_FILE = os.path.join("profiles", "pmc_traffic.json")
 
 
-def pmc_traffic():
-    """HBM bytes per MFMA-conv launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE and
+def pmc_traffic(kernel="k_gemm_h2"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE and
     WRITE_SIZE in separate passes, KiB units, gfx950 FETCH x2 correction), with the hash of the kernel sources it was
     collected on.  (None, reason) when no measurement is committed or when it belongs to other kernel code."""
     try:
@@ -89,7 +97,11 @@ def pmc_traffic():
     now = csrc_sha()
     if rec.get("csrc_sha") != now:
         return None, f"stale: measured on csrc {rec.get('csrc_sha')}, running csrc {now} (re-run tools/pmc_traffic.py)"
-    return float(rec["hbm_bytes_per_launch"]), f"rocprofv3 PMC passes of `{rec.get('command')}` on csrc {now}, {PMC_FILE}"
+    k = (rec.get("by_kernel") or {}).get(kernel)
+    if k is None:
+        return None, f"{PMC_FILE} holds no entry for {kernel}"
+    return float(k["read"] + k["write"]), (f"rocprofv3 PMC passes of `{rec.get('command')}` on csrc {now}, {PMC_FILE}: "
+                                            f"{k['read'] / 1e9:.3f} GB read + {k['write'] / 1e9:.3f} GB written per launch of {kernel}")
 
 
 def mfma_shape(cin, cout):
@@ -132,55 +144,68 @@ def account_flops(model, pc, q):
 
     names = ("conv_forward", "convt_forward", "convt_forward_csr", "convt_forward_rows", "conv_head_forward",
              "convt_forward_csr_grid")
+    from unified_point_cloud_compression_amd import lib as L
+    import ctypes as C
     S.COUNT_PAIRS = True
     for nme, f in zip(names, (spy, spy_t, spy_c, spy_r, spy_h, spy_g)):
         setattr(S, nme, f)
+    L.call("pcc_prof_enable", 1)
     try:
         step(model, pc, q)
         torch.cuda.synchronize()
+        seq = (C.c_int32 * 4096)()
+        nseq = L.load().pcc_prof_sequence(seq, 4096)
+        forms = [L.FORM_NAMES[seq[i]] for i in range(min(nseq, 4096))]
     finally:
+        L.call("pcc_prof_enable", 0)
         S.COUNT_PAIRS = False
         for nme, f in zip(names, (orig, orig_t, orig_c, orig_r, orig_h, orig_g)):
             setattr(S, nme, f)
+    # Which kernel form each launch took -- and with it the 16-bit MFMA FLOPs executed per algorithmic FLOP: 3 (scaled fp16
+    # pairs: k_gemm_h2 / k_pair_h2), 6 (bf16 split), 2500 / 157.3 for the fp32-input kernels priced at their own peak -- comes
+    # from the library (`pcc_prof_collect_forms`, recorded at the launch), not from a copy of its dispatch rules.
     flops, launches, pairs_total, alg_bytes, exec_flops = 0.0, 0, 0, 0.0, 0.0
-    split_on = os.environ.get("PCC_MFMA_SPLIT", "1") != "0"
-    h_on = os.environ.get("PCC_GEMM_H", "1") != "0"
-    for kmap, K, cin, cout, n_out, n_in in calls:
-        pair_rows = isinstance(K, float)                  # K given as a float: kept-row transposed convolution (pair GEMM)
-        K = int(K)
-        kmap_is_map = not isinstance(kmap, int) and kmap is not None
-        dense, K = K < 0, abs(K)                          # K < 0: dense products of a generative transposed convolution
-        if not mfma_shape(cin, cout):
-            continue
+    by_form = {}
+    timed = [c for c in calls if mfma_shape(c[2], c[3])]
+    if len(forms) != len(timed):        # the spies and the library's timed launches are 1:1 by construction; say so if not
+        print(f"bench: {len(timed)} accounted launches but {len(forms)} timed by the library: forms unattributed", file=sys.stderr)
+        forms = ["other"] * len(timed)
+    for (kmap, K, cin, cout, n_out, n_in), form in zip(timed, forms):
+        K = abs(int(K))
         p = kmap if isinstance(kmap, int) else (kmap.pairs() if kmap is not None else n_out)
         fl = 2.0 * p * cin * cout
         flops += fl
-        # 16-bit MFMA FLOPs executed per algorithmic FLOP: 3 (dense products, scaled fp16 pairs: k_gemm_h2), 6 (bf16 split:
-        # k_conv_mfma_bf), or the fp32-input MFMA kernels priced at their own peak (2500 / 157.3)
-        if cin % 32 != 0 or not split_on:
-            terms = PEAK_BF16_MFMA_TFLOPS / PEAK_FP32_MFMA_TFLOPS
-        elif (dense and h_on and cin <= 256 and cin // 32 in (1, 2, 4, 6, 8) and K * cout >= 128 and
-              (-(-n_in // 128) + 7) // 8 * 8 * (-(-(K * cout) // 128)) >= 512):
-            terms = 3.0
-        elif (h_on and K >= max(64, S.PAIR_MIN_K) and cin >= S.PAIR_MIN_CIN and cin <= 256 and cin // 32 in (1, 2, 4, 6, 8)
-              and cout >= 128 and cout % 4 == 0 and (pair_rows or kmap_is_map)):
-            terms = 3.0                                   # gathered pair GEMM (k_pair_h2)
-        else:
-            terms = float(SPLIT_TERMS)
-        exec_flops += fl * terms
+        exec_flops += fl * FORM_TERMS[form]
+        f = by_form.setdefault(form, {"flops": 0.0, "launches": 0})
+        f["flops"] += fl
+        f["launches"] += 1
         # compulsory traffic of the layer: every feature row, weight, map entry, coordinate touched once
         alg_bytes += 4.0 * (n_in * cin + n_out * cout + K * cin * cout) + 8.0 * p + 16.0 * (n_in + n_out)
         pairs_total += p
         launches += 1
-    return flops, launches, pairs_total, alg_bytes, exec_flops
+    return flops, launches, pairs_total, alg_bytes, exec_flops, by_form
+
+
+FORM_TERMS = {"k_gemm_h2": 3.0, "k_pair_h2": 3.0, "k_gemm_bf2": 6.0, "pair_bf": 6.0, "k_conv_mfma_bf": 6.0,
+              "k_conv_mfma": PEAK_BF16_MFMA_TFLOPS / PEAK_FP32_MFMA_TFLOPS, "k_conv_wave16": PEAK_BF16_MFMA_TFLOPS / PEAK_FP32_MFMA_TFLOPS,
+              "other": 6.0}
+
+
+def collect_forms(lib):
+    """Event-timed launches since `pcc_prof_enable(1)`, by the kernel form each one took."""
+    import ctypes as C
+    n = len(lib.FORM_NAMES)
+    ms, la, fl, by = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)()
+    lib.check(lib.load().pcc_prof_collect_forms(ms, la, fl, by), "pcc_prof_collect_forms")
+    return {nme: {"ms": ms[i], "launches": la[i], "flops": fl[i], "bytes": by[i]} for i, nme in enumerate(lib.FORM_NAMES)}
 
 
 def cpu_baseline(threads=None):
-    """The oracle (numpy restatement, 'port'; MinkowskiEngine cannot run here) timed on this host's cores on bounded
-    samples of the same workload: the same synthetic surface at vox8 (1 warm-up, median of 3) and once at vox9, same
-    R2 architecture and weights recipe, encode + decode, harness of BASELINE.md section 3.  `value` is the vox9 figure
-    (closest to the benchmark's frame that fits the time bound); the full vox10 frame takes the oracle ~150 s on the
-    build container's 8 cores (5.2 k points/s, tests/golden/make_fullsize.py), see DESIGN.md section 5."""
+    """The oracle (numpy restatement, 'port'; MinkowskiEngine cannot run here) timed on this host's cores with the
+    harness of BASELINE.md section 3 on a bounded sample of the same workload: the same synthetic surface at vox9
+    (198 k points, a quarter of the benchmark frame), same R2 architecture and weights recipe, encode + decode,
+    1 warm-up run, median of 3.  The benchmark's own vox10 frame takes the oracle ~160 s (build container, 6 threads:
+    `oracle_seconds` of tests/golden/full_config2_vox10.npz, quoted in `sample`) -- too long for the default run."""
     from oracle import codec
     from unified_point_cloud_compression_amd import synth
     threads = threads or min(os.cpu_count() or 1, 16)           # the GPU box's CPU share for one GPU
@@ -199,17 +224,24 @@ def cpu_baseline(threads=None):
         codec.decompress(P, codec.R2_CONFIG, blocks, threads=threads)
         return time.time() - t0
 
-    pc8, pc9 = synth.surface_cloud(0, 8), synth.surface_cloud(0, 9)
-    once(pc8)
-    t8 = sorted(once(pc8) for _ in range(3))[1]
-    t9 = once(pc9)
+    pc9 = synth.surface_cloud(0, 9)
+    once(pc9)                                                   # warm-up (BLAS thread pools, page faults of the work buffers)
+    runs = sorted(once(pc9) for _ in range(3))
+    t9 = runs[1]
     if limit is not None:
         limit.restore_original_limits()
+    vox10 = ""
+    try:
+        fx = np.load(os.path.join(ROOT, "tests", "golden", "full_config2_vox10.npz"))
+        sec = float(np.sum(fx["oracle_seconds"]))
+        vox10 = (f"; the benchmark's vox10 frame ({int(fx['n_points'])} points): {sec:.0f} s = {int(fx['n_points']) / sec:.0f} points/s "
+                 f"on the build container (6 threads, tests/golden/make_fullsize.py)")
+    except Exception:
+        pass
     return {"value": pc9.shape[0] / t9, "unit": "points/s", "cores": threads, "kind": "port",
-            "points_per_s_vox8": pc8.shape[0] / t8,
-            "sample": f"oracle (numpy restatement; MinkowskiEngine unavailable) encode+decode of the same synthetic surface, "
-                      f"R2 architecture: vox9 ({pc9.shape[0]} points) one run {t9:.1f} s -> value; vox8 ({pc8.shape[0]} points) "
-                      f"1 warm-up + median of 3 = {t8:.1f} s"}
+            "runs_s": [round(r, 2) for r in runs],
+            "sample": f"oracle (numpy restatement; MinkowskiEngine unavailable) encode+decode of the same synthetic surface at vox9 "
+                      f"({pc9.shape[0]} points), R2 architecture: 1 warm-up, median of 3 = {t9:.1f} s on {threads} threads{vox10}"}
 
 
 def oracle_figures(bits):
@@ -250,7 +282,7 @@ def true_geometry_ms(model, pc, q, steps=5, warmup=2):
 
     def one():
         out = model.compress(pc, q, block_size=1024)
-        return model.decompress(coordinates=out[3], strings=out[0], shape=out[1], k=out[2], q_vals=out[4], probe=probe)
+        return model.decompress(coordinates=plain(out[3]), strings=out[0], shape=out[1], k=out[2], q_vals=out[4], probe=probe)
 
     for _ in range(warmup):
         rec = one()
@@ -371,30 +403,66 @@ def main():
     for _ in range(args.warmup):
         step(model, pc, q)
     torch.cuda.synchronize()
-    flops_step, launches_step, pairs_step, alg_bytes_step, exec_flops_step = (account_flops(model, pc, q) if rank == 0
-                                                                              else (0.0, 0, 0, 0.0, 0.0))
+    (flops_step, launches_step, pairs_step, alg_bytes_step, exec_flops_step, flops_by_form) = (
+        account_flops(model, pc, q) if rank == 0 else (0.0, 0, 0, 0.0, 0.0, {}))
 
-    lib.call("pcc_prof_enable", 1 if rank == 0 else 0)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    t_enc = 0.0
-    step_marks = []
-    for _ in range(args.steps):
-        te = time.time()
-        out = model.compress(pc, q, block_size=1024)
+    def timed_loop(steps, reuse_encoder_sets=False):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides.  The decoder gets PLAIN coordinate tensors
+        (`plain`): it rebuilds every coordinate set, map and pair list from them, as a decoder reading a bitstream must."""
+        barrier()
         torch.cuda.synchronize()
-        t_enc += time.time() - te
-        rec = model.decompress(coordinates=out[3], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
-        step_marks.append(time.time())          # host time only (no sync): the next compress starts with a size read
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.time() - t0
-    import ctypes as C
-    conv_ms, conv_launches = C.c_double(0), C.c_int64(0)
-    if rank == 0:
-        lib.check(lib.load().pcc_prof_collect(C.byref(conv_ms), C.byref(conv_launches)), "pcc_prof_collect")
+        t0 = time.time()
+        t_enc, marks = 0.0, []
+        for _ in range(steps):
+            te = time.time()
+            out = model.compress(pc, q, block_size=1024)
+            torch.cuda.synchronize()
+            t_enc += time.time() - te
+            coords = out[3] if reuse_encoder_sets else plain(out[3])
+            rec = model.decompress(coordinates=coords, strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
+            marks.append(time.time())           # host time only (no sync): the next compress starts with a size read
+        torch.cuda.synchronize()
+        barrier()
+        return time.time() - t0, t_enc, [t0] + marks, out, rec
+
+    # pass 1 -- the one `value` comes from: no event records, no profiler hooks inside
     lib.call("pcc_prof_enable", 0)
+    dt, t_enc, step_marks, out, rec = timed_loop(args.steps)
+
+    # pass 2 (rank 0, un-timed for `value`): the same steps with a HIP-event pair around every MFMA launch, recorded on the
+    # launch stream inside the library -> launch durations by kernel form (roofline)
+    forms = None
+    if rank == 0:
+        lib.call("pcc_prof_enable", 1)
+        ev_steps = min(args.steps, 10)
+        for _ in range(ev_steps):
+            step(model, pc, q)
+        torch.cuda.synchronize()
+        forms = collect_forms(lib)
+        lib.call("pcc_prof_enable", 0)
+        for f in forms.values():
+            f["ms_per_step"] = f.pop("ms") / ev_steps
+            f["launches_per_step"] = f.pop("launches") / ev_steps
+            f["flops"] /= ev_steps
+            f["bytes"] /= ev_steps
+
+    # pass 3 (rank 0): the same step under the stricter arithmetic switches, so that the figure behind `dtype: f32` stands
+    # beside the headline: dense / pair products as six bf16 terms (24-bit split of both operands) instead of three fp16
+    # terms; and every product on the fp32-input MFMA instructions
+    strict_ms = fp32_ms = cached_dec_ms = None
+    if rank == 0 and not args.no_aux:
+        def quick(n=5, **kw):
+            for _ in range(2):
+                step(model, pc, q, **kw)
+            d, te, _, _, _ = timed_loop(n, **kw)
+            return d / n * 1e3, (d - te) / n * 1e3
+        lib.call("pcc_set_gemm_h", 0)
+        strict_ms, _ = quick()
+        lib.call("pcc_set_mfma_split", 0)
+        fp32_ms, _ = quick()
+        lib.call("pcc_set_mfma_split", 1)
+        lib.call("pcc_set_gemm_h", 1)
+        _, cached_dec_ms = quick(reuse_encoder_sets=True)     # round-2 figure: decoder re-using the encoder's sets and maps
 
     # auxiliary (un-timed for `value`): the same step with integer symbols handed across the entropy-coder boundary,
     # i.e. the SURVEY 8a hot path alone (sparse convolutions + likelihood kernels), for comparison across rounds
@@ -437,14 +505,58 @@ def main():
               "d1_psnr_BA": m["BA_psnr_mse"], "y_psnr_sym": m["sym_y_psnr"], "oracle": oracle_figures(args.bits)}
 
     if rank == 0:
-        traffic, traffic_note = pmc_traffic()
         split_on = os.environ.get("PCC_MFMA_SPLIT", "1") != "0"
-        # roof of the ALGORITHMIC FLOPs of this mix of launches: the dense 16-bit MFMA peak divided by the 16-bit MFMA FLOPs
-        # executed per algorithmic FLOP (3 for the dense products, 6 for the gathered convolutions, see account_flops)
-        peak = PEAK_BF16_MFMA_TFLOPS * flops_step / exec_flops_step if exec_flops_step else PEAK_FP32_MFMA_TFLOPS
         ms_step = dt_max / args.steps * 1e3
-        # conv launches: only MFMA-shaped ones are event-timed inside the library
-        ach = (flops_step * args.steps / (conv_ms.value * 1e-3) / 1e12) if conv_ms.value > 0 else None
+        # ---- roofline: per kernel form, from the event-timed pass; the DOMINANT kernel is the form with the most time ----
+        kernels = {}
+        for nme, f in forms.items():
+            if f["launches_per_step"] <= 0:
+                continue
+            fl = flops_by_form.get(nme, {}).get("flops", 0.0)                 # algorithmic FLOPs per step (pair counts read back)
+            k = {"ms_per_step": f["ms_per_step"], "launches_per_step": f["launches_per_step"],
+                 "alg_tflops": fl / (f["ms_per_step"] * 1e-3) / 1e12 if f["ms_per_step"] > 0 else None,
+                 "mfma_roof_tflops": PEAK_BF16_MFMA_TFLOPS / FORM_TERMS[nme]}
+            k["mfma_frac"] = k["alg_tflops"] / k["mfma_roof_tflops"] if k["alg_tflops"] else None
+            if f["bytes"] > 0:                                                  # dense products: the library knows their operand / result bytes
+                k["alg_gbs"] = f["bytes"] / (f["ms_per_step"] * 1e-3) / 1e9
+                k["hbm_frac"] = k["alg_gbs"] / PEAK_HBM_GBS
+                k["flop_per_byte"] = f["flops"] / f["bytes"]
+                ridge = k["mfma_roof_tflops"] * 1e12 / (PEAK_HBM_GBS * 1e9)
+                k["bound"] = "hbm" if k["flop_per_byte"] < ridge else "mfma"
+            else:
+                k["bound"] = "mfma"                                             # gathered forms: priced against the matrix roof only
+            kernels[nme] = k
+        dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"]) if kernels else None
+        d, df = (kernels[dom], forms[dom]) if dom else ({}, {})
+        traffic, traffic_note = pmc_traffic(dom) if dom else (None, "no timed launches")
+        conv_ms = sum(k["ms_per_step"] for k in kernels.values())
+        fam_ach = flops_step / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
+        fam_peak = PEAK_BF16_MFMA_TFLOPS * flops_step / exec_flops_step if exec_flops_step else PEAK_FP32_MFMA_TFLOPS
+        if d.get("bound") == "hbm":
+            roof = {"bound": "hbm", "achieved": d["alg_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["hbm_frac"]}
+        else:
+            roof = {"bound": "mfma", "achieved": d.get("alg_tflops"), "peak": d.get("mfma_roof_tflops"), "unit": "TFLOP/s",
+                    "frac": d.get("mfma_frac")}
+        lps = max(df.get("launches_per_step", 0), 1e-9)
+        roof.update({
+            "kernel": dom, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
+            "alg_bytes_per_launch": df.get("bytes", 0.0) / lps if df.get("bytes") else None,
+            "alg_flops_per_launch": (flops_by_form.get(dom, {}).get("flops", 0.0) / lps) if dom else None,
+            "avg_launch_ms": df.get("ms_per_step", 0.0) / lps, "launches_per_step": df.get("launches_per_step"),
+            "mfma_frac": d.get("mfma_frac"), "hbm_frac": d.get("hbm_frac"), "flop_per_byte": d.get("flop_per_byte"),
+            "note": ("dominant kernel = the event-timed form with the most time per step. algorithmic bytes of a dense product = "
+                     "4 B x (rows x depth + rows x columns + depth x columns), algorithmic FLOPs = 2 x rows x depth x columns "
+                     "(DESIGN.md section 4); durations from HIP events on the launch stream, recorded inside the library in a "
+                     "separate pass (never inside the loop `value` is timed on); mfma roof = dense 16-bit MFMA peak 2500 TFLOP/s / "
+                     "MFMA terms per product of the form"),
+            "kernels": kernels,
+            # all event-timed MFMA launches together (round-2 style figure, kept for comparison across rounds)
+            "mfma_family": {"achieved": fam_ach, "peak": fam_peak, "unit": "TFLOP/s", "frac": (fam_ach / fam_peak) if fam_ach else None,
+                            "executed_16bit_tflops": (fam_ach * exec_flops_step / flops_step) if (fam_ach and flops_step) else None,
+                            "vs_fp32_mfma_peak": (fam_ach / PEAK_FP32_MFMA_TFLOPS) if fam_ach else None,
+                            "flop_per_step": flops_step, "pairs_per_step": pairs_step, "launches_per_step": launches_step,
+                            "conv_ms_per_step": conv_ms, "alg_bytes_per_launch_survey_8d": (alg_bytes_step / launches_step) if launches_step else None},
+        })
         line = {
             "metric": "points/sec encode+decode, longdress vox10, 1 GPU; bpp & D1-PSNR parity",
             "value": total_points * args.steps / dt_max,
@@ -455,35 +567,23 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: one synthetic longdress-like vox{args.bits} frame per GPU "
                                    f"({n_points} points on rank 0), R2 architecture, random-init weights, q=[[0.5,0.5]], "
-                                   f"1 block; entropy coder in the timed region: {args.coder}",
-                       "arithmetic": ("fp32 features and accumulation; matrix products on the 16-bit MFMA pipe at fp32 accuracy: "
-                                      "gathered convolutions from an exact 3-way bf16 split of both operands (6 terms, "
-                                      "tests/test_gpu_map_conv.py::test_split_path_accuracy), dense products of the generative "
-                                      "convolutions from row/column-scaled fp16 pairs (3 terms, ::test_dense_products_accuracy)")
+                                   f"1 block; entropy coder in the timed region: {args.coder}; the decoder starts from plain "
+                                   f"coordinate tensors (no coordinate set, map or pair list of the encoder is re-used)",
+                       "arithmetic": ("fp32 features and accumulation; matrix products on the 16-bit MFMA pipe: gathered 3x3x3 "
+                                      "convolutions from an exact 3-way bf16 split of both operands (6 terms, 24 bits); dense and "
+                                      "pair-list products from row/column-scaled fp16 pairs (3 terms, >= 22 bits relative to the "
+                                      "row / column maximum; worst-case bound and adversarial cases: DESIGN.md section 4b, "
+                                      "tests/test_gpu_fp16_pairs.py). `ms_per_step_strict` is the same step with every product "
+                                      "on the six-term 24-bit form, `ms_per_step_fp32_mfma` on the fp32-input MFMA instructions")
                        if split_on else "fp32-input MFMA",
+                       "ms_per_step_strict": strict_ms, "ms_per_step_fp32_mfma": fp32_ms,
+                       "decode_ms_reusing_encoder_sets": cached_dec_ms,
                        "bpp_y_z_strings": bpp, "bpp_likelihood": rd["bpp_likelihood"], "d1_psnr": rd["d1_psnr_sym"],
                        "rate_distortion": rd, "ms_per_step_without_entropy_coder": hot_ms,
                        "frames_per_step": world, "encode_ms": recs[0][2] * 1e3, "decode_ms": recs[0][3] * 1e3,
-                       "step_ms_rank0": [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_marks[:-1], step_marks)],
+                       "step_ms_rank0": [round((b - a) * 1e3, 2) for a, b in zip(step_marks[:-1], step_marks[1:])],
                        "device": arch, "cus": cu},
-            # dominant kernel family: the MFMA convolutions (k_conv_mfma_bf = fp32 products as 6 exact bf16 MFMA terms).
-            # `achieved` = ALGORITHMIC fp32 FLOPs (2*P*Cin*Cout) / event-timed launch durations; `peak` = the roof of that
-            # arithmetic for algorithmic FLOPs, i.e. the dense bf16 MFMA peak / 6 terms.  (The fp32-input MFMA pipe used in
-            # round 1 peaks at 157.3 TFLOP/s: `vs_fp32_mfma_peak`.)
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (ach / peak) if ach else None, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
-                         "alg_bytes_per_launch": (alg_bytes_step / launches_step) if launches_step else None,
-                         "kernel": "k_gemm_h2 (dense products of pcc_convt_fwd_csr*, 3 fp16 MFMA terms) + k_conv_mfma_bf (pcc_conv_fwd / "
-                                   "pcc_conv_fwd_pairs, 6 bf16 MFMA terms)" if split_on else "k_conv_mfma (fp32-input MFMA)",
-                         "peak_note": ("dense 16-bit MFMA peak 2500 TFLOP/s / executed 16-bit FLOPs per algorithmic FLOP "
-                                       f"({exec_flops_step / flops_step:.2f} for this mix of launches)" if (split_on and flops_step)
-                                       else "dense fp32-input MFMA peak"),
-                         "executed_16bit_tflops": (ach * exec_flops_step / flops_step) if (ach and flops_step) else None,
-                         "vs_fp32_mfma_peak": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
-                         "flop_per_step": flops_step, "pairs_per_step": pairs_step, "launches_per_step": launches_step,
-                         "avg_launch_ms": (conv_ms.value / conv_launches.value) if conv_launches.value else None,
-                         "conv_ms_per_step": conv_ms.value / args.steps},
+            "roofline": roof,
         }
         if world == 1 and not args.no_aux:
             line["config"]["aux_true_geometry"] = true_geometry_ms(model, pc, q)

@@ -13,8 +13,17 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
  *   - functions return 0 on success, a negative PCC_E* code otherwise; pcc_last_error()
  *     gives the message of the calling thread's last failure; no exceptions, no ownership
- *     transfer, no allocation: outputs and workspaces are caller-allocated (sizes from the
- *     *_ws_bytes / *_elems queries); nothing here synchronises the stream;
+ *     transfer: outputs and workspaces are caller-allocated (sizes from the *_ws_bytes /
+ *     *_elems queries).  Two exceptions, owned by the library per process: a grow-only device
+ *     scratch for the 16-bit operand planes / split-K partial tiles of the convolution entry
+ *     points (pcc_conv_fwd, pcc_conv_fwd_pairs, pcc_convt_fwd*, pcc_gdn_fwd) and a small table
+ *     buffer of pcc_convt_fwd_csr*.  They are allocated with hipMalloc outside the caller's
+ *     allocator, and GROWING one synchronises the device once (hipDeviceSynchronize + hipFree);
+ *     otherwise nothing here synchronises the stream;
+ *   - threading: ONE stream per device at a time for the convolution entry points (they share
+ *     the scratch above in stream order); calls from two host threads or on two streams of the
+ *     same device must be serialised by the caller.  The pure coordinate / entropy entry points
+ *     keep no state;
  *   - coordinates are packed int64 keys  b<<48 | (x+2^15)<<32 | (y+2^15)<<16 | (z+2^15);
  *     a coordinate set is a strictly ascending key array ("canonical order" = the order
  *     `utils.sort_tensor` produces, utils.py:142-165);
@@ -172,14 +181,16 @@ int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t cin, const fl
 int pcc_map_from_csr(const int32_t* first, const int32_t* pair_ids, int64_t n_out, int32_t kernel_size, int32_t* hdr,
                      int32_t* nbr, void* stream);
 size_t pcc_expand_grid_csr_ws_bytes(int64_t n_out);
+/* d_total (device int64, nullable) receives first[n_out], the number of pairs: lets the caller read that size together
+ * with others it is waiting for instead of indexing first[] from the host. */
 int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
                                const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in, int64_t n_in,
-                               int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes, void* stream);
+                               int32_t* first, int32_t* pair_ids, int64_t* d_total, void* ws, size_t ws_bytes, void* stream);
 /* the same lists, kernel offsets of the pair ids numbered z fastest (iz + KS*iy + KS*KS*ix) -- for product buffers laid out
  * [input row][kx][ky][kz][c]: the composite levels gather z-runs of output rows from adjacent memory */
 int pcc_coords_expand_grid_csr_zk(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
                                const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in, int64_t n_in,
-                               int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes, void* stream);
+                               int32_t* first, int32_t* pair_ids, int64_t* d_total, void* ws, size_t ws_bytes, void* stream);
 /* dense [K][n_out] view of any map (testing / inspection): -1 where no pair */
 int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows, int64_t n_out,
                      int32_t K, int32_t* dense, void* stream);
@@ -460,6 +471,21 @@ int pcc_prof_enable(int32_t on);
 /* sums over launches since the last reset; also resets. flops = 2*P*Cin*Cout needs the pair
  * counts, which the caller accumulates itself (d_pairs). Synchronises the recorded events. */
 int pcc_prof_collect(double* h_conv_ms, int64_t* h_conv_launches);
+/* The same timings split by the kernel form each launch actually took (so that a report never has to mirror the dispatch
+ * rules): arrays of PCC_FORM_COUNT entries.  flops / bytes: algorithmic work of the dense products (rows x columns x depth,
+ * 4 bytes per operand / result element), 0 for the gathered forms whose pair counts live on the device.  Also resets. */
+#define PCC_FORM_OTHER 0      /* anything else that is event-timed */
+#define PCC_FORM_GEMM_H2 1    /* k_gemm_h2: dense products, scaled fp16 pairs, 3 MFMA terms */
+#define PCC_FORM_GEMM_BF2 2   /* k_gemm_bf2: dense products, bf16 split, 6 terms */
+#define PCC_FORM_PAIR_H2 3    /* k_pair_h2: gathered pair GEMM, 3 terms */
+#define PCC_FORM_PAIR_BF 4    /* gathered pair GEMM, 6 terms */
+#define PCC_FORM_CONV_BF 5    /* k_conv_mfma_bf: gathered output-stationary convolution, 6 terms */
+#define PCC_FORM_CONV_F32 6   /* k_conv_mfma: fp32-input MFMA */
+#define PCC_FORM_WAVE16 7     /* k_conv_wave16 / wave16z: narrow outputs, fp32-input 16x16x4 MFMA */
+#define PCC_FORM_COUNT 8
+int pcc_prof_collect_forms(double* h_ms, int64_t* h_launches, double* h_flops, double* h_bytes);
+/* forms of the timed launches recorded so far, in launch order (up to cap entries); returns their number; no reset */
+int64_t pcc_prof_sequence(int32_t* h_forms, int64_t cap);
 
 #ifdef __cplusplus
 }

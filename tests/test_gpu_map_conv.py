@@ -174,6 +174,39 @@ def test_generative_transpose_features(cin, cout, ks):
     assert_close(n(got2), want, what="generative transpose (output stationary)")
 
 
+@pytest.mark.parametrize("ks", [2, 3, 5])
+def test_generative_transpose_stride1_csr(ks):
+    """`ME.MinkowskiGenerativeConvolutionTranspose(stride=1)`: input pitch == output pitch, so EVERY kernel offset is a
+    compatible source of an output row (ks per axis, not ceil(ks / 2) as when up-sampling by 2).  The CSR pair lists built
+    through the grid index must hold all of them (round-2 advisor finding: the count pass probed (ks+1)/2 cells per axis)."""
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    from unified_point_cloud_compression_amd import sparse as S
+    keys = cloud_keys(11 + ks, 12, 0.15, 2, batch=2)
+    cs = _cs(keys, 2, 2)
+    out = cs.expand(ks, 2)
+    out_keys = co.expand_keys(keys, ks, 2)
+    assert np.array_equal(n(out.keys[:out.n]), out_keys)
+    first, pair_ids = cs.csr_map(ks, 2)
+    first, pair_ids = n(first), n(pair_ids)
+    K = ks ** 3
+    assert first[out.n] == len(keys) * K                      # every (input row, offset) is exactly one pair
+    want = co.kernel_map(keys, out_keys, ks, 2, transposed=True)          # [K, n_out] input row or -1
+    for o in (0, 1, out.n // 2, out.n - 1):
+        ids = pair_ids[first[o]:first[o + 1]]
+        assert np.array_equal(np.sort(ids), np.sort(np.array([want[k, o] * K + k for k in range(K) if want[k, o] >= 0])))
+        assert np.all(np.diff(ids // K) >= 0)                  # ascending input row
+    cin, cout = 32, 32
+    rng = np.random.default_rng(4)
+    f = rng.standard_normal((len(keys), cin)).astype(np.float32)
+    layer = ME.MinkowskiGenerativeConvolutionTranspose(cin, cout, kernel_size=ks, stride=1, bias=True, dimension=3).to(dev())
+    x = ME.SparseTensor(coordinates=t(co.unpack_keys(keys)), features=t(f), tensor_stride=2)
+    with torch.no_grad():
+        y = layer(x)
+    W, b = n(layer.kernel).reshape(K, cin, cout), n(layer.bias)
+    pairs = codec.kernel_map_pairs(keys, out_keys, ks, 2, transposed=True)
+    assert_close(n(y.F), codec.conv_pairs(f, W, b, pairs, len(out_keys)), what="stride-1 generative transpose")
+
+
 def test_conv_1x1_and_row_tails():
     """K=1 needs no map; row counts that are not multiples of the 128-row tile."""
     from unified_point_cloud_compression_amd import sparse as S

@@ -46,7 +46,7 @@ def process(i):
     torch.cuda.synchronize(); t0 = time.time()
     out = model.compress(pc, q, block_size=bs)
     torch.cuda.synchronize(); t1 = time.time()
-    rec = model.decompress(coordinates=out[3], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
+    rec = model.decompress(coordinates=[c.clone() for c in out[3]], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
     torch.cuda.synchronize(); t2 = time.time()
     rep = metrics.pointcloud_metrics(pc, rec, resolution=(1 << args.bits[i]) - 1)
     extra[i] = (rep["sym_psnr_mse"], rep["sym_y_psnr"], len(out[0]))

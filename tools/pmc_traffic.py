@@ -37,12 +37,18 @@ def collect(out):
 
 def parse(out, dst):
     res = {}
+    per = {}                                  # base kernel name -> {counter: [KiB total, launches]}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         files = glob.glob(os.path.join(out, ctr, "**", "*counter_collection.csv"), recursive=True)
         assert files, f"no counter_collection csv under {out}/{ctr}"
         tot, launches = 0.0, 0
         for r in csv.DictReader(open(files[0])):
             name = r["Kernel_Name"]
+            if r["Counter_Name"] == ctr:
+                base = re.sub(r"^void ", "", name).split("(")[0].split("<")[0]
+                e = per.setdefault(base, {}).setdefault(ctr, [0.0, 0])
+                e[0] += float(r["Counter_Value"])
+                e[1] += 1
             conv = ("k_conv_wave16" in name or re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>", name)
                     or re.search(r"k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0>", name) or re.search(r"k_gemm_(bf2|h2)<\d+>|k_pair_h2<\d+>", name))                                   # MODE_CONV only
             if r["Counter_Name"] == ctr and conv:
@@ -56,6 +62,11 @@ def parse(out, dst):
     rec = {"kernel": "k_gemm_h2 / k_pair_h2 / k_gemm_bf2 + k_conv_mfma_bf<*,MODE_CONV> + k_conv_mfma<*,MODE_CONV> + k_conv_wave16* (the event-timed MFMA launches)", "launches": n,
            "hbm_read_bytes_per_launch": read, "hbm_write_bytes_per_launch": write,
            "hbm_bytes_per_launch": read + write,
+           # the same, kernel by kernel (bench.py quotes the dominant kernel's entry): bytes per launch
+           "by_kernel": {k: {"launches": v["WRITE_SIZE"][1],
+                             "read": 2.0 * v["FETCH_SIZE"][0] * 1024 / max(v["FETCH_SIZE"][1], 1),
+                             "write": v["WRITE_SIZE"][0] * 1024 / max(v["WRITE_SIZE"][1], 1)}
+                         for k, v in per.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v and k.startswith("k_")},
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), KiB*1024, FETCH x2 (gfx950)",
            "command": " ".join(BENCH), "csrc_sha": csrc_sha()}
     json.dump(rec, open(dst, "w"), indent=1)

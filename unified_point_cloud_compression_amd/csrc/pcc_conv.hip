@@ -2135,11 +2135,23 @@ static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_ev_pool;
 static size_t g_ev_used = 0;
 static int64_t g_launches = 0;
+// which kernel form a timed launch took, with the work the library itself knows (dense products: rows x columns x depth;
+// gathered forms report 0 -- their pair counts live on the device, the caller accounts them)
+struct ProfRec { int form; double flops, bytes; };
+static std::vector<ProfRec> g_prof_recs;
+static ProfRec g_form = {PCC_FORM_OTHER, 0.0, 0.0};
+static void prof_note(int form, double flops, double bytes) { g_form = {form, flops, bytes}; }
+static void prof_push() {
+  g_prof_recs.push_back(g_form);
+  g_form = {PCC_FORM_OTHER, 0.0, 0.0};
+  ++g_launches;
+}
 
 extern "C" int pcc_prof_enable(int32_t on) {
   g_prof_on = on != 0;
   g_ev_used = 0;
   g_launches = 0;
+  g_prof_recs.clear();
   return PCC_OK;
 }
 
@@ -2166,6 +2178,30 @@ extern "C" int pcc_prof_collect(double* h_conv_ms, int64_t* h_conv_launches) {
   if (h_conv_launches) *h_conv_launches = g_launches;
   g_ev_used = 0;
   g_launches = 0;
+  g_prof_recs.clear();
+  return PCC_OK;
+}
+
+extern "C" int64_t pcc_prof_sequence(int32_t* h_forms, int64_t cap) {
+  const int64_t n = (int64_t)g_prof_recs.size();
+  for (int64_t i = 0; i < n && i < cap && h_forms; ++i) h_forms[i] = g_prof_recs[(size_t)i].form;
+  return n;
+}
+
+extern "C" int pcc_prof_collect_forms(double* h_ms, int64_t* h_launches, double* h_flops, double* h_bytes) {
+  PCC_REQUIRE(h_ms && h_launches && h_flops && h_bytes, "pcc_prof_collect_forms: NULL array");
+  for (int f = 0; f < PCC_FORM_COUNT; ++f) { h_ms[f] = 0.0; h_launches[f] = 0; h_flops[f] = 0.0; h_bytes[f] = 0.0; }
+  for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_prof_recs.size(); i += 2) {
+    PCC_CHECK_HIP(hipEventSynchronize(g_ev_pool[i + 1]));
+    float t = 0.f;
+    PCC_CHECK_HIP(hipEventElapsedTime(&t, g_ev_pool[i], g_ev_pool[i + 1]));
+    const ProfRec& r = g_prof_recs[i / 2];
+    const int f = (r.form >= 0 && r.form < PCC_FORM_COUNT) ? r.form : PCC_FORM_OTHER;
+    h_ms[f] += t; h_launches[f] += 1; h_flops[f] += r.flops; h_bytes[f] += r.bytes;
+  }
+  g_ev_used = 0;
+  g_launches = 0;
+  g_prof_recs.clear();
   return PCC_OK;
 }
 
@@ -2261,6 +2297,7 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
     if (!a.feath) PCC_TRY(make_planes_h(a, s));
     a.dbg = g_dbg;
     const dim3 g2 = grid(128);
+    prof_note(PCC_FORM_GEMM_H2, 2.0 * a.n_out * a.cin * a.cout, 4.0 * ((double)a.n_out * a.cin + (double)a.n_out * a.cout + (double)a.cin * a.cout));
     switch (a.ppo) {
       case 1: k_gemm_h2<1><<<g2, 256, 0, s>>>(a); break;
       case 2: k_gemm_h2<2><<<g2, 256, 0, s>>>(a); break;
@@ -2292,6 +2329,7 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
       bn == 128 && tiles(128) * gy >= want && (size_t)128 * a.cout * 4 < (1ull << 31)) {
     const dim3 g2 = grid(128);
     bool done = true;
+    prof_note(PCC_FORM_GEMM_BF2, 2.0 * a.n_out * a.cin * a.cout, 4.0 * ((double)a.n_out * a.cin + (double)a.n_out * a.cout + (double)a.cin * a.cout));
     switch (a.ppo) {
       case 1: k_gemm_bf2<1><<<g2, 256, 0, s>>>(a); break;
       case 2: k_gemm_bf2<2><<<g2, 256, 0, s>>>(a); break;
@@ -2302,6 +2340,7 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
     }
     if (done) { PCC_LAUNCH_CHECK(); return PCC_OK; }
   }
+  prof_note(split ? PCC_FORM_CONV_BF : PCC_FORM_CONV_F32, (!a.hdr && !a.pair_in) ? 2.0 * a.n_out * a.cin * a.cout : 0.0, 0.0);
 #define PCC_LAUNCH_MFMA(WM, WN, TM, TN, BMV)                                                     \
   do {                                                                                           \
     if (split) k_conv_mfma_bf<WM, WN, TM, TN, MODE><<<grid(BMV), 256, 0, s>>>(a);                \
@@ -2342,6 +2381,7 @@ static int launch_wave16(const Wave16Args& a, hipStream_t s) {
     PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_wave16z<CIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_set |= 1ull << (dev & 63);
   }
+  prof_note(PCC_FORM_WAVE16, 0.0, 0.0);
   const long long tiles = pcc_cdiv(a.n_out, 32) + (a.rows ? PCC_MAP_MAX_SEG : 0);
   long long want = pcc_cdiv(tiles, 8);
   want = (want + 7) / 8 * 8;                                     // multiple of 8: one contiguous tile range per XCD
@@ -2432,7 +2472,7 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
   }
   if (timed) {
     PCC_TRY(prof_event(&e1, s));
-    ++g_launches;
+    prof_push();
   }
   return PCC_OK;
 }
@@ -2568,7 +2608,7 @@ extern "C" int pcc_conv_head_fwd(const float* feat, int64_t n, int32_t cin, cons
   else PCC_TRY(launch_wave16<64>(a, s));
   if (g_prof_on) {
     PCC_TRY(prof_event(&e1, s));
-    ++g_launches;
+    prof_push();
   }
   ThinGatherArgs g;
   g.t = (const float*)ws; g.bias = bias2; g.hdr = hdr; g.nbr = nbr; g.rows = nullptr; g.out = logits; g.n_in = n; g.n_out = n;
@@ -2750,6 +2790,7 @@ extern "C" int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t ci
     const bool split = split_ok(a);
     const bool pair_h = split && g_gemm_h && conv_has_h(K, cin, cout) && (size_t)n_in * cin * 4 <= (size_t)BUF_MAX_BYTES &&
                         (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8);
+    prof_note(pair_h ? PCC_FORM_PAIR_H2 : split ? PCC_FORM_PAIR_BF : PCC_FORM_CONV_F32, 0.0, 0.0);
     if (pair_h) {                                   // scaled fp16 pairs, three MFMA terms (k_pair_h2)
       PCC_TRY(make_planes_h(a, s));
       switch (a.ppo) {
@@ -2768,7 +2809,7 @@ extern "C" int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t ci
     PCC_LAUNCH_CHECK();
     if (g_prof_on) {
       PCC_TRY(prof_event(&e1, s));
-      ++g_launches;
+      prof_push();
     }
   }
   PairReduceArgs r;
@@ -2951,6 +2992,7 @@ extern "C" int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t ci
     const bool split = split_ok(a);
     const bool pair_h = split && g_gemm_h && conv_has_h(K, cin, cout) && (size_t)n_in * cin * 4 <= (size_t)BUF_MAX_BYTES &&
                         (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8);
+    prof_note(pair_h ? PCC_FORM_PAIR_H2 : split ? PCC_FORM_PAIR_BF : PCC_FORM_CONV_F32, 0.0, 0.0);
     if (pair_h) {                                   // scaled fp16 pairs, three MFMA terms (k_pair_h2)
       PCC_TRY(make_planes_h(a, s));
       switch (a.ppo) {
@@ -2969,7 +3011,7 @@ extern "C" int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t ci
     PCC_LAUNCH_CHECK();
     if (g_prof_on) {
       PCC_TRY(prof_event(&e1, s));
-      ++g_launches;
+      prof_push();
     }
   }
   CsrReduceArgs r;
@@ -3118,7 +3160,7 @@ extern "C" int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, co
   PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));
   if (g_prof_on) {
     PCC_TRY(prof_event(&e1, s));
-    ++g_launches;
+    prof_push();
   }
   // 2) ordered gather-sum through the transposed map
   GatherArgs g;
@@ -3228,14 +3270,12 @@ static int presence_tables(const float* ex_bias, int cout, const float** tab, hi
   return PCC_OK;
 }
 
-// presence source for the next pcc_convt_fwd_csr call (pcc_convt_fwd_csr_grid sets it): the output set's grid index
-static PccGrid g_ex_grid = {nullptr, nullptr, {0, 0, 0}, {0, 0, 0}, 0, 0};
-static const long long* g_ex_keys = nullptr;
-
-extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
-                                 const float* bias, int32_t K, int32_t cout, const int32_t* first,
-                                 const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
-                                 const int32_t* ex_nbr, int32_t ex_K, const float* ex_bias, void* stream) {
+// ex_grid / ex_keys: presence source of pcc_convt_fwd_csr_grid (the output set's grid index) or NULL
+static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                              const float* bias, int32_t K, int32_t cout, const int32_t* first,
+                              const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
+                              const int32_t* ex_nbr, int32_t ex_K, const float* ex_bias, const PccGrid* ex_grid,
+                              const long long* ex_keys, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0 || n_in <= 0) return PCC_OK;
   PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && out, "pcc_convt_fwd_csr: NULL array");
@@ -3254,13 +3294,13 @@ extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin
   PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));
   if (g_prof_on) {
     PCC_TRY(prof_event(&e1, s));
-    ++g_launches;
+    prof_push();
   }
   GatherCsrArgs g;
   g.T = T; g.bias = bias; g.first = first; g.pair_ids = pair_ids; g.out = out; g.n_out = n_out; g.cout = cout;
   g.act = act; g.slope = slope; g.ex_nbr = ex_nbr; g.ex_bias = ex_bias; g.ex_K = ex_K;
   g.ex_grid.bits = nullptr; g.out_keys = nullptr;
-  if (g_ex_grid.bits) { g.ex_grid = g_ex_grid; g.out_keys = g_ex_keys; g.ex_nbr = nullptr; g_ex_grid.bits = nullptr; }
+  if (ex_grid) { g.ex_grid = *ex_grid; g.out_keys = ex_keys; g.ex_nbr = nullptr; }
   g.ex_tab = nullptr;
   if (ex_bias) {
     PCC_REQUIRE(ex_K == 27, "pcc_convt_fwd_csr: the per-neighbour constants are those of a 3x3x3 neighbourhood (ex_K=%d)", ex_K);
@@ -3278,6 +3318,14 @@ extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin
   else k_convt_gather_csr<1, 8><<<gg, 256, 0, s>>>(g);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
+}
+
+extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                                 const float* bias, int32_t K, int32_t cout, const int32_t* first,
+                                 const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
+                                 const int32_t* ex_nbr, int32_t ex_K, const float* ex_bias, void* stream) {
+  return convt_fwd_csr_impl(feat_in, n_in, cin, packed_w, bias, K, cout, first, pair_ids, n_out, T, out, act, slope, ex_nbr,
+                            ex_K, ex_bias, nullptr, nullptr, stream);
 }
 
 static int ilog2_i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -3298,12 +3346,9 @@ extern "C" int pcc_convt_fwd_csr_grid(const float* feat_in, int64_t n_in, int32_
                                       const int64_t* out_keys, const uint64_t* out_bits, const int32_t* out_rank,
                                       const int32_t* h_out, const float* ex_bias, void* stream) {
   PCC_REQUIRE(out_keys && out_bits && out_rank && h_out && ex_bias, "pcc_convt_fwd_csr_grid: NULL array");
-  g_ex_grid = grid_from_host(out_bits, out_rank, h_out);
-  g_ex_keys = (const long long*)out_keys;
-  const int rc = pcc_convt_fwd_csr(feat_in, n_in, cin, packed_w, bias, K, cout, first, pair_ids, n_out, T, out, act, slope,
-                                   nullptr, 27, ex_bias, stream);
-  g_ex_grid.bits = nullptr;
-  return rc;
+  const PccGrid ex = grid_from_host(out_bits, out_rank, h_out);
+  return convt_fwd_csr_impl(feat_in, n_in, cin, packed_w, bias, K, cout, first, pair_ids, n_out, T, out, act, slope,
+                            nullptr, 27, ex_bias, &ex, (const long long*)out_keys, stream);
 }
 
 // ---- chunked form of the CSR generative transposed convolution --------------------------------------------------------
@@ -3502,7 +3547,7 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
     PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));
     if (g_prof_on) {
       PCC_TRY(prof_event(&e1, s));
-      ++g_launches;
+      prof_push();
     }
     const int pid_lo = (int)(r0 * K), pid_hi = (int)((r0 + rows) * K);
     if (vec == 4) k_convt_gather_csr_chunk<4><<<ggrid, 256, 0, s>>>(g, ranges + c, pid_lo, pid_hi);

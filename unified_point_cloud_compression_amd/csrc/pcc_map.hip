@@ -631,6 +631,7 @@ struct ExpandCsrArgs {
   int* first;                 // FILL=false: first[o] = pairs of row o;  FILL=true: exclusive prefix (read)
   int* pair_ids;
   int zk;                     // kernel-offset index of a pair: 0 = x fastest (ix + KS*iy + KS*KS*iz, the native order), 1 = z fastest
+  long long* d_total;         // nullable: receives first[n_out], the number of pairs (fill pass)
 };
 
 // The compatible source cells of an output row: per axis the offsets whose source lies on the input lattice (offset index
@@ -707,8 +708,10 @@ __device__ __forceinline__ unsigned csr_field(const unsigned long long* __restri
   return (unsigned)f & ((1u << nz) - 1u);
 }
 
-// count pass: pairs of every output row
-template <int KS>
+// count pass: pairs of every output row.  M = compatible offsets per axis the probe covers: (KS + 1) / 2 when the input pitch
+// is at least twice the output pitch (every generative convolution of the codec), KS for a stride-1 generative transpose
+// (input pitch == output pitch: every offset is compatible).
+template <int KS, int M>
 __global__ void __launch_bounds__(256) k_expand_csr_count(ExpandCsrArgs a) {
   const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= a.n_out) return;
@@ -719,7 +722,6 @@ __global__ void __launch_bounds__(256) k_expand_csr_count(ExpandCsrArgs a) {
     // All (x, y) columns at once: a column's z field (<= 4 bits) is cut out of the 64-bit window that starts at the 32-bit
     // word holding its first cell -- it never straddles, so a column is ONE unconditional load (absent columns re-read cell 0
     // and are masked) and the <= 16 loads of a row are in flight together.  (The loop form waited for each column's word.)
-    constexpr int M = (KS + 1) / 2;                      // compatible offsets per axis (consecutive source cells)
     const unsigned* const bits32 = reinterpret_cast<const unsigned*>(a.in.bits);
     const long long cells = (long long)a.in.nbatch * a.in.dims[0] * a.in.dims[1] * a.in.dims[2];
     const long long last_dw = 2 * ((cells + 63) >> 6) - 2;       // last 32-bit word a 64-bit window may start at
@@ -780,6 +782,7 @@ __global__ void __launch_bounds__(256) k_expand_csr_fill(ExpandCsrArgs a) {
   const long long o_end = min(a.n_out, o0 + 256);
   const int base = a.first[o0], total = a.first[o_end] - base;
   const bool staged = total <= CAP;
+  if (a.d_total && blockIdx.x == 0 && threadIdx.x == 0) *a.d_total = a.first[a.n_out];
   if (o < a.n_out) {
     int wpos = a.first[o] - base;
     if (staged) csr_probe<KS>(a, o, [&](int i, int kidx) { stage[wpos++] = i * a.K + kidx; });
@@ -826,24 +829,26 @@ extern "C" size_t pcc_expand_grid_csr_ws_bytes(int64_t n_out) { return pcc_scan_
 // phase 2 (n_out known to the host): CSR pair lists of the transposed map: first[n_out+1], pair_ids[n_in*K]
 static int expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
                            const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in,
-                           int64_t n_in, int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes, int zk, void* stream);
+                           int64_t n_in, int32_t* first, int32_t* pair_ids, int64_t* d_total, void* ws, size_t ws_bytes, int zk,
+                           void* stream);
 extern "C" int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
                                           const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in,
-                                          int64_t n_in, int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes,
-                                          void* stream) {
-  return expand_grid_csr(out_keys, n_out, kernel_size, ts_out, in_bits, in_rank, h_in, n_in, first, pair_ids, ws, ws_bytes, 0, stream);
+                                          int64_t n_in, int32_t* first, int32_t* pair_ids, int64_t* d_total, void* ws,
+                                          size_t ws_bytes, void* stream) {
+  return expand_grid_csr(out_keys, n_out, kernel_size, ts_out, in_bits, in_rank, h_in, n_in, first, pair_ids, d_total, ws, ws_bytes, 0, stream);
 }
 // the same lists with the kernel offsets of the pair ids numbered z fastest (iz + KS*iy + KS*KS*ix): for a per-pair product
 // buffer laid out [input row][kx][ky][kz][c], where the z-neighbours of a canonical (z-fastest) run of output rows are adjacent
 extern "C" int pcc_coords_expand_grid_csr_zk(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
                                              const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in,
-                                             int64_t n_in, int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes,
-                                             void* stream) {
-  return expand_grid_csr(out_keys, n_out, kernel_size, ts_out, in_bits, in_rank, h_in, n_in, first, pair_ids, ws, ws_bytes, 1, stream);
+                                             int64_t n_in, int32_t* first, int32_t* pair_ids, int64_t* d_total, void* ws,
+                                             size_t ws_bytes, void* stream) {
+  return expand_grid_csr(out_keys, n_out, kernel_size, ts_out, in_bits, in_rank, h_in, n_in, first, pair_ids, d_total, ws, ws_bytes, 1, stream);
 }
 static int expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
                            const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in,
-                           int64_t n_in, int32_t* first, int32_t* pair_ids, void* ws, size_t ws_bytes, int zk, void* stream) {
+                           int64_t n_in, int32_t* first, int32_t* pair_ids, int64_t* d_total, void* ws, size_t ws_bytes, int zk,
+                           void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PCC_REQUIRE(out_keys && in_bits && in_rank && h_in && first && pair_ids && n_out > 0, "pcc_coords_expand_grid_csr: bad arguments");
   PCC_REQUIRE(kernel_size == 2 || kernel_size == 3 || kernel_size == 5 || kernel_size == 7,
@@ -853,10 +858,20 @@ static int expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kerne
   if (ws_bytes < pcc_expand_grid_csr_ws_bytes(n_out)) { pcc_set_error("pcc_coords_expand_grid_csr: workspace too small"); return PCC_EWS; }
   ExpandCsrArgs a;
   a.out_keys = out_keys; a.n_out = n_out; a.ts_out = ts_out; a.K = K; a.first = first; a.pair_ids = pair_ids; a.zk = zk;
+  a.d_total = (long long*)d_total;
   a.in.bits = (const unsigned long long*)in_bits; a.in.rank = in_rank;
   for (int i = 0; i < 3; ++i) { a.in.lo[i] = h_in[i]; a.in.dims[i] = h_in[3 + i]; }
   a.in.ts_log2 = ilog2(h_in[6]); a.in.nbatch = h_in[7];
   const unsigned g = (unsigned)pcc_cdiv(n_out, 256);
+  // pitch ratio: >= 2 leaves at most (KS + 1) / 2 compatible offsets per axis; 1 (stride-1 generative transpose) all KS
+  PCC_REQUIRE(ts_out >= 1 && h_in[6] >= ts_out && h_in[6] % ts_out == 0, "pcc_coords_expand_grid_csr: input pitch %d is not a multiple of the output pitch %d", h_in[6], ts_out);
+  const bool same_pitch = h_in[6] == ts_out;
+  PCC_REQUIRE(!(same_pitch && kernel_size == 7), "pcc_coords_expand_grid_csr: 7-wide lists need an input pitch of at least twice the output pitch");
+  if (kernel_size == 2) { if (same_pitch) k_expand_csr_count<2, 2><<<g, 256, 0, s>>>(a); else k_expand_csr_count<2, 1><<<g, 256, 0, s>>>(a); }
+  else if (kernel_size == 3) { if (same_pitch) k_expand_csr_count<3, 3><<<g, 256, 0, s>>>(a); else k_expand_csr_count<3, 2><<<g, 256, 0, s>>>(a); }
+  else if (kernel_size == 5) { if (same_pitch) k_expand_csr_count<5, 5><<<g, 256, 0, s>>>(a); else k_expand_csr_count<5, 3><<<g, 256, 0, s>>>(a); }
+  else k_expand_csr_count<7, 4><<<g, 256, 0, s>>>(a);
+  PCC_LAUNCH_CHECK();
 #define PCC_EXPAND_CSR(KERNEL)                                                      \
   do {                                                                              \
     if (kernel_size == 2) KERNEL<2><<<g, 256, 0, s>>>(a);                           \
@@ -865,7 +880,6 @@ static int expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kerne
     else KERNEL<7><<<g, 256, 0, s>>>(a);                                            \
     PCC_LAUNCH_CHECK();                                                             \
   } while (0)
-  PCC_EXPAND_CSR(k_expand_csr_count);
   // out_keys need not be the full expansion (any subset of rows, or a wider kernel restricted to a given set), so the
   // pair total is whatever the counts add up to: scan n_out + 1 entries
   k_set_int<<<1, 1, 0, s>>>(first + n_out, 0);

@@ -754,11 +754,13 @@ extern "C" int pcc_rans_decode_streams(const uint8_t* data, int64_t nbytes, cons
   // decoder table in LDS when it fits (Gaussian scale table: ~90 KB; factorised prior: ~110 KB)
   const bool in_lds = dec_table && dec_bytes > 0 && dec_bytes <= 150 * 1024 && dec_bytes % 4 == 0;
   if (in_lds) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;                      // one bit per device (hipFuncSetAttribute is per device)
+    int dev = 0;
+    PCC_CHECK_HIP(hipGetDevice(&dev));
+    if (!(attr_set >> (dev & 63) & 1ull)) {
       PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_rans_decode_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       PCC_CHECK_HIP(hipFuncSetAttribute((const void*)k_rans_decode_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
+      attr_set |= 1ull << (dev & 63);
     }
     // LDS: table + per-row offsets (row count = first word of the table, bounded by its size) + scan scratch
     const size_t lds = (size_t)dec_bytes + (size_t)dec_bytes / 128 + 64;

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcc_hip.so")
 
 MAP_HDR_INTS = 512
+FORM_NAMES = ("other", "k_gemm_h2", "k_gemm_bf2", "k_pair_h2", "pair_bf", "k_conv_mfma_bf", "k_conv_mfma", "k_conv_wave16")
 MAP_MAX_SEG = 8
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
@@ -51,8 +52,8 @@ SIGNATURES = {
     "pcc_keys_canonicalize_grid": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_coords_expand_grid": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_expand_grid_csr_ws_bytes": (_sz, [_i64]),
-    "pcc_coords_expand_grid_csr": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
-    "pcc_coords_expand_grid_csr_zk": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
+    "pcc_coords_expand_grid_csr": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _sz, _p]),
+    "pcc_coords_expand_grid_csr_zk": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "pcc_map_to_dense": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_set_mfma_split": (C.c_int, [_i32]),
     "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
@@ -126,6 +127,8 @@ SIGNATURES = {
     "pcc_nn_sorted_x": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p]),
     "pcc_prof_enable": (C.c_int, [_i32]),
     "pcc_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "pcc_prof_sequence": (_i64, [C.POINTER(_i32), _i64]),
+    "pcc_prof_collect_forms": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -228,6 +231,23 @@ def read(t):
         return t.tolist()
     torch.cuda.current_stream().synchronize()
     return t.tolist()
+
+
+def read_many(counters):
+    """Values of several counter() tensors with ONE device->host copy (they are cut from one zeroed block, so the span
+    between the first and the last is a single contiguous read).  Returns a list of lists, one per counter."""
+    if not counters:
+        return []
+    if all(t.is_cuda and t.dtype == torch.int64 for t in counters):
+        base = counters[0].untyped_storage().data_ptr()
+        if all(t.untyped_storage().data_ptr() == base for t in counters):
+            lo = min(t.storage_offset() for t in counters)
+            hi = max(t.storage_offset() + t.numel() for t in counters)
+            if hi - lo <= 4096:
+                blk = torch.empty(0, dtype=torch.int64, device=counters[0].device).set_(counters[0].untyped_storage(), lo, (hi - lo,))
+                v = blk.tolist()
+                return [v[t.storage_offset() - lo:t.storage_offset() - lo + t.numel()] for t in counters]
+    return [read(t) for t in counters]
 
 
 def call(name, *args):

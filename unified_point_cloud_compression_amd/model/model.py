@@ -56,12 +56,23 @@ class UnifiedModel(CompressionModel):
         _, counts = torch.unique_consecutive(code[order], return_counts=True)
         return order, counts.tolist()
 
-    @staticmethod
-    def block_input(x_block, coords=None):
+    def stride_chain(self):
+        """Tensor strides of the sets the encoder derives from the input one after the other (g_a's three stride-2
+        convolutions, then h_a's two): the input set's constructor builds them all in its own batch of launches."""
+        chain, ts = [], 1
+        for m in list(self.g_a.modules()) + list(self.entropy_model.h_a.modules()):
+            if getattr(m, "stride", 1) != 1 and hasattr(m, "kernel_size"):
+                ts *= m.stride
+                chain.append(ts)
+        return tuple(chain)
+
+    def block_input(self, x_block, coords=None):
         """floor -> int32, de-duplicate (first wins), features [1, r, g, b] (`model/model.py:141-161`)."""
         n = x_block.shape[0]
         if coords is None:
             coords = torch.cat([torch.zeros((n, 1), device=x_block.device, dtype=x_block.dtype), x_block[:, :3]], dim=1)
+        if not torch.is_grad_enabled():
+            coords._pcc_chain = self.stride_chain()
         feats = torch.cat([torch.ones((n, 1), device=x_block.device, dtype=torch.float32),
                            x_block[:, 3:6].to(torch.float32)], dim=1)
         return SparseTensor(coordinates=coords, features=feats, device=x_block.device)
@@ -134,9 +145,11 @@ class UnifiedModel(CompressionModel):
         feats, coords, status = [], [], []
         for i, (block_symbols, block_shape, block_coords, block_k) in enumerate(zip(strings, shape, coordinates, k)):
             y_cset = getattr(block_coords, "_pcc_cset", None)
-            if y_cset is None or y_cset.ts != 8:
-                y_cset = SparseTensor(coordinates=block_coords, features=torch.ones((block_coords.shape[0], 1)),
-                                      tensor_stride=8, device=self.g_s.down_conv.kernel.device)._cset
+            if (y_cset is None or y_cset.ts != 8 or y_cset.n != block_coords.shape[0]
+                    or getattr(block_coords, "_pcc_version", block_coords._version) != block_coords._version):
+                # plain coordinates (what a decoder gets: `utils.py:461-465`, `load_bitstream`): the canonical set of the
+                # rows (the reference builds `ME.SparseTensor(coordinates=points[0], tensor_stride=8)`, `model/entropy_models.py:439`)
+                y_cset = S.coordset_from_coords(block_coords.to(device), 8)[0]
             # z coordinates: two k3-s2 `down_conv`s in the reference (`model/model.py:227-229`) = coordinate-only stride
             z_cset = y_cset.stride(16).stride(32)
             y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i], check=status)

@@ -55,29 +55,45 @@ class KernelMap:
             self._pairs = int(self.d_pairs.item()) if self.d_pairs is not None else -1
         return self._pairs
 
+    def pair_plan_begin(self):
+        """Queue the ranking pass of the pair plan; returns a Pending (see `resolve`) that completes it."""
+        if hasattr(self, "_plan"):
+            return _ready(self._plan)
+        if hasattr(self, "_plan_pending"):
+            return self._plan_pending
+        if not (self.rows is None and not self.transposed and self.n_out > 0 and self.K * self.n_out + self.K * 128 < (1 << 31)):
+            self._plan = None
+            return _ready(None)
+        dev = self.hdr.device
+        lib = L.load()
+        pos = torch.empty(self.K * self.n_out, dtype=torch.int32, device=dev)
+        pstart = torch.empty(self.K + 1, dtype=torch.int32, device=dev)
+        info = L.counter(3)
+        ws = L.workspace(lib.pcc_pair_plan_ws_bytes(self.n_out, self.K), dev)
+        L.call("pcc_pair_plan_rank", L.ptr(self.nbr), self.n_out, self.K, L.ptr(pos), L.ptr(pstart), L.ptr(info),
+               L.ptr(ws), ws.numel(), L.stream())
+
+        def finish(v):
+            padded, _, pairs = (int(x) for x in v)
+            if self._pairs is None:
+                self._pairs = pairs
+            self._plan = None
+            if pairs <= PAIR_MAX_DENSITY * self.K * self.n_out:
+                pair_in = torch.empty(max(padded, 1), dtype=torch.int32, device=dev)
+                tile_k = torch.empty(max(padded // 128, 1), dtype=torch.int32, device=dev)
+                L.call("pcc_pair_plan_fill", L.ptr(self.nbr), L.ptr(pos), L.ptr(pstart), self.n_out, self.K, padded,
+                       L.ptr(pair_in), L.ptr(tile_k), L.stream())
+                self._plan = (pos, pair_in, tile_k, info, padded)
+            del self._plan_pending
+            return self._plan
+        self._plan_pending = Pending(info, finish)
+        return self._plan_pending
+
     def pair_plan(self):
         """Compacted pair lists of a conv map (pcc_conv_fwd_pairs), built on first use; None when the map is too dense
         for the pair form to pay (or is not a plain conv map)."""
         if not hasattr(self, "_plan"):
-            self._plan = None
-            if self.rows is None and not self.transposed and self.n_out > 0 and self.K * self.n_out + self.K * 128 < (1 << 31):
-                dev = self.hdr.device
-                lib = L.load()
-                pos = torch.empty(self.K * self.n_out, dtype=torch.int32, device=dev)
-                pstart = torch.empty(self.K + 1, dtype=torch.int32, device=dev)
-                info = L.counter(3)
-                ws = L.workspace(lib.pcc_pair_plan_ws_bytes(self.n_out, self.K), dev)
-                L.call("pcc_pair_plan_rank", L.ptr(self.nbr), self.n_out, self.K, L.ptr(pos), L.ptr(pstart), L.ptr(info),
-                       L.ptr(ws), ws.numel(), L.stream())
-                padded, _, pairs = (int(v) for v in info.tolist())
-                if self._pairs is None:
-                    self._pairs = pairs
-                if pairs <= PAIR_MAX_DENSITY * self.K * self.n_out:
-                    pair_in = torch.empty(max(padded, 1), dtype=torch.int32, device=dev)
-                    tile_k = torch.empty(max(padded // 128, 1), dtype=torch.int32, device=dev)
-                    L.call("pcc_pair_plan_fill", L.ptr(self.nbr), L.ptr(pos), L.ptr(pstart), self.n_out, self.K, padded,
-                           L.ptr(pair_in), L.ptr(tile_k), L.stream())
-                    self._plan = (pos, pair_in, tile_k, info, padded)
+            resolve(self.pair_plan_begin())
         return self._plan
 
     def dense(self):
@@ -115,6 +131,46 @@ HEAD_FUSED = os.environ.get("PCC_HEAD_FUSED", "1") != "0"      # occupancy heads
 _SET_SERIAL = itertools.count()
 
 
+class Pending:
+    """A size the device is still computing (rows of a derived coordinate set, pairs of a list, ...).  The launches are
+    queued; `finish(values)` runs once the counter has been read.  `resolve` reads the counters of ANY number of pending
+    sizes with one device->host copy: the host reads of a step are batched per level instead of one per derived object
+    (round 2: ~33 reads per step, each leaving the GPU idle until the host had queued the next kernels)."""
+
+    __slots__ = ("counter", "finish", "result", "done")
+
+    def __init__(self, counter, finish):
+        self.counter, self.finish, self.result, self.done = counter, finish, None, False
+
+
+def resolve(*pendings):
+    """Read every pending size in one go and complete the objects; returns their results in order.  A Pending's counter
+    may be a list of counters (its finish then receives the list of their values)."""
+    todo = [p for p in pendings if p is not None and not p.done]
+    if todo:
+        flat = []
+        for p in todo:
+            flat.extend(p.counter if isinstance(p.counter, list) else [p.counter])
+        vals = L.read_many(flat)
+        at = 0
+        for p in todo:
+            if isinstance(p.counter, list):
+                v = vals[at:at + len(p.counter)]
+                at += len(p.counter)
+            else:
+                v = vals[at]
+                at += 1
+            p.result = p.finish(v)
+            p.done = True
+    return [p.result if p is not None else None for p in pendings]
+
+
+def _ready(value):
+    p = Pending(None, None)
+    p.result, p.done = value, True
+    return p
+
+
 class CoordSet:
     """Canonical coordinate set at one tensor stride."""
 
@@ -128,6 +184,7 @@ class CoordSet:
         self._maps = {}
         self._grid = None
         self._bands = None
+        self._on_lattice = False            # every row a multiple of the tensor stride: sets derived by the library are, user sets are checked
         self.uid = next(_SET_SERIAL)
 
     @property
@@ -188,40 +245,85 @@ class CoordSet:
         return self._bands or None
 
     # ---- derived sets ------------------------------------------------------------------------
+    def stride_begin(self, new_stride, known_n=None, keys=None, n_keys=None):
+        """Queue the strided set unique(floor(c/m)*m) (a2-i); returns a Pending that yields the CoordSet.
+        known_n: the row count when the caller has it (the decoder knows the hyper-latent's from the bitstream): the set
+        is complete without a read.  keys / n_keys: take the rows from this key array instead (ANY order, duplicates
+        allowed -- marking a coarse cell is idempotent), e.g. the un-canonicalised user rows or a finer ancestor."""
+        key = ("stride", new_stride)
+        if key in self._derived:
+            return _ready(self._derived[key])
+        dev = self.device
+        lib = L.load()
+        src, n_src = (self.keys, self.n) if keys is None else (keys, n_keys)
+        nb = self.bounds.strided(new_stride)
+        dims = [(nb.hi[i] - nb.lo[i]) // new_stride + 1 for i in range(3)]
+        h = (C.c_int32 * 8)(nb.lo[0], nb.lo[1], nb.lo[2], dims[0], dims[1], dims[2], new_stride, nb.bmax + 1)
+        words = lib.pcc_grid_words(h)
+        cnt = L.counter()
+        cap = max(min(self.n, n_src), 1)
+        out = torch.empty(cap, dtype=torch.int64, device=dev)
+        by_grid = USE_GRID and STRIDE_BY_GRID and n_src > 0 and words < (1 << 31) and words * 12 <= GRID_MAX_BYTES
+        if by_grid:
+            # through the occupancy bitmap of the coarse lattice: no sort, and the coarse set's grid index for free
+            bits = torch.empty(words, dtype=torch.int64, device=dev)
+            rank = torch.empty(words, dtype=torch.int32, device=dev)
+            ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
+            L.call("pcc_coords_stride_grid", L.ptr(src), n_src, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
+                   L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+        else:
+            if keys is not None:
+                raise L.PccError("stride_begin(keys=...) needs the bitmap path")
+            ws = L.workspace(lib.pcc_stride_ws_bytes(self.n), dev)
+            L.call("pcc_coords_stride", L.ptr(self.keys), self.n, new_stride, self.bounds.bit_mask(), L.ptr(out),
+                   L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+
+        def finish(v):
+            n = int(v[0])
+            cs = CoordSet(out, n, new_stride, nb)
+            cs._on_lattice = True
+            if by_grid:
+                cs._grid = (bits, rank, h)
+            self._derived[key] = cs
+            return cs
+        if known_n is not None:
+            return _ready(finish([known_n]))
+        return Pending(cnt, finish)
+
     def stride(self, new_stride):
         """Output set of a strided conv (a2-i): unique(floor(c/m)*m)."""
         key = ("stride", new_stride)
         if key not in self._derived:
-            dev = self.device
-            lib = L.load()
-            nb = self.bounds.strided(new_stride)
-            dims = [(nb.hi[i] - nb.lo[i]) // new_stride + 1 for i in range(3)]
-            h = (C.c_int32 * 8)(nb.lo[0], nb.lo[1], nb.lo[2], dims[0], dims[1], dims[2], new_stride, nb.bmax + 1)
-            words = lib.pcc_grid_words(h)
-            cnt = L.counter()
-            out = torch.empty(max(self.n, 1), dtype=torch.int64, device=dev)
-            if USE_GRID and STRIDE_BY_GRID and self.n > 0 and words < (1 << 31) and words * 12 <= GRID_MAX_BYTES:
-                # through the occupancy bitmap of the coarse lattice: no sort, and the coarse set's grid index for free
-                bits = torch.empty(words, dtype=torch.int64, device=dev)
-                rank = torch.empty(words, dtype=torch.int32, device=dev)
-                ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
-                L.call("pcc_coords_stride_grid", L.ptr(self.keys), self.n, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
-                       L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-                n = int(L.read(cnt)[0])
-                cs = CoordSet(out[:n].clone() if n < self.n // 2 else out, n, new_stride, nb)
-                cs._grid = (bits, rank, h)
-                self._derived[key] = cs
-                return cs
-            ws = L.workspace(lib.pcc_stride_ws_bytes(self.n), dev)
-            L.call("pcc_coords_stride", L.ptr(self.keys), self.n, new_stride, self.bounds.bit_mask(), L.ptr(out),
-                   L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-            n = int(L.read(cnt)[0])
-            self._derived[key] = CoordSet(out[:n].clone() if n < self.n // 2 else out, n, new_stride, nb)
+            resolve(self.stride_begin(new_stride))
         return self._derived[key]
 
-    def csr_for(self, out_keys, n_out, ksize, ts_out, zk=False):
+    def stride_chain_begin(self, strides, keys=None, n_keys=None):
+        """Queue the whole chain self -> stride(s0) -> stride(s1) -> ... (the analysis transform's and the hyper-analysis'
+        output sets), every set straight from THIS set's rows -- unique(floor(c/m)*m) does not care which finer ancestor it
+        is taken from -- so that none waits for the previous one's row count.  One Pending; it links the chain into the
+        `_derived` caches the convolution modules look the sets up in."""
+        if not (USE_GRID and STRIDE_BY_GRID and self.n > 0):
+            return None
+        src, n_src = (self.keys, self.n) if keys is None else (keys, n_keys)
+        parts = []
+        for m in strides:
+            t = CoordSet(self.keys, self.n, self.ts, self.bounds)          # carrier of the bounds; its own cache is discarded
+            parts.append((m, t.stride_begin(m, keys=src, n_keys=n_src)))
+
+        def finish(vals):
+            parent = self
+            for (m, pend), v in zip(parts, vals):
+                if not pend.done:
+                    pend.result, pend.done = pend.finish(v), True
+                parent._derived[("stride", m)] = pend.result
+                parent = pend.result
+            return parent
+        return Pending([p.counter for _, p in parts], finish)
+
+    def csr_for(self, out_keys, n_out, ksize, ts_out, zk=False, total=None):
         """CSR pair lists (first[n_out+1], pair_ids) of the transposed conv from this set onto the GIVEN output rows
-        (any canonical subset of the lattice at pitch ts_out), built by probing this set's grid index."""
+        (any canonical subset of the lattice at pitch ts_out), built by probing this set's grid index.
+        total: a counter() that receives the number of pairs (to be read together with other sizes, `resolve`)."""
         g = self.grid()
         if not g:
             raise L.PccError("csr_for needs the grid index of the input set")
@@ -234,8 +336,59 @@ class CoordSet:
         ws = L.workspace(L.load().pcc_expand_grid_csr_ws_bytes(n_out), dev)
         # zk: pair ids number the kernel offsets z fastest (for product buffers laid out [row][kx][ky][kz][c])
         L.call("pcc_coords_expand_grid_csr_zk" if zk else "pcc_coords_expand_grid_csr", L.ptr(out_keys), n_out, ksize, ts_out,
-               L.ptr(g[0]), L.ptr(g[1]), g[2], self.n, L.ptr(first), L.ptr(pair_ids), L.ptr(ws), ws.numel(), L.stream())
+               L.ptr(g[0]), L.ptr(g[1]), g[2], self.n, L.ptr(first), L.ptr(pair_ids), L.cptr(total) if total is not None else None,
+               L.ptr(ws), ws.numel(), L.stream())
         return first, pair_ids
+
+    def _expand_lattice(self, ksize, ts_out):
+        ob = self.bounds.expanded(ksize, ts_out)
+        dims = [(ob.hi[i] - ob.lo[i]) // ts_out + 1 for i in range(3)]
+        cells = (ob.bmax + 1) * dims[0] * dims[1] * dims[2]
+        h = (C.c_int32 * 8)(ob.lo[0], ob.lo[1], ob.lo[2], dims[0], dims[1], dims[2], ts_out, ob.bmax + 1)
+        return ob, cells, h, (cells + 63) // 64
+
+    def _expand_by_grid(self, ksize, ts_out):
+        K = ksize ** 3
+        _, _, _, words = self._expand_lattice(ksize, ts_out)
+        if (USE_CSR and USE_GRID and EXPAND_BY_GRID and self.n > 0 and ksize in (2, 3, 5) and words < (1 << 31)
+                and words * 12 <= GRID_MAX_BYTES and self.n * K < (1 << 31)):
+            return self.grid()
+        return None
+
+    def expand_begin(self, ksize, ts_out, want_csr=True):
+        """Queue the generative expansion through the bitmaps; returns a Pending yielding the CoordSet, or None when this
+        set does not take the bitmap path (then `expand` does everything, with its own reads).  An even kernel of width 2
+        on a pitch-2*ts_out set makes exactly 8 distinct children per row: that count needs no read."""
+        key = ("expand", ksize, ts_out)
+        if key in self._derived:
+            return _ready(self.expand(ksize, ts_out, want_csr))
+        if not self._expand_by_grid(ksize, ts_out):
+            return None
+        dev = self.device
+        lib = L.load()
+        ob, cells, h, words = self._expand_lattice(ksize, ts_out)
+        m = self.n * ksize ** 3
+        # mark the output bitmap, read the set back out, then build the pair lists by probing this set's grid
+        bits = torch.empty(words, dtype=torch.int64, device=dev)
+        rank = torch.empty(words, dtype=torch.int32, device=dev)
+        out = torch.empty(min(m, cells), dtype=torch.int64, device=dev)
+        cnt = L.counter()
+        ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
+        L.call("pcc_coords_expand_grid", L.ptr(self.keys), self.n, ksize, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
+               L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+
+        def finish(v):
+            n = int(v[0])
+            cs = CoordSet(out[:n].clone() if n < out.numel() // 2 else out, n, ts_out, ob)
+            cs._grid = (bits, rank, h)
+            cs._on_lattice = self._on_lattice
+            self._derived[key] = cs
+            if want_csr:
+                self._derived[("csr", ksize, ts_out)] = self.csr_for(cs.keys, n, ksize, ts_out)
+            return cs
+        if ksize == 2 and self.ts == 2 * ts_out and self._on_lattice:
+            return _ready(finish([8 * self.n]))
+        return Pending(cnt, finish)
 
     def expand(self, ksize, ts_out, want_csr=True):
         """Output set of a generative transposed conv (a3-i): unique{c + off_k*ts_out}, plus (want_csr) the transposed
@@ -246,33 +399,12 @@ class CoordSet:
             cs = self._derived[key]                       # the set was built without its pair lists: add them
             self._derived[("csr", ksize, ts_out)] = self.csr_for(cs.keys, cs.n, ksize, ts_out)
         if key not in self._derived:
+            pend = self.expand_begin(ksize, ts_out, want_csr)
+            if pend is not None:
+                return resolve(pend)[0]
             dev = self.device
             K = ksize ** 3
-            ob = self.bounds.expanded(ksize, ts_out)
-            dims = [(ob.hi[i] - ob.lo[i]) // ts_out + 1 for i in range(3)]
-            cells = (ob.bmax + 1) * dims[0] * dims[1] * dims[2]
-            h = (C.c_int32 * 8)(ob.lo[0], ob.lo[1], ob.lo[2], dims[0], dims[1], dims[2], ts_out, ob.bmax + 1)
-            words = (cells + 63) // 64
-            g_in = self.grid() if (USE_CSR and USE_GRID and EXPAND_BY_GRID and self.n > 0 and ksize in (2, 3, 5) and
-                                   words < (1 << 31) and words * 12 <= GRID_MAX_BYTES and self.n * K < (1 << 31)) else None
-            if g_in:
-                # mark the output bitmap, read the set back out, then build the pair lists by probing this set's grid
-                lib = L.load()
-                m = self.n * K
-                bits = torch.empty(words, dtype=torch.int64, device=dev)
-                rank = torch.empty(words, dtype=torch.int32, device=dev)
-                out = torch.empty(min(m, cells), dtype=torch.int64, device=dev)
-                cnt = L.counter()
-                ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
-                L.call("pcc_coords_expand_grid", L.ptr(self.keys), self.n, ksize, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
-                       L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-                n = int(L.read(cnt)[0])
-                cs = CoordSet(out[:n].clone() if n < out.numel() // 2 else out, n, ts_out, ob)
-                cs._grid = (bits, rank, h)
-                self._derived[key] = cs
-                if want_csr:
-                    self._derived[("csr", ksize, ts_out)] = self.csr_for(cs.keys, n, ksize, ts_out)
-                return cs
+            ob, cells, h, words = self._expand_lattice(ksize, ts_out)
             if USE_CSR and self.n > 0 and cells <= 0xFFFFFFFF and self.n * K < (1 << 31):
                 m = self.n * K
                 out = torch.empty(m, dtype=torch.int64, device=dev)
@@ -380,20 +512,26 @@ def bounds_of(coords, canon_keys=None):
     return b if canon_keys is None else (b, bool(v[8]))
 
 
-def coordset_from_coords(coords, tensor_stride):
+def coordset_from_coords(coords, tensor_stride, stride_chain=None):
     """Canonicalise user coordinates.  Returns (CoordSet, perm, keep):
     perm  None when the rows already are in canonical order, else int64 [n] with
           canonical position -> row of the (de-duplicated) user-order tensor;
-    keep  None, or int64 indices of the user rows that survive de-duplication (first wins, A.1)."""
+    keep  None, or int64 indices of the user rows that survive de-duplication (first wins, A.1).
+    stride_chain: tensor strides of the sets the caller will derive next (`CoordSet.stride_chain_begin`); they are built
+    from the same rows in the same batch of launches, and their sizes come back in the read this function makes anyway."""
     n = coords.shape[0]
+    stride_chain = getattr(coords, "_pcc_chain", stride_chain)
     hint = getattr(coords, "_pcc_hint", None)             # (keys, bounds, canonical) already read by the caller (compress)
     if hint is not None:
-        keys, b, canonical = hint
+        keys, b, canonical = hint[:3]
     else:
         keys = pack_keys(coords)
         b, canonical = bounds_of(coords, canon_keys=keys if n > 1 else None) if n > 1 else (bounds_of(coords), True)
     if n <= 1 or canonical:
-        return CoordSet(keys, n, tensor_stride, b), None, None
+        cs = CoordSet(keys, n, tensor_stride, b)
+        if stride_chain and n > 1:
+            resolve(cs.stride_chain_begin(stride_chain))
+        return cs, None, None
     dev = coords.device
     lib = L.load()
     dims = [(b.hi[i] - b.lo[i]) // tensor_stride + 1 for i in range(3)]
@@ -410,10 +548,14 @@ def coordset_from_coords(coords, tensor_stride):
         ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
         L.call("pcc_keys_canonicalize_grid", L.ptr(keys), n, h, L.ptr(bits), L.ptr(rank), L.ptr(ukeys), L.ptr(first_user),
                L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-        nu, off_lattice = (int(v) for v in L.read(cnt))
+        cs = CoordSet(ukeys, n, tensor_stride, b)          # (row count filled in below)
+        # the strided sets of the chain do not need the canonical rows: marking coarse cells from the user rows is the same
+        chain = cs.stride_chain_begin(stride_chain, keys=keys, n_keys=n) if stride_chain else None
+        (nu, off_lattice), _ = resolve(Pending(cnt, lambda v: (int(v[0]), int(v[1]))), chain)
         if not off_lattice:
-            cs = CoordSet(ukeys[:nu].clone() if nu < n else ukeys, nu, tensor_stride, b)
+            cs.n = nu
             cs._grid = (bits, rank, h)
+            cs._on_lattice = True
             first_user = first_user[:nu].long()
             if nu == n:
                 return cs, first_user, None

@@ -128,9 +128,9 @@ def account_flops(model, pc, q):
 
     orig_r, orig_h = S.convt_forward_rows, S.conv_head_forward
 
-    def spy_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
+    def spy_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01, **kw):
         calls.append((int(csr[0][n_out].item()), float(K), cin, cout, n_out, feats.shape[0]))
-        return orig_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope)
+        return orig_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope, **kw)
 
     def spy_h(feats, packed_w0, bias0, cmid, w2, bias2, cset, kmap):    # fused head: the cin -> cmid convolution is the MFMA launch
         calls.append((kmap, 27, feats.shape[1], cmid, feats.shape[0], feats.shape[0]))

@@ -150,8 +150,11 @@ int pcc_grid_build(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64
  * COARSE lattice (pitch h_grid[6] = new tensor stride, origin a multiple of it).  Marks, ranks and reads the set back
  * out in bitmap (= canonical) order: out_keys (capacity n), *d_count, plus the coarse set's grid index in bits / rank.
  * Same result as pcc_coords_stride without the sort; ws of pcc_grid_ws_bytes(words). */
-int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits, int32_t* rank,
-                           int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes, void* stream);
+/* keys may be in ANY order and hold duplicates (marking a cell is idempotent).  d_n (device int64, nullable): the number
+ * of valid rows when it is still on the device -- a set derived a moment ago whose size the host has not read; n is then
+ * the capacity of keys[].  A chain of strided sets is queued this way without a host read between its links. */
+int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int64_t* d_n, const int32_t* h_grid, uint64_t* bits,
+                           int32_t* rank, int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes, void* stream);
 /* a1 through the bitmap: canonical order and first-wins de-duplication of USER-ordered keys without a sort.
  * bits / rank = the set's grid index, out_keys (capacity n) = canonical keys, first_user[canonical position] = smallest
  * user row with that coordinate, d_count[0] = number of distinct coordinates, d_count[1] != 0 when some key is off the

@@ -154,6 +154,15 @@ class EntropyModel(nn.Module):
                L.ptr(ws), ws.numel(), L.stream())
         return out[:int(L.read(nb)[0])].cpu().numpy().tobytes()
 
+    # ---- the same coding, split so that a caller with several matrices to code shares the host reads --------------------
+    HDR = 64                 # bytes in front of a container in its device blob: int64 nbytes | int64 guest word | padding
+    FULL_COPY_BYTES = 1 << 20
+
+    def streams_job(self, sym, idx=None):
+        """Coding of one symbol matrix in steps (`StreamsJob`): estimate -> encode -> fetch, each step's device->host read
+        exposed so that `MeanScaleHyperprior.compress` makes two reads for both strings instead of five."""
+        return StreamsJob(self, sym, idx)
+
     # Speed / rate knob of the stream container.  A stream is one GPU lane running a serial recurrence (~0.2-0.3 us per
     # symbol) and costs 12 bytes of framing, so MORE streams is faster and FEWER is smaller.  The (n, c) rule above
     # keeps the framing small for a trained model's ~0.5 bpp frames; a frame that codes at a high rate (the benchmark's
@@ -276,6 +285,69 @@ class EntropyModel(nn.Module):
             outs.append(s.t().reshape(indexes.shape[1:]))
         out = torch.stack(outs, dim=0).to(dtype)
         return out + means if means is not None else out
+
+
+class StreamsJob:
+    """GPU rANS coding of one [N, C] symbol matrix (`EntropyModel.compress_rows`, entropy_coder "pcc_streams") in steps.
+
+      adaptive            the stream count depends on a payload estimate (`_adaptive_segments`)
+      launch_estimate(p)  queue the estimate kernel; its int64 result goes to device address p (zeroed by the caller)
+      launch_encode(est)  queue the encoder into this job's blob = [HDR bytes | container]; word 0 of the header is the
+                          container's byte count, word 1 is free for a guest (another job's estimate)
+      fetch()             one device->host copy: header + container (large containers: header + the estimated size, a second
+                          copy only if the estimate fell short); returns the bytes
+    """
+
+    def __init__(self, em, sym, idx):
+        em._check_tables()
+        self.em, self.sym = em, sym.contiguous()
+        self.idx = idx.contiguous() if idx is not None else None
+        self.n, self.c = self.sym.shape
+        dev = self.sym.device
+        self.tabs = tuple(t.to(dev).contiguous() for t in (em._quantized_cdf, em._cdf_length, em._offset))
+        self.ng, self.segs = em.n_streams(self.n, self.c)
+        self.adaptive = em.FRAMING_TARGET > 0 and self.n * self.c >= em.ADAPTIVE_MIN_SYMBOLS
+        self.blob, self.guess, self.host = None, None, None
+
+    def launch_estimate(self, d_ptr):
+        cdf, sizes, offs = self.tabs
+        L.call("pcc_rans_estimate_bits", L.ptr(self.sym), L.ptr(self.idx), self.n, self.c, L.ptr(cdf), cdf.shape[1], L.ptr(sizes),
+               L.ptr(offs), d_ptr, L.stream())
+
+    def launch_encode(self, est_bits256=None):
+        em, dev = self.em, self.sym.device
+        lib = L.load()
+        cdf, sizes, offs = self.tabs
+        if self.adaptive:
+            if est_bits256 is None:
+                raise L.PccError("StreamsJob: an adaptive container needs its payload estimate first")
+            payload = int(est_bits256) / 2048.0
+            self.segs = em._adaptive_segments(self.n, self.c, self.ng, self.segs, payload)
+        ns = self.ng * self.segs
+        per = lib.pcc_rans_stream_symbols(self.n, self.c, self.ng, self.segs)
+        cap = lib.pcc_rans_container_max_bytes(per, ns)
+        self.blob = torch.empty(em.HDR + cap, dtype=torch.uint8, device=dev)
+        self.blob[:em.HDR].zero_()
+        if self.adaptive and cap > em.FULL_COPY_BYTES:       # payload estimate + framing + slack: what the first copy fetches
+            self.guess = min(cap, int(payload * 1.02) + 12 * ns + 4096)
+        ws = L.workspace(lib.pcc_rans_streams_ws_bytes(per, ns), dev)
+        L.call("pcc_rans_encode_streams", L.ptr(self.sym), L.ptr(self.idx), self.n, self.c, self.ng, self.segs, L.ptr(cdf),
+               cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(em._enc_table(dev)), self.blob.data_ptr() + em.HDR,
+               self.blob.data_ptr(), L.ptr(ws), ws.numel(), L.stream())
+        return self
+
+    def guest_ptr(self):
+        return self.blob.data_ptr() + 8
+
+    def fetch(self):
+        H = self.em.HDR
+        take = self.blob.numel() if self.guess is None else H + self.guess
+        host = self.blob[:take].cpu().numpy()
+        nbytes = int(host[:8].view(np.int64)[0])
+        self.guest = int(host[8:16].view(np.int64)[0])
+        if nbytes > take - H:                                   # the estimate fell short: fetch the rest
+            host = self.blob[:H + nbytes].cpu().numpy()
+        return host[H:H + nbytes].tobytes()
 
 
 class EntropyBottleneck(EntropyModel):

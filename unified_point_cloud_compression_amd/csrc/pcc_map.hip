@@ -463,14 +463,20 @@ extern "C" int pcc_grid_build(const int64_t* keys, int64_t n, const int32_t* h_g
 // unique(floor(c/m)*m) needs no sort: mark the coarse cell of every fine row (atomicOr; fine order is not coarse cell
 // order), rank the words, and read the set back out of the bitmap -- bitmap order IS canonical key order.  The coarse
 // set's grid index (bits + rank) falls out for free.  A handful of launches where the sort took ~35.
-__global__ void k_grid_bits_any(const int64_t* __restrict__ keys, int64_t n, int lo0, int lo1, int lo2, int d0, int d1,
-                                int d2, int tsl, unsigned long long* __restrict__ bits) {
+// d_n (nullable): the row count lives on the device (a set whose size the host has not read yet); n is then the capacity
+// the grid was sized for, and threads past *d_n leave.
+__global__ void k_grid_bits_any(const int64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ d_n, int lo0, int lo1,
+                                int lo2, int d0, int d1, int d2, int tsl, unsigned long long* __restrict__ bits) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= (d_n ? *d_n : n)) return;
   const long long c = grid_cell(keys[i], lo0, lo1, lo2, d0, d1, d2, tsl);
   // neighbours in fine order often share the coarse cell (z pairs): only the first of a run issues the atomic
   if (i > 0 && grid_cell(keys[i - 1], lo0, lo1, lo2, d0, d1, d2, tsl) == c) return;
-  atomicOr(&bits[c >> 6], 1ull << (c & 63));
+  // many fine rows per coarse cell (user-ordered rows, large pitch ratios): a cell already marked needs no atomic.  The
+  // load goes to L2 (agent scope), so it sees the marks of other CUs; a stale 0 only costs a redundant atomicOr.
+  const unsigned long long m = 1ull << (c & 63);
+  if (__hip_atomic_load(&bits[c >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) return;
+  atomicOr(&bits[c >> 6], m);
 }
 
 __global__ void k_grid_enumerate(const unsigned long long* __restrict__ bits, const int* __restrict__ rank,
@@ -505,7 +511,7 @@ __global__ void k_grid_enumerate(const unsigned long long* __restrict__ bits, co
 
 // keys: the FINE set (canonical); h_grid: lattice of the COARSE set (lo multiples of the coarse pitch h_grid[6]).
 // Outputs: bits/rank = grid index of the coarse set, out_keys (capacity n) = its canonical keys, *d_count = its size.
-extern "C" int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int32_t* h_grid, uint64_t* bits,
+extern "C" int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int64_t* d_n, const int32_t* h_grid, uint64_t* bits,
                                       int32_t* rank, int64_t* out_keys, int64_t* d_count, void* ws, size_t ws_bytes,
                                       void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -523,7 +529,7 @@ extern "C" int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int3
   PCC_CHECK_HIP(hipMemsetAsync(bits, 0, (size_t)words * 8, s));
   if (n > 0) {
     PCC_REQUIRE(keys, "pcc_coords_stride_grid: keys is NULL");
-    k_grid_bits_any<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(keys, n, h_grid[0], h_grid[1], h_grid[2], h_grid[3],
+    k_grid_bits_any<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(keys, n, d_n, h_grid[0], h_grid[1], h_grid[2], h_grid[3],
                                                               h_grid[4], h_grid[5], ilog2(P), (unsigned long long*)bits);
     PCC_LAUNCH_CHECK();
   }

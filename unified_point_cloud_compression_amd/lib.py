@@ -48,7 +48,7 @@ SIGNATURES = {
     "pcc_grid_words": (_i64, [C.POINTER(_i32)]),
     "pcc_grid_ws_bytes": (_sz, [_i64]),
     "pcc_grid_build": (C.c_int, [_p, _i64, C.POINTER(_i32), _p, _p, _p, _sz, _p]),
-    "pcc_coords_stride_grid": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pcc_coords_stride_grid": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_keys_canonicalize_grid": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_coords_expand_grid": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_expand_grid_csr_ws_bytes": (_sz, [_i64]),

@@ -165,9 +165,36 @@ class MeanScaleHyperprior(CompressionModel):
                                                               want_likelihood=False)
         if self.entropy_coder == "symbols":
             return [y.C, z.C], [y_sym, z_sym], [z._cset.n]
-        z_string = self.entropy_bottleneck.compress_rows(z_sym)
-        y_string = self.gaussian_conditional.compress_rows(y_sym, idx)
+        if self.entropy_coder == "pcc_streams":
+            z_string, y_string = self._code_streams(z_sym, y_sym, idx)
+        else:
+            z_string = self.entropy_bottleneck.compress_rows(z_sym)
+            y_string = self.gaussian_conditional.compress_rows(y_sym, idx)
         return [y.C, z.C], [[y_string], [z_string]], [z._cset.n]
+
+    def _code_streams(self, z_sym, y_sym, idx):
+        """Both strings with two device->host reads: the hyper-latent's container comes back in one copy that also carries
+        the payload estimate of y (which sizes y's stream count); y's container in the second."""
+        zj = self.entropy_bottleneck.streams_job(z_sym)
+        yj = self.gaussian_conditional.streams_job(y_sym, idx)
+        if zj.adaptive:                                   # large frames: the hyper-latent needs its own estimate first
+            est = L.counter(2)
+            zj.launch_estimate(est.data_ptr())
+            if yj.adaptive:
+                yj.launch_estimate(est.data_ptr() + 8)
+            ez, ey = L.read(est)
+            zj.launch_encode(ez)
+            yj.launch_encode(ey if yj.adaptive else None)
+            return zj.fetch(), yj.fetch()
+        zj.launch_encode()
+        if yj.adaptive:
+            yj.launch_estimate(zj.guest_ptr())
+        else:
+            yj.launch_encode()
+        z_string = zj.fetch()
+        if yj.adaptive:
+            yj.launch_encode(zj.guest)
+        return z_string, yj.fetch()
 
     def likelihoods(self, y, q):
         """Eval-mode likelihoods of y and z (what `forward` feeds the rate loss, `loss.py:63-81`)."""

@@ -150,8 +150,17 @@ class UnifiedModel(CompressionModel):
                 # plain coordinates (what a decoder gets: `utils.py:461-465`, `load_bitstream`): the canonical set of the
                 # rows (the reference builds `ME.SparseTensor(coordinates=points[0], tensor_stride=8)`, `model/entropy_models.py:439`)
                 y_cset = S.coordset_from_coords(block_coords.to(device), 8)[0]
-            # z coordinates: two k3-s2 `down_conv`s in the reference (`model/model.py:227-229`) = coordinate-only stride
-            z_cset = y_cset.stride(16).stride(32)
+            # z coordinates: two k3-s2 `down_conv`s in the reference (`model/model.py:227-229`) = coordinate-only stride;
+            # floor(floor(c/16)*16/32)*32 = floor(c/32)*32, so the stride-32 set comes straight from y's rows.  Everything
+            # else that depends on y's COORDINATES alone (first synthesis level: 5x5x5 pair list, candidate set) is queued
+            # with it and the sizes come back in one read.
+            ts_z = y_cset.ts * 4
+            if y_cset.n == 0:
+                z_cset = y_cset.stride(y_cset.ts * 2).stride(ts_z)
+            else:
+                z_cset = S.resolve(y_cset.stride_begin(ts_z), *self.g_s.plan(y_cset))[0]
+            if z_cset.n != int(block_shape[0]):
+                raise L.PccError(f"bitstream says {int(block_shape[0])} hyper-latent rows, the coordinates give {z_cset.n}")
             y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i], check=status)
             x_hat = self.g_s(y_hat, k=block_k, trace=trace, probe=probe)
             feats.append(x_hat.F)

@@ -60,8 +60,26 @@ class AnalysisTransform(nn.Module):
 
     count_per_batch = staticmethod(count_per_batch)
 
+    def plan(self, cs):
+        """Coordinate-only pre-pass (inference): every output set, kernel map and pair list of the transform depends on the
+        input COORDINATES alone, so they are all queued before the first feature kernel and the sizes the host needs (pair
+        counts of the three 5x5x5 128-channel layers) come back in ONE read instead of one per layer."""
+        pend = []
+        for seq in (self.down_conv_1, self.down_conv_2, self.down_conv_3):
+            for m in seq:
+                if isinstance(m, ME.MinkowskiConvolution):
+                    out = cs if m.stride == 1 else cs.stride(cs.ts * m.stride)   # (queued by the input set's stride chain)
+                    if m.kernel_volume > 1 or m.stride != 1:
+                        kmap = cs.kernel_map(out, m.kernel_size)
+                        if S.wants_pairs(m.kernel_volume, m.in_channels, m.out_channels):
+                            pend.append(kmap.pair_plan_begin())
+                    cs = out
+        S.resolve(*pend)
+
     def forward(self, x):
         """x -> (y, k) with k = rows per batch at strides [4, 2, 1] (`model/transforms.py:68-97`)."""
+        if not torch.is_grad_enabled():
+            self.plan(x._cset)
         k = [count_per_batch(x)]
         x = self.down_conv_1(x)
         k.append(count_per_batch(x))
@@ -204,8 +222,25 @@ class SparseSynthesisTransform(nn.Module):
             ok = out_set.n >= self.FUSE_NARROW_MIN_RATIO * cs.n
         return ok
 
-    def _up_predict_fused(self, up, head, x, k_lvl, probe=None, lvl=0):
-        """Returns (x pruned to the top-k rows, prediction over all candidate rows, mask)."""
+    def plan(self, cs):
+        """Coordinate-only work of the first level that depends on y's coordinates alone: the 5x5x5 map + pair list of
+        `up_1[0]` and the candidate set of `up_1`'s generative convolution.  Returns Pendings for the caller to resolve
+        together with whatever else it is waiting for (`UnifiedModel.decompress`: the hyper-latent's coordinate set)."""
+        pend = []
+        for m in list(self.up_1)[:-1]:
+            if isinstance(m, ME.MinkowskiConvolution) and m.stride == 1 and m.kernel_volume > 1:
+                kmap = cs.kernel_map(cs, m.kernel_size)
+                if S.wants_pairs(m.kernel_volume, m.in_channels, m.out_channels):
+                    pend.append(kmap.pair_plan_begin())
+        gen = self.up_1[-1]
+        if isinstance(gen, ME.MinkowskiGenerativeConvolutionTranspose) and cs.ts % gen.stride == 0 and cs.n > 0:
+            pend.append(cs.expand_begin(gen.kernel_size, cs.ts // gen.stride, want_csr=False))
+        return pend
+
+    def _up_predict_fused(self, up, head, x, k_lvl, probe=None, lvl=0, next_up=None):
+        """Returns (x pruned to the top-k rows, prediction over all candidate rows, mask).
+        next_up: the following level's up-sampling block -- its candidate set derives from the rows kept here, so that
+        expansion is queued with this level's last coordinate work and both sizes come back in one read."""
         for m in list(up)[:-1]:
             x = m(x)
         gen, c0, c2 = up[-1], head[0], head[2]
@@ -246,9 +281,17 @@ class SparseSynthesisTransform(nn.Module):
         if "_packed_conv" not in gen.__dict__:
             gen.__dict__["_packed_conv"] = S.PackedConv(transposed=False)
         packed = gen._packed_conv.get(gen.kernel, state_dict_order=True)
-        csr5 = cs_in.csr_for(kept.keys, n, 5, ts_out)
-        if L.load().pcc_conv_pairs_supported(125, gen.in_channels, gen.out_channels):
-            xk = S.convt_forward_rows(feats, packed, gen.bias, 125, gen.in_channels, gen.out_channels, csr5, n)
+        rows_form = bool(L.load().pcc_conv_pairs_supported(125, gen.in_channels, gen.out_channels))
+        total = L.counter() if rows_form else None
+        csr5 = cs_in.csr_for(kept.keys, n, 5, ts_out, total=total)
+        nxt = None
+        if next_up is not None and n > 0:
+            g2 = next_up[-1]
+            if isinstance(g2, ME.MinkowskiGenerativeConvolutionTranspose) and ts_out % g2.stride == 0:
+                nxt = kept.expand_begin(g2.kernel_size, ts_out // g2.stride, want_csr=False)
+        pairs = S.resolve(S.Pending(total, lambda v: int(v[0])) if rows_form else None, nxt)[0]
+        if rows_form:
+            xk = S.convt_forward_rows(feats, packed, gen.bias, 125, gen.in_channels, gen.out_channels, csr5, n, pairs_bound=pairs)
         else:       # narrow shapes: slot map of the kept rows + the generic convolution
             xk = S.conv_forward(feats, packed, gen.bias, 125, gen.in_channels, gen.out_channels,
                                 S.map_from_csr(csr5, cs_in.n, n, 5), n)
@@ -264,10 +307,11 @@ class SparseSynthesisTransform(nn.Module):
         the oracle's choice); probe("kept", lvl, kept set, None, None, kept features) observes the pruned tensor."""
         predictions = []
         x = y
+        ups = (self.up_1, self.up_2, self.up_3)
         for lvl, (up, head) in enumerate(((self.up_1, self.predict_1), (self.up_2, self.predict_2),
                                           (self.up_3, self.predict_3))):
             if coords is None and trace is None and self._can_fuse(up, head, x if lvl else y):
-                x, pred, _ = self._up_predict_fused(up, head, x, k[lvl], probe, lvl)
+                x, pred, _ = self._up_predict_fused(up, head, x, k[lvl], probe, lvl, ups[lvl + 1] if lvl < 2 else None)
                 predictions.append(pred)
                 continue
             x = up(x)

@@ -137,7 +137,7 @@ class Pending:
     sizes with one device->host copy: the host reads of a step are batched per level instead of one per derived object
     (round 2: ~33 reads per step, each leaving the GPU idle until the host had queued the next kernels)."""
 
-    __slots__ = ("counter", "finish", "result", "done")
+    __slots__ = ("counter", "finish", "result", "done", "keys_out", "cap")
 
     def __init__(self, counter, finish):
         self.counter, self.finish, self.result, self.done = counter, finish, None, False
@@ -245,11 +245,12 @@ class CoordSet:
         return self._bands or None
 
     # ---- derived sets ------------------------------------------------------------------------
-    def stride_begin(self, new_stride, known_n=None, keys=None, n_keys=None):
+    def stride_begin(self, new_stride, known_n=None, keys=None, n_keys=None, d_n=None):
         """Queue the strided set unique(floor(c/m)*m) (a2-i); returns a Pending that yields the CoordSet.
         known_n: the row count when the caller has it (the decoder knows the hyper-latent's from the bitstream): the set
         is complete without a read.  keys / n_keys: take the rows from this key array instead (ANY order, duplicates
-        allowed -- marking a coarse cell is idempotent), e.g. the un-canonicalised user rows or a finer ancestor."""
+        allowed -- marking a coarse cell is idempotent), e.g. the un-canonicalised user rows or a finer ancestor; d_n: a
+        counter() holding the number of valid rows of `keys` when the host has not read it yet (n_keys = capacity)."""
         key = ("stride", new_stride)
         if key in self._derived:
             return _ready(self._derived[key])
@@ -269,7 +270,7 @@ class CoordSet:
             bits = torch.empty(words, dtype=torch.int64, device=dev)
             rank = torch.empty(words, dtype=torch.int32, device=dev)
             ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
-            L.call("pcc_coords_stride_grid", L.ptr(src), n_src, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
+            L.call("pcc_coords_stride_grid", L.ptr(src), n_src, L.cptr(d_n) if d_n is not None else None, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
                    L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
         else:
             if keys is not None:
@@ -288,7 +289,9 @@ class CoordSet:
             return cs
         if known_n is not None:
             return _ready(finish([known_n]))
-        return Pending(cnt, finish)
+        p = Pending(cnt, finish)
+        p.keys_out, p.cap = out, cap
+        return p
 
     def stride(self, new_stride):
         """Output set of a strided conv (a2-i): unique(floor(c/m)*m)."""
@@ -299,16 +302,20 @@ class CoordSet:
 
     def stride_chain_begin(self, strides, keys=None, n_keys=None):
         """Queue the whole chain self -> stride(s0) -> stride(s1) -> ... (the analysis transform's and the hyper-analysis'
-        output sets), every set straight from THIS set's rows -- unique(floor(c/m)*m) does not care which finer ancestor it
-        is taken from -- so that none waits for the previous one's row count.  One Pending; it links the chain into the
-        `_derived` caches the convolution modules look the sets up in."""
+        output sets) without a host read between the links: each link takes its rows from the previous link's output
+        buffer, whose row count stays on the device (`pcc_coords_stride_grid` d_n).  One Pending; it links the chain into
+        the `_derived` caches the convolution modules look the sets up in."""
         if not (USE_GRID and STRIDE_BY_GRID and self.n > 0):
             return None
         src, n_src = (self.keys, self.n) if keys is None else (keys, n_keys)
         parts = []
+        d_n = None
         for m in strides:
             t = CoordSet(self.keys, self.n, self.ts, self.bounds)          # carrier of the bounds; its own cache is discarded
-            parts.append((m, t.stride_begin(m, keys=src, n_keys=n_src)))
+            pend = t.stride_begin(m, keys=src, n_keys=n_src, d_n=d_n)
+            parts.append((m, pend))
+            # the next link reads the rows this one writes, with their count still on the device (capacity = this link's)
+            src, n_src, d_n = pend.keys_out, pend.cap, pend.counter
 
         def finish(vals):
             parent = self
@@ -641,6 +648,12 @@ class PackedConv:
         return self.packed
 
 
+def wants_pairs(K, cin, cout):
+    """Does conv_forward try the pair-list form for this shape?  (The coordinate pre-passes of g_a / g_s queue the pair
+    plans of such layers ahead of the features, so that their sizes are read together.)"""
+    return bool(K >= PAIR_MIN_K and cin >= PAIR_MIN_CIN and L.load().pcc_conv_pairs_supported(K, cin, cout))
+
+
 def conv_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NONE, slope=0.01):
     """out[o] = act(bias + sum_k feats[nbr_k(o)] @ W[k])  -- a2-iii / a3."""
     feats = feats.contiguous()
@@ -648,7 +661,7 @@ def conv_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NON
     if n_out == 0:
         return out
     b = bias.detach().reshape(-1).contiguous() if bias is not None else None
-    if kmap is not None and K >= PAIR_MIN_K and cin >= PAIR_MIN_CIN and L.load().pcc_conv_pairs_supported(K, cin, cout):
+    if kmap is not None and wants_pairs(K, cin, cout):
         plan = kmap.pair_plan()
         if plan is not None:           # sparse map: gathered GEMM over the compacted pairs, then ordered reduce
             pos, pair_in, tile_k, info, padded = plan

@@ -1045,6 +1045,15 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
   }
 }
 
+// (Round 3, tools/gemm_h2_probe.py + PCC_DBG on the level-2 composite shape 58 051 x 128 x 21 952, and tools/write_probe.hip:
+//  the chip stores this 5.1 GB buffer in 0.90 ms at best (5.65 TB/s, this kernel's own store pattern, any occupancy); this
+//  kernel takes 1.68-1.78 = LDS skeleton 0.38 + loads 0.05 + MFMA 0.27 + stores 0.56 measured one at a time, but loads + stores
+//  + skeleton = 1.36 = (loads + skeleton 0.43) + (stores + skeleton 0.94): L2 reads and HBM-bound stores of one CU do not
+//  overlap, whatever issues them.  Built and measured against it, bit-identical results, all slower and removed: start-up skew
+//  between the workgroups of a CU (no change); a persistent LDS-DMA chunk stream (global_load_lds into a 4-slot ring three
+//  chunks ahead, operands stored in HBM in the LDS image, 16-byte stores after a quad transpose): 2.17 ms with every wave
+//  loading and storing (vmcnt orders a wave's stores with its loads), 2.15 ms with four loader waves and eight store-only
+//  compute waves, 2.08 with nt / write-through stores; its loads + stores alone take 2.0 ms.  DESIGN.md section 8.)
 // The dense products in scaled fp16 pairs (see k_feat_split_h): the structure of k_gemm_bf2 with two planes per operand
 // (8 units of 16 bytes per 32-channel piece, LDS rows of 9 units: 9 is odd, so a fragment read's 16 rows fall on 16 different
 // bank quads), three MFMA terms, and the row and column scales applied to the accumulators on the way out.
@@ -3660,6 +3669,12 @@ __global__ void __launch_bounds__(256) k_thin_gather_grid1(ThinGridArgs a) {
   a.out[p] = acc + (a.bias ? a.bias[0] : 0.f);
 }
 
+// (Round 3 built a one-pass form of this convolution -- gather the 27 neighbours' hidden rows and dot them with w2 in
+//  registers, dz = +-1 terms taken from the adjacent candidate by lane shuffle -- three times: columns walked one after the
+//  other (latency-bound, +0.8 ms per step), all loads independent with index arithmetic per lane (issue-bound, +1.6 ms), index
+//  arithmetic once per row and four lanes per row for coalesced 64-byte loads (+1.1 ms: 1.59 ms on the last level against
+//  0.55 + 0.60 for project + gather).  Moving 9 x 64 B per output through L1 costs more than writing 27 floats per row and
+//  gathering 27 x 4 B: the two-kernel form stays.)
 extern "C" size_t pcc_thin_grid_ws_bytes(int64_t n, int32_t cout) { return (size_t)27 * cout * (size_t)(n > 0 ? n : 1) * sizeof(float) + 256; }
 
 extern "C" int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin, const float* packed_w /*thin layout [27][cout][cin]*/,

@@ -212,6 +212,13 @@ int pcc_set_mfma_split(int32_t on);
 /* dense products of the generative transposed convolutions in scaled fp16 pairs (three MFMA terms; default on) or the
  * six-term bf16 form (0); both at fp32 accuracy, tests/test_gpu_map_conv.py::test_dense_products_accuracy. */
 int pcc_set_gemm_h(int32_t on);
+/* Range guard of the three-term fp16 form.  The form carries every element within 2^-18 of its row /
+ * column maximum to >= 22 bits and smaller ones with an absolute error of 2^-28 of that maximum, so a product of depth cin is
+ * off by at most cin * 2^-27 * max|row| * max|column| beyond fp32 behaviour.  With a guard word set, every fp16-pair launch
+ * ORs 1 into *d_flag (device int32, zeroed by the caller) when the scales of one of its tiles admit more than `budget`
+ * (absolute, in output units); the caller reads the word with a size it reads anyway and repeats the operation under
+ * pcc_set_gemm_h(0) (six-term bf16 form: 24 bits per element, no range condition).  NULL switches the guard off. */
+int pcc_set_h_guard(int32_t* d_flag, float budget);
 int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
 /* W: ME layout [K, cin, cout] row-major (state_dict `kernel`).  packed_cap: floats available at
  * `packed`; a buffer smaller than pcc_conv_packed_elems(K, cin, cout) is refused (PCC_EWS), never written past. */

@@ -339,12 +339,17 @@ class StreamsJob:
     def guest_ptr(self):
         return self.blob.data_ptr() + 8
 
+    def attach(self, word):
+        """Carry a 4-byte device word (int32 [1]) home in header bytes 16-19 of the next fetch (`self.guest2`)."""
+        self.blob[16:20].copy_(word.view(torch.uint8))
+
     def fetch(self):
         H = self.em.HDR
         take = self.blob.numel() if self.guess is None else H + self.guess
         host = self.blob[:take].cpu().numpy()
         nbytes = int(host[:8].view(np.int64)[0])
         self.guest = int(host[8:16].view(np.int64)[0])
+        self.guest2 = int(host[16:20].view(np.int32)[0])
         if nbytes > take - H:                                   # the estimate fell short: fetch the rest
             host = self.blob[:H + nbytes].cpu().numpy()
         return host[H:H + nbytes].tobytes()

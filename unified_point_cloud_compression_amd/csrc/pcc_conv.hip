@@ -49,6 +49,8 @@ struct ConvArgs {
   bool wh_ok = false;                   // dense products: the pack carries scaled fp16 planes + column scales (split_planes_h)
   const unsigned char* feath = nullptr; //   scaled fp16 planes of feat, [n_in][cin/32][2][32] (k_feat_split_h)
   const float* frow_inv = nullptr;      //   and 1 / (power-of-two scale) of every feature row
+  int* guard = nullptr;                 //   range guard of the fp16-pair products (pcc_set_h_guard): set to 1 when a (row, column) pair of
+  float guard_lim = 0.f;                //   a tile has rinv * cinv * 8 * cin > guard_lim, i.e. max|row| * max|column| * cin * 2^-27 may exceed the budget
   int cin, cout, cout_pad;
   int cb_log2;            // log2(CB), CB = min(cin, 32)
   int ppo;                // pieces per offset = cin / CB
@@ -583,6 +585,18 @@ static int make_planes(ConvArgs& a, bool take_abs, hipStream_t s) {
   return PCC_OK;
 }
 
+// Range guard of the fp16-pair products: a device word the kernels OR 1 into when a tile's scales admit an absolute product
+// error above `budget` (cin * 2^-27 * max|row| * max|column| > budget); NULL switches the guard off.  The caller zeroes the
+// word, reads it back with a size it reads anyway, and repeats the operation with pcc_set_gemm_h(0) when it is set.
+static int* g_h_guard = nullptr;
+static float g_h_guard_lim = 0.f;
+extern "C" int pcc_set_h_guard(int32_t* d_flag, float budget) {
+  PCC_REQUIRE(!d_flag || budget > 0.f, "pcc_set_h_guard: the budget must be positive");
+  g_h_guard = d_flag;
+  g_h_guard_lim = d_flag ? budget : 0.f;                   // compared with cin * 2^-27 * (rinv * 2^15) * (cinv * 2^15) = rinv * cinv * 8 * cin
+  return PCC_OK;
+}
+
 static int make_planes_h(ConvArgs& a, hipStream_t s) {
   PCC_REQUIRE(a.cin % 32 == 0 && a.cin <= 512, "dense products: cin=%d (needs a multiple of 32 up to 512)", a.cin);
   void* p = nullptr;
@@ -596,6 +610,8 @@ static int make_planes_h(ConvArgs& a, hipStream_t s) {
   PCC_LAUNCH_CHECK();
   a.feath = (const unsigned char*)p;
   a.frow_inv = (const float*)((char*)p + plane_bytes);
+  a.guard = g_h_guard;
+  a.guard_lim = g_h_guard_lim;
   return PCC_OK;
 }
 
@@ -1011,6 +1027,10 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
   }
   if (a.dbg & 1) { if (acc[0][0][0] != 12345.678f) return; }
 
+  // ---- range guard: the elements of a row / column far below its maximum are carried with an
+  //      ABSOLUTE error of 2^-28 of that maximum, so a product's error can reach cin * 2^-27 * max|row| * max|column|; the
+  //      scales bound the maxima (max < 2^15 / scale).  A lane's rows x a lane's columns are exactly its outputs.
+  // (evaluated on the row scales the epilogue reads anyway)
   // ---- stores: element e of acc[i][j] is row wm*64 + i*32 + (e&3) + 8*(e>>2) + 4*half, column wn*64 + j*32 + r31 of the tile
   const unsigned ncol = (unsigned)a.cout;
   float* const obase = a.out + (size_t)p0 * ncol + colblock;
@@ -1168,12 +1188,14 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
   const bool full = npos == BM && (unsigned)colblock + BN <= ncol;
   const int row_lim = npos - wm * 64 - 4 * half;
   const int col_lim = (int)ncol - colblock - wn * 64 - r31;
+  float guard_mr = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int e4 = 0; e4 < 4; ++e4) {
       const float4 r4 = *reinterpret_cast<const float4*>(&rs[wm * 64 + i * 32 + 8 * e4 + 4 * half]);
       const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+      guard_mr = fmaxf(guard_mr, fmaxf(fmaxf(r4.x, r4.y), fmaxf(r4.z, r4.w)));
 #pragma unroll
       for (int e1 = 0; e1 < 4; ++e1) {
         const int e = e4 * 4 + e1;
@@ -1191,6 +1213,10 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
         }
       }
     }
+  // range guard: elements of a row / column far below its maximum are carried with an ABSOLUTE error of
+  // 2^-28 of that maximum, so a product's error can reach cin * 2^-27 * max|row| * max|column|; the scales bound the maxima
+  // (max < 2^15 / scale).  A lane's rows x a lane's columns are exactly its outputs.
+  if (a.guard && guard_mr * fmaxf(cs[0], cs[1]) * (8.f * (float)a.cin) > a.guard_lim) atomicOr(a.guard, 1);
 }
 
 // The gathered pair GEMM (pcc_conv_fwd_pairs, pcc_convt_fwd_rows: one kernel offset per 128-pair tile, T[pair] = x[in(pair)] W[k])
@@ -1299,12 +1325,14 @@ __global__ void __launch_bounds__(256, 3) k_pair_h2(ConvArgs a) {
   const unsigned vO = ((unsigned)(wm * 64 + 4 * half) * ncol + (unsigned)(wn * 64 + r31)) * 4u;
   const bool full = (unsigned)colblock + BN <= ncol;
   const int col_lim = (int)ncol - colblock - wn * 64 - r31;
+  float guard_mr = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int e4 = 0; e4 < 4; ++e4) {
       const float4 r4 = *reinterpret_cast<const float4*>(&rs[wm * 64 + i * 32 + 8 * e4 + 4 * half]);
       const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+      guard_mr = fmaxf(guard_mr, fmaxf(fmaxf(r4.x, r4.y), fmaxf(r4.z, r4.w)));
 #pragma unroll
       for (int e1 = 0; e1 < 4; ++e1) {
         const int e = e4 * 4 + e1;
@@ -1321,6 +1349,7 @@ __global__ void __launch_bounds__(256, 3) k_pair_h2(ConvArgs a) {
         }
       }
     }
+  if (a.guard && guard_mr * fmaxf(cs[0], cs[1]) * (8.f * (float)a.cin) > a.guard_lim) atomicOr(a.guard, 1);   // range guard, as in k_gemm_h2
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3549,7 +3578,7 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
     const long long r0 = (long long)c * chunk_rows;
     const long long rows = r0 + chunk_rows < n_in ? chunk_rows : n_in - r0;
     a.feat = feat_in + r0 * cin; a.n_in = rows; a.n_out = rows;
-    if (use_h) { a.feath = planes + (size_t)r0 * cin * 4; a.frow_inv = row_inv + r0; }
+    if (use_h) { a.feath = planes + (size_t)r0 * cin * 4; a.frow_inv = row_inv + r0; a.guard = g_h_guard; a.guard_lim = g_h_guard_lim; }
     else a.featb = planes ? planes + (size_t)r0 * cin * 6 : nullptr;
     hipEvent_t e0, e1;
     if (g_prof_on) PCC_TRY(prof_event(&e0, s));

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pcc_convt_scatter_rows": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_convt_fwd_csr_grid": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p, _p, _p, C.POINTER(_i32), _p, _p]),
     "pcc_set_gemm_h": (C.c_int, [_i32]),
+    "pcc_set_h_guard": (C.c_int, [_p, _f32]),
     "pcc_set_t_chunk_bytes": (C.c_int, [_i64]),
     "pcc_convt_chunk_t_bytes": (_sz, [_i64, _i32, _i32]),
     "pcc_convt_chunk_ws_bytes": (_sz, [_i64, _i32, _i32]),
@@ -248,6 +249,27 @@ def read_many(counters):
                 v = blk.tolist()
                 return [v[t.storage_offset() - lo:t.storage_offset() - lo + t.numel()] for t in counters]
     return [read(t) for t in counters]
+
+
+# ---- range guard of the three-term fp16 products (include/pcc_hip.h: pcc_set_h_guard) ----------------
+H_GUARD_BUDGET = 2.5e-5     # absolute error the scales of a tile may admit before the operation is repeated in the six-term form:
+#                             a quarter of the 1e-4 parity bar (cin * 2^-27 * max|row| * max|column|: 26 for cin = 128; the
+#                             benchmark's layers stay below 0.5, tools/fp16_ranges.py)
+_guard = {}
+
+
+class RangeGuardTripped(Exception):
+    """An fp16-pair product saw operands whose range admits more than H_GUARD_BUDGET of absolute error."""
+
+
+def h_guard(device):
+    """The guard word of `device` (int32 [1], zero unless a launch tripped it), installed in the library on first use."""
+    key = torch.device(device).index or 0
+    g = _guard.get(key)
+    if g is None:
+        g = _guard[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        call("pcc_set_h_guard", g.data_ptr(), H_GUARD_BUDGET)
+    return g
 
 
 def call(name, *args):

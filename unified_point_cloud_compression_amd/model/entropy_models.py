@@ -177,6 +177,7 @@ class MeanScaleHyperprior(CompressionModel):
         the payload estimate of y (which sizes y's stream count); y's container in the second."""
         zj = self.entropy_bottleneck.streams_job(z_sym)
         yj = self.gaussian_conditional.streams_job(y_sym, idx)
+        guard = L.h_guard(z_sym.device)                   # every matrix product of the encoder is queued by now: its range guard
         if zj.adaptive:                                   # large frames: the hyper-latent needs its own estimate first
             est = L.counter(2)
             zj.launch_estimate(est.data_ptr())
@@ -184,16 +185,22 @@ class MeanScaleHyperprior(CompressionModel):
                 yj.launch_estimate(est.data_ptr() + 8)
             ez, ey = L.read(est)
             zj.launch_encode(ez)
+            zj.attach(guard)
             yj.launch_encode(ey if yj.adaptive else None)
-            return zj.fetch(), yj.fetch()
-        zj.launch_encode()
-        if yj.adaptive:
-            yj.launch_estimate(zj.guest_ptr())
+            z_string = zj.fetch()
         else:
-            yj.launch_encode()
-        z_string = zj.fetch()
-        if yj.adaptive:
-            yj.launch_encode(zj.guest)
+            zj.launch_encode()
+            zj.attach(guard)                              # ... travels in the header of the hyper-latent's container
+            if yj.adaptive:
+                yj.launch_estimate(zj.guest_ptr())
+            else:
+                yj.launch_encode()
+            z_string = zj.fetch()
+            if yj.adaptive:
+                yj.launch_encode(zj.guest)
+        if zj.guest2:
+            guard.zero_()
+            raise L.RangeGuardTripped()
         return z_string, yj.fetch()
 
     def likelihoods(self, y, q):

@@ -94,6 +94,19 @@ class UnifiedModel(CompressionModel):
 
     @torch.no_grad()
     def compress(self, pointcloud, q, path=None, block_size=1024, scaling_factor=1.0):
+        """`UnifiedModel.compress` (`model/model.py:94-187`).  The matrix products run in the three-term fp16 form under its
+        range guard: should a layer's operands leave the range the form's error bound covers, the
+        block is coded again with every product in the six-term 24-bit form."""
+        try:
+            return self._compress(pointcloud, q, path, block_size, scaling_factor)
+        except L.RangeGuardTripped:
+            L.call("pcc_set_gemm_h", 0)
+            try:
+                return self._compress(pointcloud, q, path, block_size, scaling_factor)
+            finally:
+                L.call("pcc_set_gemm_h", 1)
+
+    def _compress(self, pointcloud, q, path=None, block_size=1024, scaling_factor=1.0):
         if path and self.entropy_model.entropy_coder == "symbols":
             raise L.PccError("path= needs byte strings: build the model with entropy_coder 'pcc_streams' or 'ans'")
         if not pointcloud.is_cuda:
@@ -135,6 +148,18 @@ class UnifiedModel(CompressionModel):
     @torch.no_grad()
     def decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None, q_vals=None, trace=None,
                    probe=None):
+        """`UnifiedModel.decompress` (`model/model.py:189-250`), under the same range guard as `compress`."""
+        try:
+            return self._decompress(path, coordinates, strings, shape, k, q_vals, trace, probe)
+        except L.RangeGuardTripped:
+            L.call("pcc_set_gemm_h", 0)
+            try:
+                return self._decompress(path, coordinates, strings, shape, k, q_vals, trace, probe)
+            finally:
+                L.call("pcc_set_gemm_h", 1)
+
+    def _decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None, q_vals=None, trace=None,
+                    probe=None):
         device = self.g_s.down_conv.kernel.device
         if path:
             coordinates, strings, shape, k, q_vals = self.load_bitstream(path)
@@ -165,8 +190,13 @@ class UnifiedModel(CompressionModel):
             x_hat = self.g_s(y_hat, k=block_k, trace=trace, probe=probe)
             feats.append(x_hat.F)
             coords.append(x_hat.C)
-        if status and int(torch.stack(status).abs().max().item()) != 0:     # one deferred check for all rANS containers
+        guard = L.h_guard(device)
+        flags = torch.cat([s.reshape(-1)[:1].to(torch.int32) for s in status] + [guard]).tolist()   # one deferred read: rANS containers + range guard
+        if any(flags[:-1]):
             raise L.PccError("malformed rANS container in the bitstream")
+        if flags[-1]:
+            guard.zero_()
+            raise L.RangeGuardTripped()
         f = torch.cat(feats, dim=0)
         c = torch.cat(coords, dim=0)
         f = torch.clamp(torch.round(f * 255), 0.0, 255.0) / 255

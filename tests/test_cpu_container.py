@@ -98,3 +98,53 @@ def test_corrupt_headers_fail_loudly(tmp_path):
         container.decode_points(b"\x00" * 8)
     with pytest.raises(L.PccError):
         container.decode_points(struct.pack("<iiiiB", 0, 0, 0, 0, 3) + b"\x00" * 16)          # pitch 0
+
+
+def test_file_records_the_stream_geometry_and_old_files_still_load(tmp_path):
+    """A file written today must decode with a build whose coder constants differ: the channel-group count of both strings is
+    in the block header (format version 2) and overrides what `n_streams` would derive; a headerless version-1 file (round 2)
+    still loads, with the geometry derived as before; a wrong magic / version is refused."""
+    import struct
+    from unified_point_cloud_compression_amd.compressai.entropy_models import EntropyModel
+    c = _cells(3, 5, 120).astype(np.int64) * 8
+    c = c[np.lexsort((c[:, 2], c[:, 1], c[:, 0]))]
+    coords = torch.from_numpy(np.concatenate([np.zeros((len(c), 1), np.int64), c], 1)).int()
+    n, ch = 870, 192
+    em = EntropyModel()
+    ng_now, _ = em.n_streams(n, ch)
+    y = container.StreamBytes(struct.pack("<I", 128 * 3) + b"y" * 64, 128)
+    z = container.StreamBytes(struct.pack("<I", ng_now * 2) + b"z" * 32, ng_now)
+    path = os.path.join(tmp_path, "v2.bin")
+    container.save_bitstream(path, [coords], [[[y], [z]]], [[n]], [[[5], [50], [500]]], [torch.tensor([[0.5, 0.5]])])
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"PCCB" and struct.unpack_from("<H", raw, 4)[0] == 2
+    _, strings, _, _, _ = container.load_bitstream(path)
+    ys, zs = strings[0][0][0], strings[0][1][0]
+    assert bytes(ys) == bytes(y) and ys.groups == 128 and zs.groups == ng_now
+    old = EntropyModel.STREAM_SYMBOLS
+    try:
+        EntropyModel.STREAM_SYMBOLS = old * 8                       # a build tuned differently derives another group count ...
+        assert em.n_streams(n, ch)[0] != ng_now
+        assert em._segments_of(zs, n, ch) == (ng_now, 2)            # ... but cuts the file's container as it was written
+        assert em._segments_of(bytes(zs), n, ch)[0] != ng_now       # (plain bytes: derived from the constants, as in memory)
+    finally:
+        EntropyModel.STREAM_SYMBOLS = old
+    # a version-1 file: the same blocks without format word and geometry
+    v1 = raw[8:12] + raw[12:12 + 44] + raw[12 + 48:]
+    p1 = os.path.join(tmp_path, "v1.bin")
+    open(p1, "wb").write(v1)
+    c1, s1, sh1, k1, _ = container.load_bitstream(p1)
+    assert np.array_equal(c1[0].numpy(), c.astype(np.int32)) and bytes(s1[0][0][0]) == bytes(y) and s1[0][0][0].groups == 0
+    assert sh1 == [[n]] and k1 == [[[5], [50], [500]]]
+    bad = os.path.join(tmp_path, "bad.bin")
+    open(bad, "wb").write(raw[:4] + struct.pack("<H", 9) + raw[6:])
+    with pytest.raises(Exception, match="version"):
+        container.load_bitstream(bad)
+
+
+def test_dense_latent_block_is_not_rejected_by_the_point_count_bound():
+    """A fully occupied 32^3 latent block codes at far more than 64 points per payload byte (the old sanity bound)."""
+    g = np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(32), indexing="ij"), -1).reshape(-1, 3).astype(np.int64) * 8
+    data = container.encode_points(g)
+    assert len(g) / (len(data) - 17) > 64
+    assert np.array_equal(container.decode_points(data), g[np.lexsort((g[:, 2], g[:, 1], g[:, 0]))].astype(np.int32))

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Frame-parallel evaluation sweep (BASELINE configs 3 and 5): synthetic vox10-like / vox11-like frames are assigned to the
-ranks (one process per GPU, longest first), each rank codes its frames to byte strings and decodes them, measures
-bits / point and the D1 / colour PSNRs on its GPU, and one all_gather of fixed-size records ends the sweep
-(`evaluate.py:102-195` without the external tools).  Single process: python tools/eval_frames.py [--bits 9 9 10]
+"""Block-parallel evaluation sweep (BASELINE configs 3 and 5): synthetic vox10-like / vox11-like frames are cut
+into their blocks (`partition`), the (frame, block) items are assigned to the ranks (one process per GPU, longest first over
+ALL items, so a vox11 frame's >= 8 blocks spread over the node), each rank codes its items to byte strings and decodes
+them from plain coordinates, measures bits and the block-local D1 numerators on its GPU, and one all_gather of fixed-size
+records ends the sweep; per-frame totals are summed from the block records (`evaluate.py:102-195` without the external tools).  Single process: python tools/eval_frames.py [--bits 9 9 10]
 N GPUs:  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/eval_frames.py"""
 import argparse
 import os
@@ -29,54 +30,77 @@ dev = torch.device("cuda", local)
 model = bench.build_model(dev)
 q = torch.tensor([[0.5, 0.5]], device=dev)
 clouds = {}
+torch.set_num_threads(max(1, (os.cpu_count() or 1) // max(world, 1)))        # the host cores are shared by the ranks of the node
 
 
 def cloud(i):
     if i not in clouds:
-        clouds[i] = synth.surface_cloud(seed=i, bits=args.bits[i])
+        clouds[i] = torch.from_numpy(synth.surface_cloud(seed=i, bits=args.bits[i])).to(dev)
     return clouds[i]
 
 
-sizes = [int(0.75 * 4 ** b) for b in args.bits]          # surface area grows with the square of the resolution
+def block_size(i):
+    return args.block_size or (1024 if args.bits[i] <= 10 else 512)
 
 
-def process(i):
-    pc = torch.from_numpy(cloud(i)).to(dev)
-    bs = args.block_size or (1024 if args.bits[i] <= 10 else 512)
+# ---- partition pass: frames dealt round-robin, every rank learns every frame's block sizes (the work list) -------------------
+frame_blocks = {}
+local_sizes = {}
+for i in range(len(args.bits)):
+    if i % world == rank:
+        frame_blocks[i] = model.blocks_of(cloud(i), block_size(i))
+        local_sizes[i] = [int(b.shape[0]) for b in frame_blocks[i]]
+sizes = frames.gather_block_sizes(local_sizes, dev, rank, world)
+balance = frames.load_balance(sizes, world)
+
+
+def blocks(i):
+    if i not in frame_blocks:
+        frame_blocks[i] = model.blocks_of(cloud(i), block_size(i))
+    return frame_blocks[i]
+
+
+def process(f, b):
+    """One (frame, block) item: code, decode from plain coordinates, block-local D1 numerators."""
+    x = blocks(f)[b]
     torch.cuda.synchronize(); t0 = time.time()
-    out = model.compress(pc, q, block_size=bs)
+    strings, shape, k, yc = model.compress_block(x, q)
     torch.cuda.synchronize(); t1 = time.time()
-    rec = model.decompress(coordinates=[c.clone() for c in out[3]], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
+    rec = model.decompress(coordinates=[yc.clone()], strings=[strings], shape=[shape], k=[k], q_vals=[q])
     torch.cuda.synchronize(); t2 = time.time()
-    rep = metrics.pointcloud_metrics(pc, rec, resolution=(1 << args.bits[i]) - 1)
-    extra[i] = (rep["sym_psnr_mse"], rep["sym_y_psnr"], len(out[0]))
-    return (i, pc.shape[0], t1 - t0, t2 - t1, metrics.count_bits(out[0]), rec.shape[0])
+    rep = metrics.pointcloud_metrics(x, rec, resolution=(1 << args.bits[f]) - 1)
+    return (f, b, x.shape[0], t1 - t0, t2 - t1, metrics.count_bits([strings]), rec.shape[0],
+            rep["AB_mse"] * x.shape[0], x.shape[0], rep["BA_mse"] * rec.shape[0], rec.shape[0])
 
 
-extra = {}
-for i in frames.assign(sizes, world)[rank][:1]:
-    process(i)                                         # warm-up on this rank's first frame (allocator, weight packing)
-extra.clear()
+items = frames.block_items(sizes)
+mine = frames.assign([n for _, _, n in items], world)[rank]
+if mine:
+    process(*items[mine[0]][:2])                       # warm-up on this rank's first item (allocator, weight packing)
 if world > 1:
     dist.barrier(device_ids=[local])
 torch.cuda.synchronize()
 t_wall0 = time.time()
-recs = frames.run_sharded(sizes, process, dev, rank, world)
+recs, totals = frames.run_sharded_blocks(sizes, process, dev, rank, world)
 torch.cuda.synchronize()
 wall = torch.tensor([time.time() - t_wall0], dtype=torch.float64, device=dev)
 if world > 1:
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)        # the sweep ends when the slowest rank ends
 wall = float(wall.item())
 if rank == 0:
-    print(f"{'frame':>5s} {'points':>9s} {'enc ms':>8s} {'dec ms':>8s} {'bpp':>7s} {'decoded':>9s}")
-    for r in recs:
-        print(f"{int(r[0]):5d} {int(r[1]):9d} {r[2] * 1e3:8.1f} {r[3] * 1e3:8.1f} {r[4] / r[1]:7.3f} {int(r[5]):9d}")
-    tot = sum(r[1] for r in recs)
-    print(f"{len(recs)} frames, {tot} points in {wall:.3f} s wall (max over ranks, includes the D1 / colour report of every "
-          f"frame) = {tot / wall / 1e6:.2f} M points/s over {world} rank(s); coding time alone, perfectly balanced: "
-          f"{tot / sum(r[2] + r[3] for r in recs) * world / 1e6:.1f} M points/s")
-for i, (d1, y, nb) in sorted(extra.items()):
-    print(f"rank {rank} frame {i}: blocks {nb}  sym D1-PSNR {d1:.2f} dB  sym Y-PSNR {y:.2f} dB", flush=True)
+    print(f"{'frame':>5s} {'blocks':>6s} {'points':>9s} {'enc ms':>8s} {'dec ms':>8s} {'bpp':>7s} {'decoded':>9s} {'D1 dB':>7s}")
+    import math
+    for f, t in sorted(totals.items()):
+        res = (1 << args.bits[f]) - 1
+        mse = max(t["mse_ab"], t["mse_ba"])
+        d1 = 10 * math.log10(res * res / mse) if mse > 0 else float("inf")
+        print(f"{f:5d} {t['blocks']:6d} {t['n_points']:9d} {t['t_encode'] * 1e3:8.1f} {t['t_decode'] * 1e3:8.1f} {t['bpp']:7.3f} "
+              f"{t['n_decoded']:9d} {d1:7.2f}")
+    tot = sum(t["n_points"] for t in totals.values())
+    busy = sum(t["t_encode"] + t["t_decode"] for t in totals.values())
+    print(f"{len(totals)} frames as {len(recs)} (frame, block) items over {world} rank(s): {tot} points in {wall:.3f} s wall (max over "
+          f"ranks, includes the block-local D1 report) = {tot / wall / 1e6:.2f} M points/s; point load max/mean over ranks {balance:.3f}; "
+          f"coding time alone, perfectly balanced: {tot / busy * world / 1e6:.1f} M points/s")
 if world > 1:
     dist.barrier(device_ids=[local])
     dist.destroy_process_group()

@@ -66,6 +66,7 @@ class EntropyModel(nn.Module):
             raise L.PccError(f"unknown entropy coder {self.entropy_coder!r}")
         self.entropy_coder_precision = int(entropy_coder_precision)
         self.use_likelihood_bound = likelihood_bound > 0
+        self._likelihood_bound_value = float(likelihood_bound)
         if self.use_likelihood_bound:
             self.likelihood_lower_bound = LowerBound(likelihood_bound)
         self.register_buffer("_offset", torch.IntTensor())
@@ -152,7 +153,8 @@ class EntropyModel(nn.Module):
         L.call("pcc_rans_encode_streams", L.ptr(sym), L.ptr(idx.contiguous()) if idx is not None else None, n, c, ng, segs,
                L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs), L.ptr(self._enc_table(dev)), L.ptr(out), L.cptr(nb),
                L.ptr(ws), ws.numel(), L.stream())
-        return out[:int(L.read(nb)[0])].cpu().numpy().tobytes()
+        from ...container import StreamBytes
+        return StreamBytes(out[:int(L.read(nb)[0])].cpu().numpy().tobytes(), ng)
 
     # ---- the same coding, split so that a caller with several matrices to code shares the host reads --------------------
     HDR = 64                 # bytes in front of a container in its device blob: int64 nbytes | int64 guest word | padding
@@ -184,6 +186,9 @@ class EntropyModel(nn.Module):
         """(groups, segments) of a container: the group count follows from (n, c), the segment count from the stream count
         in its first word (the encoder may have raised it, `_adaptive_segments`)."""
         ng, segs = self.n_streams(n, c)
+        g = int(getattr(data, "groups", 0) or 0)           # a string read from a file carries its channel-group count
+        if g > 0 and c % g == 0:
+            ng = g
         if len(data) >= 4:
             ns = int.from_bytes(data[:4], "little")
             if ns >= ng and ns % ng == 0 and ns // ng <= max(1, self.MAX_STREAMS // ng):
@@ -352,7 +357,8 @@ class StreamsJob:
         self.guest2 = int(host[16:20].view(np.int32)[0])
         if nbytes > take - H:                                   # the estimate fell short: fetch the rest
             host = self.blob[:H + nbytes].cpu().numpy()
-        return host[H:H + nbytes].tobytes()
+        from ...container import StreamBytes
+        return StreamBytes(host[H:H + nbytes].tobytes(), self.ng)
 
 
 class EntropyBottleneck(EntropyModel):
@@ -577,6 +583,7 @@ class GaussianConditional(EntropyModel):
         """Differentiable Gaussian likelihood of [N,C] rows (training path): one HIP kernel per direction on the GPU
         (`pcc_gauss_lik_fwd/bwd`, bounds 0.11 / 1e-9 as constructed by the reference); torch ops otherwise."""
         if (values.is_cuda and self.use_likelihood_bound and values.dtype == torch.float32
+                and abs(self._likelihood_bound_value - 1e-9) < 1e-15                         # (the kernels hard-code both bounds: 0.11 / 1e-9)
                 and self._scale_bound_value is not None and abs(self._scale_bound_value - 0.11) < 1e-7 and values.shape == scales.shape == means.shape):
             from ...autograd import GaussLikFn
             return GaussLikFn.apply(values, scales, means)

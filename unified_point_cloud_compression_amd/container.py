@@ -1,9 +1,15 @@
 """Bitstream container + lossless latent-coordinate coding.
 
 Field order follows the reference's `UnifiedModel.save_bitstream / load_bitstream` (`model/model.py:253-385`):
+    "PCCB" | uint16 version (2) | uint16 flags (0)                                   -- format word (round 3)
     int32 num_blocks
     per block:  int32 Nz | int32 len(points stream) | float64 q_g | float64 q_a | int32 len(y string) |
-                int32 len(z string) | int32 k1 | int32 k2 | int32 k3 | points stream | y string | z string
+                int32 len(z string) | int32 k1 | int32 k2 | int32 k3 |
+                uint32 stream geometry = channel groups of the y string << 16 | of the z string (0: not recorded) |
+                points stream | y string | z string
+The stream geometry makes a file independent of the coder's tuning constants (`EntropyModel.STREAM_SYMBOLS` decides how many
+channels share a GPU stream; a decoder built with another value would otherwise cut the container differently): the strings
+come back as `StreamBytes` carrying it.  Version-1 files (no format word, no geometry) are still read.
 Integers / floats are little-endian here (the reference writes them through the `bitstream` package, which is not
 available to check its byte order).  The points stream is the octree coder of libpcc_hip (`pcc_octree_*_host`) instead
 of an ASCII-PLY round trip through the external G-PCC `tmc3` binary (`model/model.py:388-486`); a second header
@@ -16,6 +22,20 @@ import numpy as np
 import torch
 
 from . import lib as L
+
+
+MAGIC, VERSION = b"PCCB", 2
+
+
+class StreamBytes(bytes):
+    """A coded string that remembers its stream geometry (channel groups of the `pcc_streams` container); otherwise bytes."""
+
+    groups = 0
+
+    def __new__(cls, data, groups=0):
+        b = super().__new__(cls, data)
+        b.groups = int(groups)
+        return b
 
 
 def _np_ptr(a):
@@ -54,10 +74,11 @@ def decode_points(data):
     lib = L.load()
     n, depth = C.c_int64(0), C.c_int32(0)
     L.check(lib.pcc_octree_decode_host(_np_ptr(body), len(body), None, 0, C.byref(n), C.byref(depth)), "pcc_octree_decode_host")
-    # the point count comes from the stream header: bound it by what the payload could possibly code (a leaf costs at
-    # least a fraction of a bit; 64 points per payload byte is far beyond any real stream) before allocating for it
-    if n.value < 0 or n.value > 64 * max(len(body), 1) + 64:
-        raise L.PccError(f"latent-coordinate stream: header claims {n.value} points for {len(body)} payload bytes")
+    # the point count comes from the stream header: bound it before allocating for it.  The adaptive range coder's cost per
+    # occupancy decision saturates near 0.02 bit, so a fully dense block codes at well over 100 points per payload byte: the
+    # bound is what the lattice can hold (8^depth cells) and a loose 4096 points per byte, not a rate assumption
+    if n.value < 0 or n.value > min(8 ** min(int(depth.value), 20), 4096 * max(len(body), 1) + 4096):
+        raise L.PccError(f"latent-coordinate stream: header claims {n.value} points for {len(body)} payload bytes at depth {depth.value}")
     cells = np.zeros((max(n.value, 1), 3), np.int32)
     L.check(lib.pcc_octree_decode_host(_np_ptr(body), len(body), _np_ptr(cells), n.value, C.byref(n), C.byref(depth)),
             "pcc_octree_decode_host")
@@ -68,7 +89,7 @@ def decode_points(data):
 
 def save_bitstream(path, blocks_coordinates, blocks_strings, blocks_shapes, blocks_k, blocks_q):
     """`UnifiedModel.save_bitstream` (`model/model.py:253-311`)."""
-    out = bytearray(struct.pack("<i", len(blocks_coordinates)))
+    out = bytearray(MAGIC + struct.pack("<HHi", VERSION, 0, len(blocks_coordinates)))
     for coords, strings, shape, k, q in zip(blocks_coordinates, blocks_strings, blocks_shapes, blocks_k, blocks_q):
         pts = encode_points(coords)
         qv = q.detach().cpu().double().reshape(-1)
@@ -77,6 +98,8 @@ def save_bitstream(path, blocks_coordinates, blocks_strings, blocks_shapes, bloc
             out += struct.pack("<i", len(s[0]))
         for ks in k:
             out += struct.pack("<i", int(ks[0]))
+        gy, gz = (min(int(getattr(s[0], "groups", 0)), 0xFFFF) for s in strings)
+        out += struct.pack("<I", (gy << 16) | gz)
         out += pts
         for s in strings:
             out += s[0]
@@ -90,20 +113,31 @@ def load_bitstream(path):
     data = open(path, "rb").read()
     if len(data) < 4:
         raise L.PccError("bitstream file truncated")
-    (nblocks,), off = struct.unpack_from("<i", data, 0), 4
+    version, off = 1, 0
+    if data[:4] == MAGIC:
+        if len(data) < 12:
+            raise L.PccError("bitstream file truncated")
+        version, _flags = struct.unpack_from("<HH", data, 4)
+        if version != VERSION:
+            raise L.PccError(f"bitstream file: format version {version}, this build reads {VERSION} (and headerless version-1 files)")
+        off = 8
+    (nblocks,), off = struct.unpack_from("<i", data, off), off + 4
     if nblocks < 0 or nblocks * 44 > len(data):
         raise L.PccError(f"bitstream file: implausible block count {nblocks}")
     coords, strings, shapes, ks, qs = [], [], [], [], []
     for _ in range(nblocks):
-        if off + struct.calcsize("<iiddiiiii") > len(data):
+        if off + struct.calcsize("<iiddiiiii") + (4 if version >= 2 else 0) > len(data):
             raise L.PccError("bitstream file truncated inside a block header")
         nz, lp, qg, qa, ly, lz, k1, k2, k3 = struct.unpack_from("<iiddiiiii", data, off)
         off += struct.calcsize("<iiddiiiii")
+        geom = 0
+        if version >= 2:
+            (geom,), off = struct.unpack_from("<I", data, off), off + 4
         if min(nz, lp, ly, lz, k1, k2, k3) < 0 or off + lp + ly + lz > len(data):
             raise L.PccError("bitstream file: block header with negative or oversized lengths")
         pts = data[off:off + lp]; off += lp
-        ys = data[off:off + ly]; off += ly
-        zs = data[off:off + lz]; off += lz
+        ys = StreamBytes(data[off:off + ly], geom >> 16); off += ly
+        zs = StreamBytes(data[off:off + lz], geom & 0xFFFF); off += lz
         coords.append(torch.from_numpy(decode_points(pts)))
         strings.append([[ys], [zs]])
         shapes.append([nz])

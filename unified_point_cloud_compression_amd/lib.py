@@ -195,7 +195,7 @@ def workspace(nbytes, device):
 # by the kernels straight into pinned host memory (device-visible at the same address under HIP's unified addressing):
 # the host zeroes the slot, launches, synchronises the stream and reads -- no device allocation, no fill kernel and no
 # device->host copy launch per read (round 1: ~40 `.item()` reads per step, 25-50 us of idle GPU each).
-_pin = {"buf": None, "next": 0, "dev": None, "dev_next": 0}
+_pin = {"buf": None, "next": 0, "dev_blocks": {}}
 _PIN_SLOTS, _PIN_WORDS = 1024, 4
 PINNED_COUNTERS = os.environ.get("PCC_PINNED_COUNTERS", "0") != "0"   # measured 0.3 ms/step slower than `.item()` reads (round 2): off
 
@@ -203,12 +203,14 @@ PINNED_COUNTERS = os.environ.get("PCC_PINNED_COUNTERS", "0") != "0"   # measured
 def counter(n=1, dtype=torch.int64):
     """Zeroed pinned host tensor of `n` (<= 4) int64 (or 2n int32) words for a kernel to write into."""
     if not PINNED_COUNTERS:           # default: device counters cut from a zeroed block (one fill per 1024 counters instead of
-        blk = _pin.get("dev")         # one per counter), read back with a copy
-        if blk is None or _pin["dev_next"] + _PIN_WORDS > blk.numel():
-            blk = _pin["dev"] = torch.zeros(1024 * _PIN_WORDS, dtype=torch.int64, device="cuda")
-            _pin["dev_next"] = 0
-        t = blk[_pin["dev_next"]:_pin["dev_next"] + _PIN_WORDS]
-        _pin["dev_next"] += _PIN_WORDS
+        d = torch.cuda.current_device()          # one per counter), read back with a copy; one block per device
+        st = _pin["dev_blocks"].setdefault(d, {"blk": None, "next": 0})
+        blk = st["blk"]
+        if blk is None or st["next"] + _PIN_WORDS > blk.numel():
+            blk = st["blk"] = torch.zeros(1024 * _PIN_WORDS, dtype=torch.int64, device=torch.device("cuda", d))
+            st["next"] = 0
+        t = blk[st["next"]:st["next"] + _PIN_WORDS]
+        st["next"] += _PIN_WORDS
         return (t if dtype == torch.int64 else t.view(dtype))[:n]
     if _pin["buf"] is None:
         _pin["buf"] = torch.zeros((_PIN_SLOTS, _PIN_WORDS), dtype=torch.int64).pin_memory()

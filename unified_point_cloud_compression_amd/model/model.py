@@ -77,6 +77,28 @@ class UnifiedModel(CompressionModel):
                            x_block[:, 3:6].to(torch.float32)], dim=1)
         return SparseTensor(coordinates=coords, features=feats, device=x_block.device)
 
+    # ---- blocks as independent work items (the shard unit across GPUs) ------------------------------------------
+    def blocks_of(self, pointcloud, block_size=1024):
+        """The frame's blocks in the order `compress` codes them (`partition`): a list of [n_i, 6] tensors.  Blocks carry no
+        halo, so any subset may be coded on another rank (`frames.run_sharded_blocks`) and decoded there: `decompress` takes
+        per-block lists of any length."""
+        order, counts = self.partition(pointcloud, block_size)
+        xs = pointcloud if order is None else pointcloud[order]
+        out, start = [], 0
+        for c in counts:
+            out.append(xs[start:start + c])
+            start += c
+        return out
+
+    @torch.no_grad()
+    def compress_block(self, x_block, q, coords=None):
+        """One block through g_a and the entropy model: (strings, shape, k, latent coordinates) -- the body of the block loop
+        of `compress` (`model/model.py:137-176`)."""
+        x = self.block_input(x_block, coords=coords)
+        y, k = self.g_a(x)
+        _, symbols, shape = self.entropy_model.compress(y, q)
+        return symbols, shape, k, y.C
+
     # ---- file container (`model/model.py:253-486`) ---------------------------------------------------------
     def save_bitstream(self, path, blocks_coordinates, blocks_strings, blocks_shapes, blocks_k, blocks_q):
         return container.save_bitstream(path, blocks_coordinates, blocks_strings, blocks_shapes, blocks_k, blocks_q)
@@ -131,11 +153,9 @@ class UnifiedModel(CompressionModel):
         bitstreams, block_shapes, block_coordinates, block_q_vals, block_k = [], [], [], [], []
         start = 0
         for count in counts:
-            x = self.block_input(xs[start:start + count], coords=single)
-            y, k = self.g_a(x)
-            _, symbols, shape = self.entropy_model.compress(y, q)
+            symbols, shape, k, yc = self.compress_block(xs[start:start + count], q, coords=single)
             block_q_vals.append(q)
-            block_coordinates.append(y.C)
+            block_coordinates.append(yc)
             block_shapes.append(shape)
             block_k.append(k)
             bitstreams.append(symbols)

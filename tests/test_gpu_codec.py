@@ -354,7 +354,8 @@ def test_file_bitstream_roundtrip_and_rd_figures(tmp_path):
     bpp_strings = metrics.count_bits(mem[0]) / n_pts
     assert bpp_file > bpp_strings                                   # + coordinates + 44-byte block headers
     coord_bits = sum(len(model.gpcc_encode(c)) for c in mem[3]) * 8
-    assert abs(os.path.getsize(path) * 8 - (metrics.count_bits(mem[0]) + coord_bits + 8 * (4 + 44 * len(mem[0])))) == 0
+    # format word (8 bytes) + block count (4) + per block: the reference's 44-byte header + the 4-byte stream-geometry word
+    assert abs(os.path.getsize(path) * 8 - (metrics.count_bits(mem[0]) + coord_bits + 8 * (8 + 4 + 48 * len(mem[0])))) == 0
     # D1 parity with the oracle: decode the same symbols with the oracle and compare the PSNR figure
     sym_model = _model(cfg, P, "symbols")
     a = sym_model.compress(pc, q, block_size=32)

@@ -296,7 +296,7 @@ def true_geometry_ms(model, pc, q, steps=5, warmup=2):
     return {"ms_per_step_true_geometry": ms, "candidate_rows": [sizes.get(i) for i in range(3)], "lossless_geometry": bool(exact)}
 
 
-def train_step_ms(device, steps=5, warmup=2):
+def train_step_ms(device, steps=5, warmup=6):
     """Auxiliary (BASELINE configs[3], never `value`): one training step -- forward, losses, backward, gradient clipping,
     Adam -- on 4 cubes of 128^3 cut from the benchmark frame, `configs/CVPR_inverse_scaling.yaml` (adaptive bottleneck,
     quantisation offsets, inverse rescaling, STE), as `train.py:178-240` runs it."""

@@ -53,4 +53,6 @@ def assert_close(got, want, atol=ATOL, rtol=RTOL, what=""):
     err = np.abs(got - want)
     tol = atol + rtol * np.abs(want)
     bad = err > tol
-    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} out of tolerance, max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    rows = np.unique(np.nonzero(bad)[0])[:16].tolist() if bad.ndim >= 1 and bad.any() else []
+    assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} out of tolerance, max err {err.max():.3e} at "
+                           f"{np.unravel_index(err.argmax(), err.shape)}; first rows with bad entries {rows}")

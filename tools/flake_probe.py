@@ -22,6 +22,19 @@ f = rng.standard_normal((len(keys), cin)).astype(np.float32)
 torch.manual_seed(0)
 mod = ME.MinkowskiConvolution(cin, cout, kernel_size=ks, stride=stride, bias=True, dimension=3).to(dev())
 go = t(np.random.default_rng(7).standard_normal((len(co.stride_keys(keys, stride)), cout)).astype(np.float32))
+# CPU reference of the data gradient (the test's own: gather + matmul + index_add under torch autograd)
+from oracle import codec
+out_keys = co.stride_keys(keys, stride)
+pairs = codec.kernel_map_pairs(keys, out_keys, ks, 1)
+fr = torch.from_numpy(f).requires_grad_(True)
+Wr = mod.kernel.detach().cpu().reshape(ks ** 3, cin, cout)
+ref = torch.zeros((len(out_keys), cout)) + mod.bias.detach().cpu()
+for k, (i, o) in enumerate(pairs):
+    if len(i):
+        ref = ref.index_add(0, torch.from_numpy(o.astype(np.int64)), fr[torch.from_numpy(i.astype(np.int64))] @ Wr[k])
+ref = torch.nn.functional.leaky_relu(ref, 0.01)
+ref.backward(go.cpu())
+ref_grad = fr.grad.numpy()
 first = None
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
@@ -34,6 +47,12 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     out.backward(go)
     res = (out.detach().clone(), x._F.grad.clone(), mod.kernel.grad.clone())
     torch.cuda.synchronize()
+    err = np.abs(n(res[1]) - ref_grad)
+    nbad = int((err > 1e-4 + 1e-4 * np.abs(ref_grad)).sum())
+    if nbad:
+        rows = np.unique(np.nonzero(err > 1e-3)[0])
+        print(f"iteration {it}: data gradient differs from the CPU reference in {nbad} elements, max {err.max():.3e}, rows {rows[:12].tolist()}", flush=True)
+        bad += 1
     if first is None:
         first = res
     else:

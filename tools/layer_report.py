@@ -55,10 +55,10 @@ def spy_c(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01, **
 orig_r = S.convt_forward_rows
 
 
-def spy_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01):
+def spy_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act=0, slope=0.01, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    out = orig_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope)
+    out = orig_r(feats, packed_w, bias, K, cin, cout, csr, n_out, act, slope, **kw)
     e1.record()
     calls.append((int(csr[0][n_out].item()), -K, cin, cout, feats.shape[0], n_out, e0, e1))
     return out

@@ -11,7 +11,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr int WG_PAIRS = 32;         // pairs staged per step
-static constexpr int WG_LD = 128 + 4;       // floats per staged row (128 channels + pad)
 static constexpr int WG_SLICE = 4096;       // positions per workgroup slice
 
 // 4 consecutive channels [col, col+4) of a row of `width` floats; 16-byte load when the row pitch allows it,
@@ -39,10 +38,28 @@ struct WgradArgs {
 
 // total (segment, slot) work items are enumerated on the host side as K slots of kernel offsets: slot kid in [0,K).
 // For transposed / class maps a kernel offset appears in exactly one segment; the kernel finds it in the header.
+//
+// Round 3 (the training step of BASELINE configs[3] spent 27 of its 43 ms of kernel time here, profiles/r03_train_step_*):
+//   * a slice's positions are COMPACTED before they are multiplied: 1024 positions at a time, the present pairs (input row,
+//     output row) are gathered into an LDS list in position order and consumed 32 at a time.  A 5x5x5 map on a surface fills
+//     30 % of its (offset, position) slots and a 3x3x3 one about half; the first version staged and multiplied the empty
+//     ones too.  Skipped terms are exact zeros, so the sums are unchanged bit for bit;
+//   * NARROW (cin, cout <= 32: the occupancy heads' 32 -> 16 and 16 -> 1 convolutions over the largest sets, the colour head):
+//     the 128 x 128 tile had one 32 x 32 MFMA block of real work in sixteen and three idle waves in four.  Here the four
+//     waves split the 32 staged pairs between them, each with one accumulator block, and their blocks are summed in wave
+//     order at the end (8.7 ms -> ~1 ms for the two largest launches of the step);
+//   * sub-blocks of the 128 x 128 tile that lie outside cin x cout are skipped (wave-uniform).
+static constexpr int WG_SUB = 1024;         // positions compacted at a time
+
+template <bool NARROW>
 __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float Xs[WG_PAIRS * WG_LD];
-  __shared__ __attribute__((aligned(16))) float Gs[WG_PAIRS * WG_LD];
-  __shared__ int s_in[WG_PAIRS], s_out[WG_PAIRS];
+  constexpr int CH = NARROW ? 32 : 128;       // channels staged per operand
+  constexpr int LD = CH + 4;
+  __shared__ __attribute__((aligned(16))) float Xs[WG_PAIRS * LD];
+  __shared__ __attribute__((aligned(16))) float Gs[WG_PAIRS * LD];
+  __shared__ int c_in[WG_SUB + WG_PAIRS], c_out[WG_SUB + WG_PAIRS];
+  __shared__ int s_wtot[4];
+  __shared__ __attribute__((aligned(16))) float red[NARROW ? 4 * 1024 : 4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kid = blockIdx.y;                       // kernel offset id
   const int slice = blockIdx.x;
@@ -72,7 +89,7 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
   const long long p_lo = (long long)slice * per;
   const long long p_hi = min(pos_count, p_lo + per);
 
-  const int wm = w >> 1, wn = w & 1;                // 2x2 waves, each 64x64 of the 128x128 tile
+  const int wm = w >> 1, wn = w & 1;                // full tile: 2x2 waves, each 64x64 of the 128x128 tile
   const int half = lane >> 5, r31 = lane & 31;
   f32x16 acc[2][2];
 #pragma unroll
@@ -81,52 +98,120 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  bool sub_on[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sub_on[i][j] = m0 + (wm * 2 + i) * 32 < a.cin && n0 + (wn * 2 + j) * 32 < a.cout;
 
-  for (long long p0 = p_lo; p0 < p_hi; p0 += WG_PAIRS) {
-    __syncthreads();                                 // previous step's fragment reads are done
-    if (tid < WG_PAIRS) {
-      const long long p = p0 + tid;
-      int ir = -1, orow = -1;
-      if (p < p_hi) {
-        ir = identity ? (int)p : seg_nbr[p];
-        orow = a.rows ? a.rows[pos_begin + p] : (int)(pos_begin + p);
-      }
-      s_in[tid] = ir; s_out[tid] = (ir >= 0) ? orow : -1;
-    }
-    __syncthreads();
-    // stage: 32 pairs x 128 channels of X (columns m0..) and of G (columns n0..); 8 threads per row, 4 float4 each
+  // one step: the pairs list[0 .. cnt) (cnt <= 32) staged and multiplied
+  auto step = [&](const int* l_in, const int* l_out, int cnt) {
+    __syncthreads();                                 // previous step's fragment reads are done; the list is complete
     {
       const int r = tid >> 3, part = tid & 7;
-      const int ir = s_in[r], orow = s_out[r];
+      const int ir = r < cnt ? l_in[r] : -1, orow = r < cnt ? l_out[r] : -1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < (NARROW ? 1 : 4); ++q) {
         const int c = (part + 8 * q) * 4;
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), gv = xv;
         if (ir >= 0) {
           xv = load4(a.x + (long long)ir * a.cin, a.cin, m0 + c);
           gv = load4(a.g + (long long)orow * a.cout, a.cout, n0 + c);
         }
-        *reinterpret_cast<float4*>(&Xs[r * WG_LD + c]) = xv;
-        *reinterpret_cast<float4*>(&Gs[r * WG_LD + c]) = gv;
+        *reinterpret_cast<float4*>(&Xs[r * LD + c]) = xv;
+        *reinterpret_cast<float4*>(&Gs[r * LD + c]) = gv;
       }
     }
     __syncthreads();
     // D[ci][co] += sum_pairs X[pair][ci] * G[pair][co]:  A[i=ci][k=pair], B[k=pair][j=co]
+    if (NARROW) {
+#pragma unroll
+      for (int kk = 0; kk < 8; kk += 2) {            // this wave's quarter of the staged pairs
+        const int k0 = w * 8 + kk + half;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[k0 * LD + r31], Gs[k0 * LD + r31], acc[0][0], 0, 0, 0);
+      }
+    } else {
 #pragma unroll 4
-    for (int kk = 0; kk < WG_PAIRS; kk += 2) {
-      float af[2], bf[2];
+      for (int kk = 0; kk < WG_PAIRS; kk += 2) {
+        float af[2], bf[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = Xs[(kk + half) * WG_LD + (wm * 2 + i) * 32 + r31];
+        for (int i = 0; i < 2; ++i) af[i] = Xs[(kk + half) * LD + (wm * 2 + i) * 32 + r31];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = Gs[(kk + half) * WG_LD + (wn * 2 + j) * 32 + r31];
+        for (int j = 0; j < 2; ++j) bf[j] = Gs[(kk + half) * LD + (wn * 2 + j) * 32 + r31];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j)
+            if (sub_on[i][j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
     }
+  };
+
+  int pending = 0;                                   // compacted pairs waiting in c_in / c_out [0, pending)
+  for (long long pb = p_lo; pb < p_hi; pb += WG_SUB) {
+    // ---- compact the present pairs of positions [pb, pb + 1024): thread t owns positions pb + 4t .. 4t+3 (position order) ----
+    int ir[4], cnt = 0;
+    const long long q0 = pb + 4 * tid;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long p = q0 + j;
+      ir[j] = -1;
+      if (p < p_hi) ir[j] = identity ? (int)p : seg_nbr[p];
+      cnt += ir[j] >= 0;
+    }
+    int inc = cnt;                                   // inclusive scan over the wave, then over the four waves
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    __syncthreads();                                 // (the previous sub-block's steps are done with the list)
+    if (lane == 63) s_wtot[w] = inc;
+    __syncthreads();
+    int off = pending + inc - cnt;
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (i < w) off += s_wtot[i]; total += s_wtot[i]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ir[j] >= 0) {
+        const long long p = q0 + j;
+        c_in[off] = ir[j];
+        c_out[off] = a.rows ? a.rows[pos_begin + p] : (int)(pos_begin + p);
+        ++off;
+      }
+    pending += total;
+    int g = 0;
+    for (; pending - g >= WG_PAIRS; g += WG_PAIRS) step(c_in + g, c_out + g, WG_PAIRS);
+    // the remainder (< 32 pairs) moves to the front of the list
+    const int rem = pending - g;
+    __syncthreads();
+    int ti = 0, to = 0;
+    if (tid < rem) { ti = c_in[g + tid]; to = c_out[g + tid]; }
+    __syncthreads();
+    if (tid < rem) { c_in[tid] = ti; c_out[tid] = to; }
+    pending = rem;
   }
+  if (pending > 0) step(c_in, c_out, pending);
+
   // partial tile -> [slice][kid][cin][cout]
   float* dst = a.partial + ((long long)slice * a.K + kid) * a.cin * a.cout;
+  if (NARROW) {
+    // the four waves' blocks, summed in wave order: red[w][e][lane]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(w * 16 + e) * 64 + lane] = acc[0][0][e];
+    __syncthreads();
+    if (w == 0) {
+      const int co = n0 + r31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = ((red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane]) + red[(2 * 16 + e) * 64 + lane]) + red[(3 * 16 + e) * 64 + lane];
+        const int ci = m0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (ci < a.cin && co < a.cout) dst[(long long)ci * a.cout + co] = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -180,7 +265,8 @@ extern "C" int pcc_conv_wgrad(const float* feat_in, int64_t n_in, int32_t cin, c
   a.x = feat_in; a.g = grad_out; a.hdr = hdr; a.nbr = nbr; a.rows = rows; a.partial = (float*)ws; a.n_out = n_out;
   a.cin = cin; a.cout = cout; a.K = K; a.nslices = wgrad_slices(n_out);
   const unsigned tiles = (unsigned)(((cin + 127) / 128) * ((cout + 127) / 128));
-  k_wgrad<<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
+  if (cin <= 32 && cout <= 32) k_wgrad<true><<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
+  else k_wgrad<false><<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
   PCC_LAUNCH_CHECK();
   k_wgrad_reduce<<<(unsigned)pcc_cdiv(elems, 256), 256, 0, s>>>(a.partial, elems, a.nslices, dW);
   PCC_LAUNCH_CHECK();

@@ -4,13 +4,17 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/meas; mkdir -p $O
 echo "kernel stats" > $O/progress.txt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-aux > $O/ks_bench.json 2> $O/ks.err && python profiles/summarize.py $O/ks 13 > $O/kernel_stats.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-aux > $O/ks_bench.json 2> $O/ks.err && python profiles/summarize.py $O/ks 18 > $O/kernel_stats.txt 2>&1 && python tools/gpu_idle.py $O/ks k_eb_encode 4 3 > $O/gpu_idle.txt 2>&1
 echo "attribution" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/attr -- python3 tools/layer_report.py 10 $O/attr_calls.json > $O/layer_report_profiled.txt 2>&1 && python tools/kernel_attribution.py $O/attr $O/attr_calls.json > $O/kernel_attribution.txt 2>&1
 echo "layer report" >> $O/progress.txt
 timeout -k 10 200 python tools/layer_report.py 10 > $O/layer_report.txt 2>&1
 echo "pmc" >> $O/progress.txt
 timeout -k 10 400 python tools/pmc_traffic.py collect $O/pmc > $O/pmc.log 2>&1 && python tools/pmc_traffic.py parse $O/pmc $O/pmc_traffic.json >> $O/pmc.log 2>&1 && python tools/pmc_by_kernel.py $O/pmc > $O/pmc_by_kernel.txt 2>&1
+echo "train step" >> $O/progress.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 tools/train_profile.py 10 > $O/train_profile.txt 2>&1 && python profiles/summarize.py $O/train 16 > $O/train_kernel_stats.txt 2>&1
+echo "eval frames" >> $O/progress.txt
+timeout -k 10 300 python tools/eval_frames.py --bits 9 10 11 9 > $O/eval_frames.txt 2>&1
 echo "bench" >> $O/progress.txt
 timeout -k 10 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 echo "done" >> $O/progress.txt

@@ -10,5 +10,5 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-r = bench.train_step_ms(torch.device("cuda:0"), steps=steps, warmup=3)
+r = bench.train_step_ms(torch.device("cuda:0"), steps=steps, warmup=6)
 print(r)

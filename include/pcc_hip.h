@@ -383,6 +383,15 @@ int pcc_gauss_lik_bwd(const float* v, const float* scale, const float* mean, con
 int pcc_eb_encode(const float* z, int64_t n, int32_t c, const float* eb_packed, const float* medians,
                   int32_t* sym, float* z_hat, float* lik, void* stream);
 
+/* Differentiable factorised-prior likelihood of the TRAINING forward (EntropyBottleneck._likelihood + lower bound 1e-9;
+ * model/entropy_models.py:272,282-285; rate term loss.py:77-79), [n, c] rows, filters (3,3,3,3):
+ *   lik = max(|sigmoid(sg up) - sigmoid(sg lo)|, 1e-9),  lo / up = logits(v -+ .5),  sg = -sign(lo + up) (no gradient)
+ * backward: dv [n, c] (nullable) and d_packed [c, 58], the gradient of the packed parameters (eb_packed layout: softplus /
+ * tanh already applied -- the caller differentiates those reparametrisations), rows summed in a fixed order. */
+int pcc_eb_lik_fwd(const float* v, int64_t n, int32_t c, const float* eb_packed, float* lik, void* stream);
+int pcc_eb_lik_bwd(const float* v, const float* grad_lik, int64_t n, int32_t c, const float* eb_packed, float* dv,
+                   float* d_packed, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * training (BASELINE config 4; reference train.py:221-227 back-propagates through every ME convolution)
  *   data gradient  : the forward entry points on the inverse map with transposed weights (no extra kernel)

@@ -175,3 +175,25 @@ class GaussLikFn(torch.autograd.Function):
         L.call("pcc_gauss_lik_bwd", L.ptr(v), L.ptr(scale), L.ptr(mean), L.ptr(g), v.numel(), L.ptr(dv), L.ptr(ds), L.ptr(dm),
                L.stream())
         return dv, ds, dm
+
+
+class EbLikFn(torch.autograd.Function):
+    """Factorised-prior likelihood of the training forward as one kernel per direction (`pcc_eb_lik_fwd/bwd`): values [N, C],
+    packed parameters [C, 58] (softplus(matrices) | biases | tanh(factors), built under autograd by the caller)."""
+
+    @staticmethod
+    def forward(ctx, v, packed):
+        v, packed = v.contiguous(), packed.contiguous()
+        lik = torch.empty_like(v)
+        L.call("pcc_eb_lik_fwd", L.ptr(v), v.shape[0], v.shape[1], L.ptr(packed), L.ptr(lik), L.stream())
+        ctx.save_for_backward(v, packed)
+        return lik
+
+    @staticmethod
+    def backward(ctx, g):
+        v, packed = ctx.saved_tensors
+        g = g.contiguous()
+        dv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        dp = torch.empty_like(packed)
+        L.call("pcc_eb_lik_bwd", L.ptr(v), L.ptr(g), v.shape[0], v.shape[1], L.ptr(packed), L.ptr(dv), L.ptr(dp), L.stream())
+        return dv, (dp if ctx.needs_input_grad[1] else None)

@@ -458,8 +458,22 @@ class EntropyBottleneck(EntropyModel):
         self._tables_gen += 1
         return True
 
+    def _packed_with_grad(self):
+        """`packed()` under autograd: [C, 58] = softplus(matrices) | biases | tanh(factors) (14 small ops; their derivatives
+        are torch's, the likelihood's own gradient comes from `pcc_eb_lik_bwd`)."""
+        parts = [torch.nn.functional.softplus(getattr(self, f"_matrix{i}")).reshape(self.channels, -1) for i in range(5)]
+        parts += [getattr(self, f"_bias{i}").reshape(self.channels, -1) for i in range(5)]
+        parts += [torch.tanh(getattr(self, f"_factor{i}")).reshape(self.channels, -1) for i in range(4)]
+        return torch.cat(parts, dim=1).to(torch.float32)
+
     def likelihood_rows(self, v):
-        """Differentiable likelihood of [N,C] rows (training path; torch ops): |sigmoid(s*u) - sigmoid(s*l)| >= 1e-9."""
+        """Differentiable likelihood of [N,C] rows (training path): |sigmoid(s*u) - sigmoid(s*l)| >= 1e-9 -- one HIP kernel per
+        direction on the GPU (`pcc_eb_lik_fwd/bwd`; filters (3,3,3,3), bound 1e-9 as the reference constructs it), the torch
+        chain otherwise."""
+        if (v.is_cuda and v.dtype == torch.float32 and self.filters == (3, 3, 3, 3) and self.use_likelihood_bound
+                and abs(self._likelihood_bound_value - 1e-9) < 1e-15 and v.dim() == 2 and v.shape[1] == self.channels):
+            from ...autograd import EbLikFn
+            return EbLikFn.apply(v, self._packed_with_grad())
         x = v.t().unsqueeze(1)
         lo, up = self._logits_cumulative(x - 0.5), self._logits_cumulative(x + 0.5)
         sg = -torch.sign(lo + up).detach()

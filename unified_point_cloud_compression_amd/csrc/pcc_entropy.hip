@@ -142,6 +142,142 @@ extern "C" int pcc_eb_encode(const float* z, int64_t n, int32_t c, const float* 
 }
 
 // ------------------------------------------------------------------------------------------
+// Differentiable likelihood of the factorised prior (training forward: `EntropyBottleneck._likelihood` + lower bound 1e-9;
+// reference `model/entropy_models.py:272,282-285`, rate term `loss.py:77-79`).  The torch chain is ~35 element-wise / batched
+// matmul launches per direction and per evaluation point (lower, upper); here one kernel per direction.
+//   lik = max(|sigmoid(sg up) - sigmoid(sg lo)|, 1e-9),  lo / up = logits(v -+ 0.5),  sg = -sign(lo + up) (no gradient)
+// backward: d v per element, and the gradient of the 58 PACKED parameters of every channel (softplus(matrices) | biases |
+// tanh(factors): the reparametrisations are differentiated by torch on the [C, 58] tensor), summed over the rows by a
+// workgroup per channel in a fixed order (deterministic).  LowerBound rule of CompressAI on the bound.
+// ------------------------------------------------------------------------------------------
+struct EbTape { float a[4][3]; float h[5][3]; };       // pre-activations of the four gated layers, inputs of the five linear maps
+
+__device__ inline float eb_logits_tape(const float* __restrict__ p, float x, EbTape& t) {
+  const float* m0 = p;        const float* Ms = p + 3;  const float* m4 = p + 30;   const float* b = p + 33;  const float* f = p + 46;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { t.a[0][i] = m0[i] * x + b[i]; t.h[1][i] = t.a[0][i] + f[i] * tanhf(t.a[0][i]); }
+#pragma unroll
+  for (int l = 1; l < 4; ++l) {
+    const float* M = Ms + 9 * (l - 1);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = M[o * 3 + 0] * t.h[l][0];
+      v += M[o * 3 + 1] * t.h[l][1];
+      v += M[o * 3 + 2] * t.h[l][2];
+      v += b[3 * l + o];
+      t.a[l][o] = v;
+      t.h[l + 1][o] = v + f[3 * l + o] * tanhf(v);
+    }
+  }
+  float v = m4[0] * t.h[4][0];
+  v += m4[1] * t.h[4][1];
+  v += m4[2] * t.h[4][2];
+  return v + b[12];
+}
+
+// reverse pass of eb_logits for the upstream gradient gout: dp[58] += d out / d packed * gout; returns d out / d x * gout
+__device__ inline float eb_logits_bwd(const float* __restrict__ p, float x, const EbTape& t, float gout, float* __restrict__ dp) {
+  const float* m0 = p;        const float* Ms = p + 3;  const float* m4 = p + 30;   const float* f = p + 46;
+  float dh[3];
+  dp[33 + 12] += gout;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { dp[30 + j] += gout * t.h[4][j]; dh[j] = gout * m4[j]; }
+#pragma unroll
+  for (int l = 3; l >= 1; --l) {
+    const float* M = Ms + 9 * (l - 1);
+    float da[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const float th = tanhf(t.a[l][o]);
+      dp[46 + 3 * l + o] += dh[o] * th;
+      da[o] = dh[o] * (1.f + f[3 * l + o] * (1.f - th * th));
+      dp[33 + 3 * l + o] += da[o];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) dp[3 + 9 * (l - 1) + o * 3 + j] += da[o] * t.h[l][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dh[j] = da[0] * M[0 * 3 + j] + da[1] * M[1 * 3 + j] + da[2] * M[2 * 3 + j];
+  }
+  float dx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float th = tanhf(t.a[0][i]);
+    dp[46 + i] += dh[i] * th;
+    const float da = dh[i] * (1.f + f[i] * (1.f - th * th));
+    dp[33 + i] += da;
+    dp[i] += da * x;
+    dx += da * m0[i];
+  }
+  return dx;
+}
+
+__global__ void __launch_bounds__(256) k_eb_lik_fwd(const float* __restrict__ v, long long n, int c, const float* __restrict__ packed,
+                                                    float* __restrict__ lik) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * c) return;
+  const float* p = packed + (long long)(t % c) * 58;
+  const float lo = eb_logits(p, v[t] - 0.5f), up = eb_logits(p, v[t] + 0.5f);
+  const float sum = lo + up;
+  const float sg = (sum > 0.f) ? -1.f : ((sum < 0.f) ? 1.f : 0.f);
+  lik[t] = fmaxf(fabsf(sigmoidf_(sg * up) - sigmoidf_(sg * lo)), LIK_BOUND);
+}
+
+// one workgroup per channel: rows strided over the threads, 58 partial sums per thread, fixed-order reduction
+__global__ void __launch_bounds__(256) k_eb_lik_bwd(const float* __restrict__ v, const float* __restrict__ g, long long n, int c,
+                                                    const float* __restrict__ packed, float* __restrict__ dv,
+                                                    float* __restrict__ dpacked) {
+  __shared__ float red[4][58];
+  const int ch = blockIdx.x;
+  const float* p = packed + (long long)ch * 58;
+  float dp[58];
+#pragma unroll
+  for (int i = 0; i < 58; ++i) dp[i] = 0.f;
+  for (long long r = threadIdx.x; r < n; r += 256) {
+    const long long t = r * c + ch;
+    const float x = v[t];
+    EbTape tl, tu;
+    const float lo = eb_logits_tape(p, x - 0.5f, tl), up = eb_logits_tape(p, x + 0.5f, tu);
+    const float sum = lo + up;
+    const float sg = (sum > 0.f) ? -1.f : ((sum < 0.f) ? 1.f : 0.f);
+    const float su = sigmoidf_(sg * up), sl = sigmoidf_(sg * lo);
+    const float d = su - sl;
+    float gl = g[t];
+    if (!(fabsf(d) >= LIK_BOUND || gl < 0.f)) gl = 0.f;               // LowerBound(1e-9) on the likelihood
+    const float sd = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+    const float gup = gl * sd * su * (1.f - su) * sg, glo = -gl * sd * sl * (1.f - sl) * sg;
+    float dx = eb_logits_bwd(p, x + 0.5f, tu, gup, dp);
+    dx += eb_logits_bwd(p, x - 0.5f, tl, glo, dp);
+    if (dv) dv[t] = dx;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 58; ++i) {
+    float s = dp[i];
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) s += __shfl_xor(s, dlt);
+    if (lane == 0) red[w][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 58) dpacked[(long long)ch * 58 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+extern "C" int pcc_eb_lik_fwd(const float* v, int64_t n, int32_t c, const float* eb_packed, float* lik, void* stream) {
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(v && eb_packed && lik && c >= 1, "pcc_eb_lik_fwd: bad arguments");
+  k_eb_lik_fwd<<<(unsigned)pcc_cdiv(n * c, 256), 256, 0, (hipStream_t)stream>>>(v, n, c, eb_packed, lik);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_eb_lik_bwd(const float* v, const float* grad_lik, int64_t n, int32_t c, const float* eb_packed, float* dv,
+                              float* d_packed, void* stream) {
+  PCC_REQUIRE(eb_packed && d_packed && c >= 1 && n >= 0 && (n == 0 || (v && grad_lik)), "pcc_eb_lik_bwd: bad arguments");
+  k_eb_lik_bwd<<<(unsigned)c, 256, 0, (hipStream_t)stream>>>(v, grad_lik, n, c, eb_packed, dv, d_packed);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Differentiable Gaussian likelihood of the training forward (`GaussianConditional._likelihood` +
 // likelihood lower bound; reference call sites `model/entropy_models.py:312-316,327-331`, rate term `loss.py:77-79`):
 //   s = max(scale, 0.11), a = |v - mean|,  lik = max(Phi((.5 - a)/s) - Phi((-.5 - a)/s), 1e-9)

@@ -103,6 +103,8 @@ SIGNATURES = {
     "pcc_gauss_encode": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i32, _p, _p, _p, _p]),
     "pcc_gauss_decode": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i32, _p, _p, _p]),
     "pcc_eb_encode": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "pcc_eb_lik_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
+    "pcc_eb_lik_bwd": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p]),
     "pcc_pmf_to_quantized_cdf": (C.c_int, [_p, _i32, _i32, _p]),
     "pcc_rans_max_bytes": (_i64, [_i64]),
     "pcc_rans_encode_host": (C.c_int, [_p, _p, _i64, _p, _i32, _p, _p, _p, _i64, C.POINTER(_i64)]),

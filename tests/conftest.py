@@ -29,3 +29,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.skip(reason="no GPU in this container"))
         if "reference" in item.keywords and not has_ref:
             item.add_marker(pytest.mark.skip(reason="/root/reference not present"))
+
+
+@pytest.fixture(autouse=True)
+def _seed_torch(request):
+    """Every test starts from the same torch generator state (module initialisers draw from it): a test's data must not
+    depend on which tests ran before it (round 3: an 'intermittent' gradient mismatch was a weight draw that put one
+    LeakyReLU pre-activation within summation noise of 0 -- it came and went with the suite's composition)."""
+    try:
+        import torch
+        torch.manual_seed(0x5EED)
+    except Exception:
+        pass
+    yield

@@ -16,19 +16,27 @@ def _torch_ref(feats, W, b, pairs, n_out, act):
     for k, (i, o) in enumerate(pairs):
         if len(i):
             out = out.index_add(0, torch.from_numpy(o.astype(np.int64)), feats[torch.from_numpy(i.astype(np.int64))] @ W[k])
+    pre = out
     if act == "relu":
         out = torch.relu(out)
     elif act == "leaky":
         out = torch.nn.functional.leaky_relu(out, 0.01)
-    return out
+    return out, pre.detach()
 
 
 def _check(mod, x, out_fn, pairs, n_out, act, W, b, f):
     fr = torch.from_numpy(f).requires_grad_(True)
     Wr = torch.from_numpy(W).requires_grad_(True)
     br = torch.from_numpy(b).requires_grad_(True) if b is not None else None
-    ref = _torch_ref(fr, Wr, br, pairs, n_out, act)
+    ref, pre = _torch_ref(fr, Wr, br, pairs, n_out, act)
     go = np.random.default_rng(7).standard_normal(ref.shape).astype(np.float32)
+    if act is not None:
+        # The derivative of ReLU / LeakyReLU jumps at 0: an output whose pre-activation sits within fp32 summation noise of
+        # 0 (|pre| < 1e-5 on sums of magnitude ~1) may take either sign depending on the summation order, and its upstream
+        # gradient then differs by (1 - slope) * go -- a whole-row error of |go| * |W| in every input row it touches.  That
+        # is what the round-3 "intermittent" failure of the 192 -> 192 case was (tools/kink_rate.py: one weight draw in
+        # ~20 has such an output; the weights were drawn from an unseeded generator).  Such outputs get no upstream gradient.
+        go[np.abs(pre.numpy()) < 1e-5] = 0.0
     ref.backward(torch.from_numpy(go))
     got = out_fn()
     assert_close(n(got), ref.detach().numpy(), what="forward")
@@ -64,21 +72,7 @@ def test_conv_gradients(cin, cout, ks, stride, act):
         out_set = cs if stride == 1 else cs.stride(stride)
         kmap = None if ks == 1 else cs.kernel_map(out_set, ks)
         return mod._apply_conv(x, out_set, kmap, act=code)
-    try:
-        _check(mod, x, run, pairs, len(out_keys), act, W, b, f)
-    except AssertionError as e:
-        # OPEN ITEM: the data gradient of the strided 192 -> 192 case mismatched in a few whole rows on
-        # about one in twenty FIRST executions in a process during round 3, never on a later one, and could not be
-        # reproduced in isolation (tools/flake_probe*.py).  A mismatch that does not repeat on fresh tensors is reported as
-        # an expected-intermittent failure with the rows it touched; one that repeats is a real failure.
-        if "data gradient" not in str(e):
-            raise
-        mod.kernel.grad = None
-        if mod.bias is not None:
-            mod.bias.grad = None
-        x = ME.SparseTensor(coordinates=t(co.unpack_keys(keys)), features=t(f).requires_grad_(True))
-        _check(mod, x, run, pairs, len(out_keys), act, W, b, f)
-        pytest.xfail(f"intermittent first-execution mismatch, not reproduced on repeat: {str(e)[:200]}")
+    _check(mod, x, run, pairs, len(out_keys), act, W, b, f)
 
 
 @pytest.mark.parametrize("cin,cout,ks", [(16, 16, 5), (128, 32, 5), (32, 32, 2), (192, 192, 2)])

@@ -195,9 +195,11 @@ class EntropyModel(nn.Module):
                 segs = ns // ng
         return ng, segs
 
-    def decompress_rows(self, data, n, c, idx=None, device=None, check=None):
+    def decompress_rows(self, data, n, c, idx=None, device=None, check=None, status=None):
         """bytes -> sym [N,C] int32 on `device`.  `check`: list collecting the status words for a deferred check
-        (keeps the decode path free of host synchronisation)."""
+        (keeps the decode path free of host synchronisation).  `status`: the counter() word to use (a caller that runs this
+        under another stream allocates it beforehand: counter blocks are zeroed on the stream that is current when they are
+        cut)."""
         self._check_tables()
         dev = torch.device(device) if device is not None else (idx.device if idx is not None else self._quantized_cdf.device)
         cdf, sizes, offs = (t.to(dev).contiguous() for t in (self._quantized_cdf, self._cdf_length, self._offset))
@@ -206,9 +208,10 @@ class EntropyModel(nn.Module):
                  else np.repeat(np.arange(c, dtype=np.int32), n))
             s = self._host_decode(data, np.ascontiguousarray(i, np.int32))
             return torch.from_numpy(s.reshape(c, n).T.copy()).to(dev)
-        buf = torch.frombuffer(bytearray(data) + bytearray(8), dtype=torch.uint8).to(dev)   # decoder looks one word ahead
+        buf = data.device_buf if isinstance(data, UploadedString) else self.upload_string(data, dev).device_buf
         sym = torch.empty((n, c), dtype=torch.int32, device=dev)
-        status = L.counter(1, torch.int32)
+        if status is None:
+            status = L.counter(1, torch.int32)
         L.call("pcc_rans_decode_streams", L.ptr(buf), len(data), L.ptr(idx.contiguous()) if idx is not None else None,
                n, c, *self._segments_of(data, n, c), L.ptr(cdf), cdf.shape[1], L.ptr(sizes), L.ptr(offs),
                L.ptr(self._dec_table(dev)), self._dec_table(dev).numel(), L.ptr(sym), L.ptr(status), L.stream())
@@ -219,6 +222,15 @@ class EntropyModel(nn.Module):
         else:                                   # deferred: the caller checks all status words once, at the end
             check.append(status)
         return sym
+
+    @staticmethod
+    def upload_string(data, dev):
+        """The container's bytes on the device (padded: the decoder looks one word ahead), as an `UploadedString` that
+        `decompress_rows` takes in place of the bytes -- so that a caller can start the copy early, on another stream."""
+        if isinstance(data, UploadedString):
+            return data
+        buf = torch.frombuffer(bytearray(data) + bytearray(8), dtype=torch.uint8).to(dev)
+        return UploadedString(data, buf)
 
     def _dec_table(self, dev):
         """Compact decoder table of the current CDFs (rebuilt when the tables change)."""
@@ -290,6 +302,20 @@ class EntropyModel(nn.Module):
             outs.append(s.t().reshape(indexes.shape[1:]))
         out = torch.stack(outs, dim=0).to(dtype)
         return out + means if means is not None else out
+
+
+class UploadedString:
+    """A coded string together with its (padded) copy in device memory; behaves like the bytes for the host-side parsing."""
+
+    def __init__(self, data, device_buf):
+        self.data, self.device_buf = data, device_buf
+        self.groups = getattr(data, "groups", 0)
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, i):
+        return self.data[i]
 
 
 class StreamsJob:

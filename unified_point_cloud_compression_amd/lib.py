@@ -176,8 +176,29 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """The current HIP stream of the current device as an integer handle.  (`torch.cuda.current_stream()` builds a Stream
+    object through four Python frames -- 8 us per call, 100 calls per step; the raw query is the same handle in 0.2 us.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+_side = {}
+
+
+def side_stream(device):
+    """A second HIP stream per device for work that is latency-bound on a handful of CUs and independent of what the main
+    stream is doing (the hyper-latent's rANS decode beside the decoder's coordinate work).  Tensors allocated under it must be
+    `record_stream`-ed on the stream that consumes them."""
+    key = torch.device(device).index or 0
+    st = _side.get(key)
+    if st is None:
+        st = _side[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 _ws = {}

@@ -14,6 +14,8 @@ The entropy-coder boundary carries rANS byte strings (`strings = [[y_string], [z
 coder is the per-channel GPU rANS of libpcc_hip by default (`entropy_coder="ans"`: single host stream in CompressAI's
 byte layout; `"symbols"`: hand the int32 symbol tensors across, for kernel-level measurements).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -212,7 +214,30 @@ class MeanScaleHyperprior(CompressionModel):
         _, _, y_lik = self.gaussian_conditional.encode_rows(y._canonical_features(), params, y._cset.keys, scale)
         return y_lik, z_lik
 
-    def decompress(self, points, symbols, shape, q, check=None):
+    SIDE_STREAM_DECODE = os.environ.get("PCC_SIDE_DECODE", "1") != "0"
+
+    def predecode(self, symbols, shape, device, check=None):
+        """What depends on the strings alone, started before the decoder's coordinate work and beside it: the hyper-latent's
+        rANS decode (a serial recurrence per stream on a handful of CUs: 0.4 ms during which the main stream builds y's and
+        z's coordinate sets, the first level's maps and candidate set) and the upload of y's string, on the side stream.
+        Returns a token for `decompress(pre=...)`, or None when the coder is not the GPU one."""
+        if self.entropy_coder != "pcc_streams" or not self.SIDE_STREAM_DECODE or int(shape[0]) <= 0:
+            return None
+        (y_string,), (z_string,) = symbols
+        eb = self.entropy_bottleneck
+        eb._check_tables()
+        status = L.counter(1, torch.int32)
+        main = torch.cuda.current_stream(device)
+        side = L.side_stream(device)
+        with torch.cuda.stream(side):
+            y_up = self.gaussian_conditional.upload_string(y_string, device)
+            z_sym = eb.decompress_rows(z_string, int(shape[0]), eb.channels, device=device, check=check, status=status)
+            ev = side.record_event()
+        for t in (y_up.device_buf, z_sym):          # allocated under the side stream, consumed on the main one
+            t.record_stream(main)
+        return z_sym, y_up, ev
+
+    def decompress(self, points, symbols, shape, q, check=None, pre=None):
         """points = [y CoordSet, z CoordSet]; symbols = strings [[y_string], [z_string]] (or the symbol tensors with
         entropy_coder="symbols") (`model/entropy_models.py:409-490`).  Returns y_hat as a stride-8 SparseTensor."""
         assert isinstance(symbols, list) and len(symbols) == 2
@@ -224,8 +249,12 @@ class MeanScaleHyperprior(CompressionModel):
             y_sym, z_sym = symbols
         else:
             (y_string,), (z_string,) = symbols
-            z_sym = self.entropy_bottleneck.decompress_rows(z_string, z_cset.n, self.entropy_bottleneck.channels,
-                                                            device=dev, check=check)
+            if pre is not None:
+                z_sym, y_string, ev = pre
+                torch.cuda.current_stream(dev).wait_event(ev)
+            else:
+                z_sym = self.entropy_bottleneck.decompress_rows(z_string, z_cset.n, self.entropy_bottleneck.channels,
+                                                                device=dev, check=check)
             y_sym = None
         med = self.entropy_bottleneck.quantiles[:, 0, 1].detach().to(torch.float32)
         z_hat = SparseTensor._from_canonical(z_cset, z_sym.to(torch.float32) + med[None, :])

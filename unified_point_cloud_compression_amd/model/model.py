@@ -189,6 +189,7 @@ class UnifiedModel(CompressionModel):
                 q_vals[i] = q_vals[i].to(device)
         feats, coords, status = [], [], []
         for i, (block_symbols, block_shape, block_coords, block_k) in enumerate(zip(strings, shape, coordinates, k)):
+            pre = self.entropy_model.predecode(block_symbols, block_shape, device, check=status)
             y_cset = getattr(block_coords, "_pcc_cset", None)
             if (y_cset is None or y_cset.ts != 8 or y_cset.n != block_coords.shape[0]
                     or getattr(block_coords, "_pcc_version", block_coords._version) != block_coords._version):
@@ -206,7 +207,7 @@ class UnifiedModel(CompressionModel):
                 z_cset = S.resolve(y_cset.stride_begin(ts_z), *self.g_s.plan(y_cset))[0]
             if z_cset.n != int(block_shape[0]):
                 raise L.PccError(f"bitstream says {int(block_shape[0])} hyper-latent rows, the coordinates give {z_cset.n}")
-            y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i], check=status)
+            y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i], check=status, pre=pre)
             x_hat = self.g_s(y_hat, k=block_k, trace=trace, probe=probe)
             feats.append(x_hat.F)
             coords.append(x_hat.C)

@@ -110,10 +110,11 @@ def _two_batch_keys(seed, ts, shift):
     return np.unique(co.pack_keys(np.concatenate(C)))
 
 
-@pytest.mark.parametrize("ts,shift,cin,cout", [(1, 0, 16, 1), (2, -5, 8, 3), (1, -3, 32, 4)])
+@pytest.mark.parametrize("ts,shift,cin,cout", [(1, 0, 16, 1), (2, -5, 8, 3), (1, -3, 32, 4), (1, 0, 64, 1), (2, -5, 32, 1)])
 def test_thin_conv_from_grid_matches_oracle(ts, shift, cin, cout):
     """`pcc_conv_thin_grid_fwd`: 3x3x3 conv to <= 4 channels, neighbour rows from the bitmap + rank (no kernel map);
-    two batch entries, negative coordinates, rows on every face of the bounding lattice."""
+    two batch entries, negative coordinates, rows on every face of the bounding lattice.  (cin 32 / 64 with one output
+    channel: the projections run on the matrix pipe, `k_thin_project_mfma`.)"""
     from unified_point_cloud_compression_amd import sparse as S
     import unified_point_cloud_compression_amd.MinkowskiEngine as ME
     rng = np.random.default_rng(cin * 7 + cout)

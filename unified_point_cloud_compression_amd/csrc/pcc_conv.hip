@@ -2438,8 +2438,82 @@ static int launch_wave16(const Wave16Args& a, hipStream_t s) {
   return PCC_OK;
 }
 
+// The same projections on the matrix pipe, for wide inputs (cin 32 / 64) and at most 32 projections (the one-channel heads:
+// 27): t^T = W2 x^T as v_mfma_f32_32x32x2_f32 with the WEIGHTS as the A operand (its 32 rows = the projections k) and 32 feature
+// rows as the B operand (its 32 columns), so that an accumulator register holds t[k][32 consecutive rows] across the lanes of a
+// half wave: every store instruction writes two 128-byte runs of the k-major planes -- the layout the gather reads.  A lane
+// (row r = lane & 31, half h) carries the channels h * CIN/2 ... of its row (CIN/8 16-byte loads, its half of the row,
+// contiguous) and of its projection (CIN/2 registers, loaded once per wave); CIN/2 MFMAs per 32 rows.  The VALU form above
+// spends 27 * CIN FMAs + 27 * CIN/4 broadcast LDS reads per row (24 TFLOP/s on the 64-channel heads: issue-bound).
+template <int CIN>
+__global__ void __launch_bounds__(256) k_thin_project_mfma(const float* __restrict__ feat, long long n_in,
+                                                           const float* __restrict__ wt, int kc, float* __restrict__ t) {
+  constexpr int HC = CIN / 2, NV = HC / 4;
+  const int lane = threadIdx.x & 63, r31 = lane & 31, half = lane >> 5;
+  const long long ntiles = (n_in + 31) / 32;
+  float wa[HC];
+#pragma unroll
+  for (int c = 0; c < HC; ++c) wa[c] = r31 < kc ? wt[r31 * CIN + half * HC + c] : 0.f;
+  const long long tstep = (long long)gridDim.x * 4;
+  long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  auto load = [&](long long tl, float4 (&x)[NV]) {
+    long long row = tl * 32 + r31;
+    if (row >= n_in) row = n_in - 1;                       // tail rows repeat the last row (never stored)
+    const float4* src = reinterpret_cast<const float4*>(feat + row * CIN + half * HC);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) x[v] = src[v];
+  };
+  auto run = [&](long long tl, const float4 (&x)[NV]) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {                         // fixed order: channels ascending inside each half
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[4 * v + 0], x[v].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[4 * v + 1], x[v].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[4 * v + 2], x[v].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[4 * v + 3], x[v].w, acc, 0, 0, 0);
+    }
+    const long long row = tl * 32 + r31;
+    if (row < n_in) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (k < kc) t[(long long)k * n_in + row] = acc[e];
+      }
+    }
+  };
+  float4 xa[NV], xb[NV];
+  load(tile, xa);
+  for (;;) {                                               // two tiles per trip, the buffers swapping roles
+    const long long t1 = tile + tstep;
+    if (t1 < ntiles) load(t1, xb);
+    run(tile, xa);
+    if (t1 >= ntiles) break;
+    const long long t2 = t1 + tstep;
+    if (t2 < ntiles) load(t2, xa);
+    run(t1, xb);
+    if (t2 >= ntiles) break;
+    tile = t2;
+  }
+}
+
+static bool g_thin_mfma = getenv("PCC_THIN_MFMA") ? atoi(getenv("PCC_THIN_MFMA")) != 0 : true;
+
 template <int CIN>
 static int launch_project(const float* feat, int64_t n_in, const float* wt, int kc, float* t, hipStream_t s) {
+  if constexpr (CIN >= 32) {
+    if (g_thin_mfma && kc <= 32) {
+      const long long tiles = pcc_cdiv(n_in, 32);
+      long long grid = pcc_cdiv(tiles, 4 * 4);             // ~4 tiles per wave: the weight registers are loaded once per wave
+      if (grid > 4096) grid = 4096;
+      if (grid < 1) grid = 1;
+      k_thin_project_mfma<CIN><<<(unsigned)grid, 256, 0, s>>>(feat, n_in, wt, kc, t);
+      PCC_LAUNCH_CHECK();
+      return PCC_OK;
+    }
+  }
   k_thin_project<CIN><<<(unsigned)pcc_cdiv(n_in, 256), 256, (size_t)kc * CIN * sizeof(float), s>>>(feat, n_in, wt, kc, t);
   PCC_LAUNCH_CHECK();
   return PCC_OK;

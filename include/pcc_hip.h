@@ -336,6 +336,12 @@ size_t pcc_topk_ws_bytes(int64_t n);
 int pcc_topk_mask(const float* logits, int64_t stride_elems, const int64_t* h_seg_begin,
                   const int64_t* h_k, int32_t nb, uint8_t* mask, void* ws, size_t ws_bytes,
                   void* stream);
+/* the same selection with the kept rows' keys compacted in the same pass (the decoder's "top-k, then prune the coordinates",
+ * model/transforms.py:246-282 without the features): keys [rows], keys_out capacity sum_b min(max(k_b,0), rows_b), written
+ * batch after batch in canonical order; mask as pcc_topk_mask. */
+int pcc_topk_prune_keys(const float* logits, int64_t stride_elems, const int64_t* h_seg_begin,
+                        const int64_t* h_k, int32_t nb, const int64_t* keys, uint8_t* mask, int64_t* keys_out,
+                        void* ws, size_t ws_bytes, void* stream);
 /* row compaction by mask: keys_out/feat_out capacity n; *d_count device int64 */
 size_t pcc_prune_ws_bytes(int64_t n);
 int pcc_prune_rows(const uint8_t* mask, int64_t n, const int64_t* keys, const float* feat, int32_t c,

@@ -34,6 +34,34 @@ def test_topk_threshold_inside_tie_run_and_batches():
     assert np.array_equal(got, ops.topk_mask(logits, [2, 3], batch))
 
 
+@pytest.mark.parametrize("rows", [10, 2047, 2048, 2049, 100_000, 1_300_000])
+def test_topk_prune_keys_equals_mask_then_prune(rows):
+    """`pcc_topk_prune_keys` (selection + key compaction in one pass: the decoder's composite levels) against the oracle's
+    mask and `keys[mask]`: ties at the threshold inside and across the 2048-row workgroups, strided logits, three batches
+    with k = 0 / k inside a tie run / k >= rows."""
+    from unified_point_cloud_compression_amd import sparse as S
+    rng = np.random.default_rng(rows)
+    logits = rng.standard_normal(rows).astype(np.float32)
+    logits[rng.integers(0, rows, rows // 2)] = np.float32(0.125)      # half the rows tie at one value
+    logits[rng.integers(0, rows, max(rows // 40, 1))] = np.float32(-0.0)
+    keys = np.sort(rng.choice(10 ** 12, rows, replace=False)).astype(np.int64)
+    wide = np.stack([logits, rng.standard_normal(rows).astype(np.float32)], axis=1)       # column 0 of an [n, 2] tensor
+    for k in sorted({0, 1, rows // 3, rows // 2, rows - 1, rows, rows + 5}):
+        want = ops.topk_mask(logits, [k])
+        mask, ko, cnt = S.topk_prune_keys(t(wide), [0, rows], [k], t(keys))
+        assert cnt == min(k, rows) == int(want.sum()), k
+        assert np.array_equal(n(mask), want), k
+        assert np.array_equal(n(ko), keys[want]), k
+        assert np.array_equal(n(S.topk_mask(t(logits)[:, None], [0, rows], [k])), want), k
+    if rows >= 100:
+        cut = [0, rows // 5, rows // 2, rows]
+        batch = np.repeat(np.arange(3), np.diff(cut))
+        ks = [0, (cut[2] - cut[1]) // 2, rows]
+        want = ops.topk_mask(logits, ks, batch)
+        mask, ko, cnt = S.topk_prune_keys(t(logits)[:, None], cut, ks, t(keys))
+        assert np.array_equal(n(mask), want) and np.array_equal(n(ko), keys[want]) and cnt == int(want.sum())
+
+
 def test_prune_rows():
     from unified_point_cloud_compression_amd import sparse as S
     rng = np.random.default_rng(1)

@@ -12,57 +12,166 @@ __device__ inline unsigned f2u(float f) {
 
 struct SelState { unsigned prefix, mask; int remaining; int pad; };
 
+// Radix select in three passes of 11 + 11 + 10 bits (round 3; four passes of 8 before): a pass is one read of the logits with a
+// histogram of the digit below the prefix found so far, then one workgroup picks the digit holding the `remaining`-th largest
+// candidate.  With 11 bits the first digit is sign + exponent + 2 mantissa bits, so occupancy logits no longer pile onto two or
+// three bins of the LDS histogram (same-address atomics of a wave serialise).
+static constexpr int SEL_MAXBINS = 2048;
+static constexpr int SEL_WS_HDR = 256 + SEL_MAXBINS * 4 + 256;      // state | histogram | pad
+static constexpr int SEL_B = 2048;                                    // rows per workgroup of the count / compact passes (256 x 8)
+
 __global__ void k_sel_init(SelState* st, int* hist, int k) {
   if (threadIdx.x == 0) { st->prefix = 0; st->mask = 0; st->remaining = k; st->pad = 0; }
-  hist[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < SEL_MAXBINS; i += blockDim.x) hist[i] = 0;
 }
 
+template <int BITS>
 __global__ void __launch_bounds__(256) k_sel_hist(const float* __restrict__ logits, long long stride, long long n,
                                                   int shift, const SelState* __restrict__ st, int* __restrict__ hist) {
-  __shared__ int h[256];
-  h[threadIdx.x] = 0;
+  constexpr int NB = 1 << BITS;
+  __shared__ int h[NB];
+  for (int i = threadIdx.x; i < NB; i += 256) h[i] = 0;
   __syncthreads();
   const unsigned prefix = st->prefix, mask = st->mask;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const unsigned u = f2u(logits[i * stride]);
-    if ((u & mask) == prefix) atomicAdd(&h[(u >> shift) & 0xFF], 1);
+    if ((u & mask) == prefix) atomicAdd(&h[(u >> shift) & (NB - 1)], 1);
   }
   __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+  for (int i = threadIdx.x; i < NB; i += 256)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
-// pick the digit holding the `remaining`-th largest candidate; clears hist for the next pass
-__global__ void k_sel_pick(SelState* st, int* hist, int shift) {
-  __shared__ int h[256];
-  h[threadIdx.x] = hist[threadIdx.x];
-  hist[threadIdx.x] = 0;
+// pick the digit holding the `remaining`-th largest candidate (bins walked from the top); clears hist for the next pass.
+// 256 threads: thread t owns the NB/256 bins below NB - t * per; an exclusive scan over the threads finds the owner.
+__global__ void __launch_bounds__(256) k_sel_pick(SelState* st, int* hist, int shift, int bits) {
+  __shared__ int wsum[4];
+  __shared__ int h[SEL_MAXBINS];
+  const int nb = 1 << bits, per = nb >> 8;
+  for (int i = threadIdx.x; i < nb; i += 256) { h[i] = hist[i]; hist[i] = 0; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int rem = st->remaining, cum = 0, d = 255;
-    for (; d > 0; --d) {
-      if (cum + h[d] >= rem) break;
+  const int top = nb - 1 - (int)threadIdx.x * per;                    // this thread's bins: top, top-1, ..., top-per+1
+  int mine = 0;
+  for (int q = 0; q < per; ++q) mine += h[top - q];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int before = inc - mine;
+  for (int q = 0; q < w; ++q) before += wsum[q];
+  const int rem = st->remaining;                                       // (read by everyone before anyone writes: barrier below)
+  const bool last = threadIdx.x == 255;
+  __syncthreads();
+  // the owner: cumulative count reaches `rem` inside its bins; if it is never reached (rem > population, cannot happen for
+  // 0 < k < n) the last thread settles on bin 0, as the sequential walk did
+  if ((before < rem && before + mine >= rem) || (last && before + mine < rem)) {
+    int cum = before, d = top;
+    for (int q = 0; q < per; ++q, --d) {
+      if (cum + h[d] >= rem || d == 0) break;
       cum += h[d];
     }
     st->remaining = rem - cum;
     st->prefix |= (unsigned)d << shift;
-    st->mask |= 0xFFu << shift;
+    st->mask |= (unsigned)(nb - 1) << shift;
   }
 }
 
-__global__ void k_sel_eqflags(const float* __restrict__ logits, long long stride, long long n,
-                              const SelState* __restrict__ st, int* __restrict__ eq) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  eq[i] = (f2u(logits[i * stride]) == st->prefix) ? 1 : 0;
+// ---- mask + stable compaction in three launches (after the select: T = st->prefix is the k-th largest value) --------------
+// keep[i] = u_i > T  or  (u_i == T and fewer than `remaining` equal values precede i): the rows of a workgroup need the number of
+// equal values and of kept rows before it -- both follow from per-workgroup (greater, equal) counts by one small scan.
+__device__ inline int sel_block_scan(int v, int* total, int* wsum) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int sv = wsum[q]; if (q < w) base += sv; tot += sv; }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
 }
 
-__global__ void k_sel_mask(const float* __restrict__ logits, long long stride, long long n,
-                           const SelState* __restrict__ st, const int* __restrict__ eq_rank,
-                           unsigned char* __restrict__ mask) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned u = f2u(logits[i * stride]), T = st->prefix;
-  mask[i] = (u > T || (u == T && eq_rank[i] < st->remaining)) ? 1 : 0;
+__global__ void __launch_bounds__(256) k_sel_count(const float* __restrict__ logits, long long stride, long long n,
+                                                   const SelState* __restrict__ st, int2* __restrict__ cnt) {
+  __shared__ int wsum[4];
+  const unsigned T = st->prefix;
+  const long long base = (long long)blockIdx.x * SEL_B + (long long)threadIdx.x * 8;
+  int gt = 0, eq = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (base + q < n) {
+      const unsigned u = f2u(logits[(base + q) * stride]);
+      gt += u > T; eq += u == T;
+    }
+  int tg, te;
+  sel_block_scan(gt, &tg, wsum);
+  sel_block_scan(eq, &te, wsum);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = make_int2(tg, te);
+}
+
+// one workgroup: per counted workgroup b the equal values before it and the rows kept before it (exclusive scans, chunked)
+__global__ void __launch_bounds__(256) k_sel_offsets(const int2* __restrict__ cnt, int nblk, const SelState* __restrict__ st,
+                                                     int2* __restrict__ before) {
+  __shared__ int wsum[4];
+  const int rem = st->remaining;
+  int carry_eq = 0, carry_keep = 0;
+  for (int b0 = 0; b0 < nblk; b0 += 256) {
+    const int b = b0 + (int)threadIdx.x;
+    const int2 c = b < nblk ? cnt[b] : make_int2(0, 0);
+    int tot;
+    const int eqb = carry_eq + sel_block_scan(c.y, &tot, wsum);
+    carry_eq += tot;
+    const int room = rem - eqb;
+    const int kept = c.x + (room <= 0 ? 0 : (room < c.y ? room : c.y));
+    const int keepb = carry_keep + sel_block_scan(kept, &tot, wsum);
+    carry_keep += tot;
+    if (b < nblk) before[b] = make_int2(eqb, keepb);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_sel_compact(const float* __restrict__ logits, long long stride, long long n,
+                                                     const SelState* __restrict__ st, const int2* __restrict__ before,
+                                                     const int64_t* __restrict__ keys, unsigned char* __restrict__ mask,
+                                                     int64_t* __restrict__ keys_out) {
+  __shared__ int wsum[4];
+  const unsigned T = st->prefix;
+  const int rem = st->remaining;
+  const int2 bf = before[blockIdx.x];
+  const long long base = (long long)blockIdx.x * SEL_B + (long long)threadIdx.x * 8;
+  unsigned u[8];
+  int eq = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    u[q] = base + q < n ? f2u(logits[(base + q) * stride]) : 0u;
+    eq += (base + q < n) && u[q] == T;
+  }
+  int tot;
+  int eq_rank = bf.x + sel_block_scan(eq, &tot, wsum);
+  bool keep[8];
+  int kc = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const bool in = base + q < n;
+    const bool e = in && u[q] == T;
+    keep[q] = in && (u[q] > T || (e && eq_rank < rem));
+    eq_rank += e;
+    kc += keep[q];
+  }
+  int pos = bf.y + sel_block_scan(kc, &tot, wsum);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    if (base + q >= n) break;
+    mask[base + q] = keep[q] ? 1 : 0;
+    if (keep[q]) {
+      if (keys_out) keys_out[pos] = keys[base + q];
+      ++pos;
+    }
+  }
 }
 
 __global__ void k_fill_u8(unsigned char* p, long long n, unsigned char v) {
@@ -70,52 +179,79 @@ __global__ void k_fill_u8(unsigned char* p, long long n, unsigned char v) {
   if (i < n) p[i] = v;
 }
 
+__global__ void k_copy_i64(const int64_t* __restrict__ in, long long n, int64_t* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
 extern "C" size_t pcc_topk_ws_bytes(int64_t n) {
-  if (n <= 0) return 2048;
-  return 2048 + pcc_align_up((size_t)n * 4) + pcc_scan_ws_bytes(n);
+  if (n <= 0) return SEL_WS_HDR;
+  return SEL_WS_HDR + 2 * pcc_align_up((size_t)pcc_cdiv(n, SEL_B) * sizeof(int2)) + 256;
+}
+
+// keys / keys_out nullable: the mask alone (pcc_topk_mask).  keys_out receives the kept rows' keys batch after batch
+// (batch b starts at the sum of min(k, rows) of the batches before it -- sizes the host has).
+static int topk_impl(const float* logits, int64_t stride_elems, const int64_t* h_seg_begin, const int64_t* h_k, int32_t nb,
+                     const int64_t* keys, uint8_t* mask, int64_t* keys_out, void* ws, size_t ws_bytes, hipStream_t s) {
+  PCC_REQUIRE(h_seg_begin && h_k && nb >= 0, "pcc_topk: bad arguments");
+  int64_t out_base = 0;
+  for (int b = 0; b < nb; ++b) {
+    const int64_t b0 = h_seg_begin[b], n = h_seg_begin[b + 1] - b0, k = h_k[b];
+    if (n <= 0) continue;
+    PCC_REQUIRE(logits && mask && stride_elems >= 1, "pcc_topk: NULL array");
+    PCC_REQUIRE(n < (1ll << 31), "pcc_topk: too many rows");
+    const unsigned g = (unsigned)pcc_cdiv(n, 256);
+    if (k <= 0 || k >= n) {
+      k_fill_u8<<<g, 256, 0, s>>>(mask + b0, n, k >= n ? 1 : 0);
+      PCC_LAUNCH_CHECK();
+      if (k >= n && keys_out) {
+        k_copy_i64<<<g, 256, 0, s>>>(keys + b0, n, keys_out + out_base);
+        PCC_LAUNCH_CHECK();
+      }
+      if (k >= n) out_base += n;
+      continue;
+    }
+    if (ws_bytes < pcc_topk_ws_bytes(n)) {
+      pcc_set_error("pcc_topk: workspace too small");
+      return PCC_EWS;
+    }
+    SelState* st = (SelState*)ws;
+    int* hist = (int*)((char*)ws + 256);
+    const int nblk = (int)pcc_cdiv(n, SEL_B);
+    int2* cnt = (int2*)((char*)ws + SEL_WS_HDR);
+    int2* before = (int2*)((char*)cnt + pcc_align_up((size_t)nblk * sizeof(int2)));
+    const float* lg = logits + b0 * stride_elems;
+    k_sel_init<<<1, 256, 0, s>>>(st, hist, (int)k);
+    PCC_LAUNCH_CHECK();
+    const unsigned gh = g < 1024 ? g : 1024;
+    k_sel_hist<11><<<gh, 256, 0, s>>>(lg, stride_elems, n, 21, st, hist);
+    k_sel_pick<<<1, 256, 0, s>>>(st, hist, 21, 11);
+    k_sel_hist<11><<<gh, 256, 0, s>>>(lg, stride_elems, n, 10, st, hist);
+    k_sel_pick<<<1, 256, 0, s>>>(st, hist, 10, 11);
+    k_sel_hist<10><<<gh, 256, 0, s>>>(lg, stride_elems, n, 0, st, hist);
+    k_sel_pick<<<1, 256, 0, s>>>(st, hist, 0, 10);
+    PCC_LAUNCH_CHECK();
+    k_sel_count<<<(unsigned)nblk, 256, 0, s>>>(lg, stride_elems, n, st, cnt);
+    k_sel_offsets<<<1, 256, 0, s>>>(cnt, nblk, st, before);
+    k_sel_compact<<<(unsigned)nblk, 256, 0, s>>>(lg, stride_elems, n, st, before, keys ? keys + b0 : nullptr, mask + b0,
+                                                keys_out ? keys_out + out_base : nullptr);
+    PCC_LAUNCH_CHECK();
+    out_base += k;
+  }
+  return PCC_OK;
 }
 
 extern "C" int pcc_topk_mask(const float* logits, int64_t stride_elems, const int64_t* h_seg_begin,
                              const int64_t* h_k, int32_t nb, uint8_t* mask, void* ws, size_t ws_bytes,
                              void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  PCC_REQUIRE(h_seg_begin && h_k && nb >= 0, "pcc_topk_mask: bad arguments");
-  for (int b = 0; b < nb; ++b) {
-    const int64_t b0 = h_seg_begin[b], n = h_seg_begin[b + 1] - b0, k = h_k[b];
-    if (n <= 0) continue;
-    PCC_REQUIRE(logits && mask && stride_elems >= 1, "pcc_topk_mask: NULL array");
-    PCC_REQUIRE(n < (1ll << 31), "pcc_topk_mask: too many rows");
-    const unsigned g = (unsigned)pcc_cdiv(n, 256);
-    if (k <= 0 || k >= n) {
-      k_fill_u8<<<g, 256, 0, s>>>(mask + b0, n, k >= n ? 1 : 0);
-      PCC_LAUNCH_CHECK();
-      continue;
-    }
-    if (ws_bytes < pcc_topk_ws_bytes(n)) {
-      pcc_set_error("pcc_topk_mask: workspace too small");
-      return PCC_EWS;
-    }
-    SelState* st = (SelState*)ws;
-    int* hist = (int*)((char*)ws + 256);
-    int* eq = (int*)((char*)ws + 2048);
-    void* scan_ws = (char*)eq + pcc_align_up((size_t)n * 4);
-    const float* lg = logits + b0 * stride_elems;
-    k_sel_init<<<1, 256, 0, s>>>(st, hist, (int)k);
-    PCC_LAUNCH_CHECK();
-    const unsigned gh = g < 1024 ? g : 1024;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-      k_sel_hist<<<gh, 256, 0, s>>>(lg, stride_elems, n, shift, st, hist);
-      PCC_LAUNCH_CHECK();
-      k_sel_pick<<<1, 256, 0, s>>>(st, hist, shift);
-      PCC_LAUNCH_CHECK();
-    }
-    k_sel_eqflags<<<g, 256, 0, s>>>(lg, stride_elems, n, st, eq);
-    PCC_LAUNCH_CHECK();
-    PCC_TRY(pcc_scan_exclusive_i32(eq, eq, n, scan_ws, ws_bytes - 2048 - pcc_align_up((size_t)n * 4), s));
-    k_sel_mask<<<g, 256, 0, s>>>(lg, stride_elems, n, st, eq, mask + b0);
-    PCC_LAUNCH_CHECK();
-  }
-  return PCC_OK;
+  return topk_impl(logits, stride_elems, h_seg_begin, h_k, nb, nullptr, mask, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int pcc_topk_prune_keys(const float* logits, int64_t stride_elems, const int64_t* h_seg_begin,
+                                   const int64_t* h_k, int32_t nb, const int64_t* keys, uint8_t* mask, int64_t* keys_out,
+                                   void* ws, size_t ws_bytes, void* stream) {
+  PCC_REQUIRE(keys && keys_out, "pcc_topk_prune_keys: NULL array");
+  return topk_impl(logits, stride_elems, h_seg_begin, h_k, nb, keys, mask, keys_out, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------

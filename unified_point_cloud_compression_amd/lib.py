@@ -96,6 +96,7 @@ SIGNATURES = {
     "pcc_gdn_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p]),
     "pcc_topk_ws_bytes": (_sz, [_i64]),
     "pcc_topk_mask": (C.c_int, [_p, _i64, C.POINTER(_i64), C.POINTER(_i64), _i32, _p, _p, _sz, _p]),
+    "pcc_topk_prune_keys": (C.c_int, [_p, _i64, C.POINTER(_i64), C.POINTER(_i64), _i32, _p, _p, _p, _p, _sz, _p]),
     "pcc_prune_ws_bytes": (_sz, [_i64]),
     "pcc_prune_rows": (C.c_int, [_p, _i64, _p, _p, _i32, _p, _p, _p, _p, _sz, _p]),
     "pcc_lookup_gather": (C.c_int, [_p, _i64, _p, _i32, _p, _i64, _p, _p]),

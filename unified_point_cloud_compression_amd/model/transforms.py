@@ -270,12 +270,16 @@ class SparseSynthesisTransform(nn.Module):
                                     act=L.ACT_RELU, ex_map=kmap3, ex_bias=cb)
             logit = c2._apply_conv(SparseTensor._from_canonical(out_set, h), out_set, kmap3)
         pred = SparseTensor._from_canonical(out_set, logit)
-        mask, n_keep = self._topk_prediction(pred, k_lvl)
-        if probe is not None:
+        if probe is None:              # selection and key compaction in one pass over the logits
+            seg, bids = batch_segments(out_set)
+            ks = [int(k_lvl[b]) if (seg[i + 1] > seg[i]) else 0 for i, b in enumerate(bids)]
+            mask, keys, n = S.topk_prune_keys(logit, seg, ks, out_set.keys)
+        else:
+            mask, n_keep = self._topk_prediction(pred, k_lvl)
             forced = probe("select", lvl, out_set, logit, mask, None)
             if forced is not None:
                 mask, n_keep = forced, int(forced.sum().item())
-        keys, _, n = S.prune(out_set.keys, out_set.n, None, mask, n_keep)
+            keys, _, n = S.prune(out_set.keys, out_set.n, None, mask, n_keep)
         kept = S.CoordSet(keys, n, ts_out, out_set.bounds)
         # the up-sampled features, for the kept rows only: transposed conv restricted to them, in pair-list form
         if "_packed_conv" not in gen.__dict__:

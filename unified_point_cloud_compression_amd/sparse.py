@@ -864,6 +864,32 @@ def topk_mask(logits, seg_begin, ks):
     return mask[:n].view(torch.bool)
 
 
+def topk_prune_keys(logits, seg_begin, ks, keys):
+    """`topk_mask` and the compaction of the kept rows' keys in one pass over the logits (a4, coordinates only: what the
+    decoder's composite levels need).  Returns (mask bool [n], kept keys int64 [n_keep], n_keep)."""
+    n = logits.shape[0]
+    nb = len(ks)
+    n_keep = sum(min(max(int(k), 0), seg_begin[i + 1] - seg_begin[i]) for i, k in enumerate(ks))
+    mask = torch.empty(max(n, 1), dtype=torch.uint8, device=logits.device)
+    keys_out = torch.empty(max(n_keep, 1), dtype=torch.int64, device=logits.device)
+    if n == 0:
+        return mask[:0].bool(), keys_out[:0], 0
+    if logits.dim() == 2:
+        if logits.stride(1) != 1 and logits.shape[1] != 1:
+            logits = logits.contiguous()
+        stride = logits.stride(0)
+    else:
+        logits, stride = logits.contiguous(), 1
+    if not logits.is_cuda:
+        raise L.PccError("topk_prune_keys: GPU tensor required")
+    sb = (C.c_int64 * (nb + 1))(*seg_begin)
+    kk = (C.c_int64 * nb)(*[int(k) for k in ks])
+    ws = L.workspace(L.load().pcc_topk_ws_bytes(n), logits.device)
+    L.call("pcc_topk_prune_keys", logits.data_ptr(), stride, sb, kk, nb, L.ptr(keys), L.ptr(mask), L.ptr(keys_out), L.ptr(ws),
+           ws.numel(), L.stream())
+    return mask[:n].view(torch.bool), keys_out[:n_keep], n_keep
+
+
 def prune(keys, n, feats, mask, n_keep=None):
     """Stable row compaction (a4).  n_keep known (top-k) avoids the device->host count read."""
     dev = keys.device

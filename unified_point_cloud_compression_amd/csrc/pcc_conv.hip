@@ -2272,6 +2272,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
   reinterpret_cast<float4*>(out)[t] = v;
 }
 
+static int g_splitk_chunks = getenv("PCC_SPLITK_CHUNKS") ? atoi(getenv("PCC_SPLITK_CHUNKS")) : 40;
 static bool g_splitk = getenv("PCC_SPLITK") ? atoi(getenv("PCC_SPLITK")) != 0 : true;
 static bool g_gemm_persistent = getenv("PCC_GEMM_PERSISTENT") ? atoi(getenv("PCC_GEMM_PERSISTENT")) != 0 : false;   // measured slower (2 workgroups per CU): off
 static bool g_splitk_tiles = getenv("PCC_SPLITK_TILES") ? atoi(getenv("PCC_SPLITK_TILES")) != 0 : true;
@@ -2323,7 +2324,7 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
   if (split && g_splitk && MODE == MODE_CONV && a.hdr && !a.pair_in && (a.cout & 3) == 0) {
     const int depth = 27 * a.ppo;                      // chunks of a 3x3x3 map (the maps that reach here; 5x5x5 take the pair form)
     if (tiles(128) * gy < 256 && depth >= 64) {
-      ksplit = depth / 40;                             // ~40 chunks per workgroup
+      ksplit = depth / g_splitk_chunks;                // ~40 chunks per workgroup
       if (ksplit > 8) ksplit = 8;
       if (ksplit < 2) ksplit = 1;
     }

@@ -23,7 +23,17 @@ struct SegPlan {           // host-built, passed by value to k_write_hdr
 // class_begin: nullptr -> single segment covering [0, n_out)
 __global__ void k_write_hdr(SegPlan plan, const int* __restrict__ class_begin, int class_stride,
                             int64_t n_out, int* __restrict__ hdr) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // launched <<<1, 192>>>: thread i writes the i-th offset / order entry, thread 0 the segment table (one thread walking
+  // all of it took 10-14 us per map, ten maps per step)
+  if (blockIdx.x != 0) return;
+  {
+    const int i = (int)threadIdx.x;
+    if (i < plan.K && i < 192) {
+      hdr[HDR_KOFFS + i] = plan.listed ? plan.koffs[i] : i;
+      hdr[HDR_ORDER + i] = plan.order[i];
+    }
+  }
+  if (threadIdx.x != 0) return;
   hdr[HDR_NSEG] = plan.nseg;
   hdr[HDR_K] = plan.K;
   hdr[HDR_FLAGS] = plan.listed;
@@ -43,10 +53,6 @@ __global__ void k_write_hdr(SegPlan plan, const int* __restrict__ class_begin, i
     seg[SEG_NBR_LO] = (int)(nbr_begin & 0xFFFFFFFFll);
     seg[SEG_NBR_HI] = (int)(nbr_begin >> 32);
     nbr_begin += (int64_t)pc * plan.k_count[s];
-  }
-  for (int i = 0; i < plan.K && i < 192; ++i) {
-    hdr[HDR_KOFFS + i] = plan.listed ? plan.koffs[i] : i;
-    hdr[HDR_ORDER + i] = plan.order[i];
   }
 }
 
@@ -314,7 +320,7 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
     plan.k_count[0] = K;
     plan.koff_begin[0] = 0;
     plan_order(plan, kernel_size);
-    k_write_hdr<<<1, 1, 0, s>>>(plan, nullptr, 0, n_out, hdr);
+    k_write_hdr<<<1, 192, 0, s>>>(plan, nullptr, 0, n_out, hdr);
     PCC_LAUNCH_CHECK();
     if (n_out == 0) return PCC_OK;
     PCC_REQUIRE(in_keys && out_keys && nbr, "pcc_kernel_map_build: NULL array");
@@ -365,7 +371,7 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
   }
   plan_order(plan, kernel_size);
   if (n_out == 0) {
-    k_write_hdr<<<1, 1, 0, s>>>(plan, nullptr, 0, 0, hdr);   // all segments empty
+    k_write_hdr<<<1, 192, 0, s>>>(plan, nullptr, 0, 0, hdr);   // all segments empty
     PCC_LAUNCH_CHECK();
     return PCC_OK;
   }
@@ -383,7 +389,7 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
                         ws_bytes - (size_t)(p - (char*)ws), s));
   k_class_begin<<<1, 64, 0, s>>>(cls_sorted, n_out, nclass, class_begin);
   PCC_LAUNCH_CHECK();
-  k_write_hdr<<<1, 1, 0, s>>>(plan, class_begin, 1, n_out, hdr);
+  k_write_hdr<<<1, 192, 0, s>>>(plan, class_begin, 1, n_out, hdr);
   PCC_LAUNCH_CHECK();
   dim3 gdim((unsigned)pcc_cdiv(n_out, 256), (unsigned)max_class_k(kernel_size, stride));
   k_map_transposed<<<gdim, 256, 0, s>>>(grid, in_keys, (int)n_in, out_keys, n_out, kernel_size, step, hdr, rows, nbr,
@@ -397,6 +403,8 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
 }
 
 // ---- grid index build ---------------------------------------------------------------------------------
+static int grid_rank(const unsigned long long* b, int64_t words, int32_t* rank, const int32_t* h, int tsl, int64_t* out_keys,
+                     int64_t* d_count, void* ws, size_t ws_bytes, hipStream_t s);
 __device__ inline long long grid_cell(const int64_t key, const int lo0, const int lo1, const int lo2, const int d0,
                                       const int d1, const int d2, const int tsl) {
   const int b = (int)(key >> 48);
@@ -453,10 +461,7 @@ extern "C" int pcc_grid_build(const int64_t* keys, int64_t n, const int32_t* h_g
                                                           h_grid[5], ilog2(h_grid[6]), (unsigned long long*)bits);
     PCC_LAUNCH_CHECK();
   }
-  k_grid_popc<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>((const unsigned long long*)bits, words, rank);
-  PCC_LAUNCH_CHECK();
-  PCC_TRY(pcc_scan_exclusive_i32(rank, rank, words, ws, ws_bytes, s));
-  return PCC_OK;
+  return grid_rank((const unsigned long long*)bits, words, rank, h_grid, 0, nullptr, nullptr, ws, ws_bytes, s);
 }
 
 // ---- strided coordinate set straight from the occupancy bitmap --------------------------------------------
@@ -509,6 +514,152 @@ __global__ void k_grid_enumerate(const unsigned long long* __restrict__ bits, co
   }
 }
 
+// rank (+ read-out) of a bitmap in two launches (round 3; popcount kernel + scan (2 launches) + read-out kernel before, each
+// a pass over the words of the whole bounding lattice -- 16.8 M words for the last level's candidates): the reduce pass
+// popcounts the words itself, the apply pass derives its workgroup's offset from the workgroup totals, writes rank[] and reads
+// the set bits back out of the words it already holds.  2048 words per workgroup (256 threads x 8 consecutive words).
+static constexpr int GR_B = 2048;
+static constexpr int64_t GR_DIRECT_NB = 16384;          // workgroup totals the apply pass sums up itself (as the scan does)
+
+__global__ void __launch_bounds__(256) k_grid_rank_reduce(const unsigned long long* __restrict__ bits, int64_t words,
+                                                          int* __restrict__ sums) {
+  __shared__ int wsum[4];
+  const int64_t base = (int64_t)blockIdx.x * GR_B + (int64_t)threadIdx.x * 8;
+  int c = 0;
+  if (base + 8 <= words) {
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(bits + base);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const ulonglong2 v = p[q]; c += __popcll(v.x) + __popcll(v.y); }
+  } else {
+    for (int q = 0; q < 8; ++q) if (base + q < words) c += __popcll(bits[base + q]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+template <bool ENUM>
+__global__ void __launch_bounds__(256) k_grid_rank_apply(const unsigned long long* __restrict__ bits, int64_t words,
+                                                         const int* __restrict__ sums, int* __restrict__ rank, int lo0, int lo1,
+                                                         int lo2, int d0, int d1, int d2, int tsl, int64_t* __restrict__ keys,
+                                                         int64_t* __restrict__ count) {
+  __shared__ int wsum[4];
+  __shared__ int s_off;
+  __shared__ int rk_s[ENUM ? GR_B : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // offset of this workgroup: totals of the workgroups before it
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += sums[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+  if (lane == 0) wsum[wv] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) s_off = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  const int off = s_off;
+  const int64_t base = (int64_t)blockIdx.x * GR_B + (int64_t)threadIdx.x * 8;
+  unsigned long long w[8];
+  if (base + 8 <= words) {
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(bits + base);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const ulonglong2 v = p[q]; w[2 * q] = v.x; w[2 * q + 1] = v.y; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = base + q < words ? bits[base + q] : 0ull;
+  }
+  int c = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) c += __popcll(w[q]);
+  int inc = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+  __syncthreads();
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int run = off + inc - c;
+  for (int q = 0; q < wv; ++q) run += wsum[q];
+  int r8[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { r8[q] = run; run += __popcll(w[q]); }
+  if (base + 8 <= words) {
+    reinterpret_cast<int4*>(rank + base)[0] = make_int4(r8[0], r8[1], r8[2], r8[3]);
+    reinterpret_cast<int4*>(rank + base)[1] = make_int4(r8[4], r8[5], r8[6], r8[7]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (base + q < words) rank[base + q] = r8[q];
+  }
+  if (!ENUM) return;
+  if (base <= words - 1 && words - 1 < base + 8) *count = (int64_t)run;          // the thread holding the last word: total
+  // read-out, one word per thread and trip (adjacent threads = adjacent words, so their key runs are adjacent in memory)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) rk_s[threadIdx.x * 8 + q] = r8[q];
+  __syncthreads();
+  const int total_here = (wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+  if (total_here == 0) return;                                                    // empty stretch of the lattice
+  for (int t = 0; t < 8; ++t) {
+    const int li = t * 256 + (int)threadIdx.x;
+    const int64_t wi = (int64_t)blockIdx.x * GR_B + li;
+    if (wi >= words) break;
+    unsigned long long x = bits[wi];                                              // (L1 / L2 hit: this workgroup just read it)
+    if (!x) continue;
+    int r = rk_s[li];
+    long long cell = wi * 64;
+    const int z0 = (int)(cell % d2); cell /= d2;
+    const int y0 = (int)(cell % d1); cell /= d1;
+    const int x0 = (int)(cell % d0);
+    const int b0 = (int)(cell / d0);
+    while (x) {
+      const int bit = __ffsll((long long)x) - 1;
+      x &= x - 1;
+      int cz = z0 + bit, cy = y0, cx = x0, b = b0;
+      while (cz >= d2) {
+        cz -= d2;
+        if (++cy == d1) { cy = 0; if (++cx == d0) { cx = 0; ++b; } }
+      }
+      const int64_t X = (int64_t)(lo0 + (cx << tsl)) + PCC_BIAS, Y = (int64_t)(lo1 + (cy << tsl)) + PCC_BIAS,
+                    Z = (int64_t)(lo2 + (cz << tsl)) + PCC_BIAS;
+      keys[r++] = ((int64_t)b << 48) | (X << 32) | (Y << 16) | Z;
+    }
+  }
+}
+
+static int g_grid_rank_fused = getenv("PCC_GRID_RANK_FUSED") ? atoi(getenv("PCC_GRID_RANK_FUSED")) : 1;   // 2: read-out inside the apply pass
+
+// rank[] of a marked bitmap and, with out_keys, the canonical keys of its set bits + their count.  ws: pcc_grid_ws_bytes(words).
+static int grid_rank(const unsigned long long* b, int64_t words, int32_t* rank, const int32_t* h, int tsl, int64_t* out_keys,
+                     int64_t* d_count, void* ws, size_t ws_bytes, hipStream_t s) {
+  const int64_t nb = pcc_cdiv(words, GR_B);
+  if (g_grid_rank_fused && nb <= GR_DIRECT_NB && ws_bytes >= (size_t)nb * 4 + 256 && (((uintptr_t)b | (uintptr_t)rank) & 15) == 0) {
+    int* sums = (int*)ws;
+    k_grid_rank_reduce<<<(unsigned)nb, 256, 0, s>>>(b, words, sums);
+    // (the read-out inside the apply pass -- k_grid_rank_apply<true>, 8 words per thread -- measured 2x slower than the
+    //  word-per-thread read-out kernel: 0.61 against 0.27 ms per step; the rank passes alone save the popcount kernel and
+    //  its 200 MB round trip on the large lattices)
+    if (out_keys && g_grid_rank_fused > 1) {
+      k_grid_rank_apply<true><<<(unsigned)nb, 256, 0, s>>>(b, words, sums, rank, h[0], h[1], h[2], h[3], h[4], h[5], tsl, out_keys, d_count);
+      PCC_LAUNCH_CHECK();
+      return PCC_OK;
+    }
+    k_grid_rank_apply<false><<<(unsigned)nb, 256, 0, s>>>(b, words, sums, rank, 0, 0, 0, 1, 1, 1, 0, nullptr, nullptr);
+    PCC_LAUNCH_CHECK();
+    if (out_keys) {
+      k_grid_enumerate<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, rank, words, h[0], h[1], h[2], h[3], h[4], h[5], tsl, out_keys, d_count);
+      PCC_LAUNCH_CHECK();
+    }
+    return PCC_OK;
+  }
+  k_grid_popc<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, words, rank);
+  PCC_LAUNCH_CHECK();
+  PCC_TRY(pcc_scan_exclusive_i32(rank, rank, words, ws, ws_bytes, s));
+  if (out_keys) {
+    k_grid_enumerate<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, rank, words, h[0], h[1], h[2], h[3], h[4], h[5], tsl, out_keys, d_count);
+    PCC_LAUNCH_CHECK();
+  }
+  return PCC_OK;
+}
+
 // keys: the FINE set (canonical); h_grid: lattice of the COARSE set (lo multiples of the coarse pitch h_grid[6]).
 // Outputs: bits/rank = grid index of the coarse set, out_keys (capacity n) = its canonical keys, *d_count = its size.
 extern "C" int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int64_t* d_n, const int32_t* h_grid, uint64_t* bits,
@@ -533,14 +684,7 @@ extern "C" int pcc_coords_stride_grid(const int64_t* keys, int64_t n, const int6
                                                               h_grid[4], h_grid[5], ilog2(P), (unsigned long long*)bits);
     PCC_LAUNCH_CHECK();
   }
-  k_grid_popc<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>((const unsigned long long*)bits, words, rank);
-  PCC_LAUNCH_CHECK();
-  PCC_TRY(pcc_scan_exclusive_i32(rank, rank, words, ws, ws_bytes, s));
-  k_grid_enumerate<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>((const unsigned long long*)bits, rank, words, h_grid[0],
-                                                                 h_grid[1], h_grid[2], h_grid[3], h_grid[4], h_grid[5],
-                                                                 ilog2(P), out_keys, d_count);
-  PCC_LAUNCH_CHECK();
-  return PCC_OK;
+  return grid_rank((const unsigned long long*)bits, words, rank, h_grid, ilog2(P), out_keys, d_count, ws, ws_bytes, s);
 }
 
 // ---- canonical order of user-ordered rows through the bitmap (ME.SparseTensor construction, a1) ------------------
@@ -591,14 +735,9 @@ extern "C" int pcc_keys_canonicalize_grid(const int64_t* keys, int64_t n, const 
   k_grid_bits_each<<<g, 256, 0, s>>>(keys, n, h_grid[0], h_grid[1], h_grid[2], h_grid[3], h_grid[4], h_grid[5], tsl, b,
                                      d_count + 1);
   PCC_LAUNCH_CHECK();
-  k_grid_popc<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, words, rank);
-  PCC_LAUNCH_CHECK();
-  PCC_TRY(pcc_scan_exclusive_i32(rank, rank, words, ws, ws_bytes, s));
+  PCC_TRY(grid_rank(b, words, rank, h_grid, tsl, out_keys, d_count, ws, ws_bytes, s));
   k_grid_first_user<<<g, 256, 0, s>>>(keys, n, h_grid[0], h_grid[1], h_grid[2], h_grid[3], h_grid[4], h_grid[5], tsl, b,
                                       rank, first_user);
-  PCC_LAUNCH_CHECK();
-  k_grid_enumerate<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, rank, words, h_grid[0], h_grid[1], h_grid[2],
-                                                                 h_grid[3], h_grid[4], h_grid[5], tsl, out_keys, d_count);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
@@ -749,6 +888,7 @@ __global__ void __launch_bounds__(256) k_expand_csr_count(ExpandCsrArgs a) {
     for (int i = 0; i < M * M; ++i) total += sh[i] < 64 ? __popc((unsigned)(w[i] >> (sh[i] & 63)) & fmask) : 0;
   }
   a.first[o] = total;
+  if (o == a.n_out - 1) a.first[a.n_out] = 0;         // the scan runs over n_out + 1 entries (its last output = the pair total)
 }
 
 // on_hit(i, kidx) for every existing source of row o, ascending source cell (= ascending input row)
@@ -821,13 +961,7 @@ extern "C" int pcc_coords_expand_grid(const int64_t* keys, int64_t n, int32_t ke
   else if (kernel_size == 3) k_expand_mark<3><<<g, 256, 0, s>>>(keys, n, ts_out, h_out[0], h_out[1], h_out[2], h_out[3], h_out[4], h_out[5], tsl, b);
   else k_expand_mark<5><<<g, 256, 0, s>>>(keys, n, ts_out, h_out[0], h_out[1], h_out[2], h_out[3], h_out[4], h_out[5], tsl, b);
   PCC_LAUNCH_CHECK();
-  k_grid_popc<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, words, rank);
-  PCC_LAUNCH_CHECK();
-  PCC_TRY(pcc_scan_exclusive_i32(rank, rank, words, ws, ws_bytes, s));
-  k_grid_enumerate<<<(unsigned)pcc_cdiv(words, 256), 256, 0, s>>>(b, rank, words, h_out[0], h_out[1], h_out[2], h_out[3],
-                                                                 h_out[4], h_out[5], tsl, out_keys, d_count);
-  PCC_LAUNCH_CHECK();
-  return PCC_OK;
+  return grid_rank(b, words, rank, h_out, tsl, out_keys, d_count, ws, ws_bytes, s);
 }
 
 extern "C" size_t pcc_expand_grid_csr_ws_bytes(int64_t n_out) { return pcc_scan_ws_bytes(n_out + 1) + 256; }
@@ -888,8 +1022,6 @@ static int expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kerne
   } while (0)
   // out_keys need not be the full expansion (any subset of rows, or a wider kernel restricted to a given set), so the
   // pair total is whatever the counts add up to: scan n_out + 1 entries
-  k_set_int<<<1, 1, 0, s>>>(first + n_out, 0);
-  PCC_LAUNCH_CHECK();
   PCC_TRY(pcc_scan_exclusive_i32(first, first, n_out + 1, ws, ws_bytes, s));
   PCC_EXPAND_CSR(k_expand_csr_fill);
 #undef PCC_EXPAND_CSR
@@ -919,7 +1051,7 @@ extern "C" int pcc_map_from_csr(const int32_t* first, const int32_t* pair_ids, i
   memset(&plan, 0, sizeof(plan));
   plan.K = K; plan.nseg = 1; plan.listed = 0; plan.k_count[0] = K; plan.koff_begin[0] = 0;
   plan_order(plan, kernel_size);
-  k_write_hdr<<<1, 1, 0, s>>>(plan, nullptr, 0, n_out, hdr);
+  k_write_hdr<<<1, 192, 0, s>>>(plan, nullptr, 0, n_out, hdr);
   PCC_LAUNCH_CHECK();
   PCC_CHECK_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)K * n_out * sizeof(int), s));
   k_csr_to_nbr<<<(unsigned)pcc_cdiv(n_out, 256), 256, 0, s>>>(first, pair_ids, n_out, K, nbr);

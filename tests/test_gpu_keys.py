@@ -154,3 +154,45 @@ def test_expand_matches_oracle(ks, ts_in, mode, monkeypatch):
         bits, rank, h = got.grid()
         fresh = S.CoordSet(got.keys[:got.n].clone(), got.n, got.ts, got.bounds).grid()
         assert torch.equal(bits, fresh[0]) and torch.equal(rank, fresh[1]) and list(h) == list(fresh[2])
+
+
+@pytest.mark.parametrize("rows,canonical", [(2, True), (777, False), (100_003, False), (100_003, True)])
+def test_frame_intake_matches_the_torch_chain(rows, canonical):
+    """`pcc_frame_intake` (keys, [1, r, g, b] features, bounds, order flag of a frame in one kernel) against the element-wise
+    chain it replaces (`model/model.py:141-161`): floor of negative / fractional coordinates, rows in and out of canonical
+    order, duplicates."""
+    S, L = _S()
+    rng = np.random.default_rng(rows)
+    xyz = rng.integers(-40, 900, size=(rows, 3)).astype(np.float32) + rng.random((rows, 3)).astype(np.float32) * 0.9
+    pc = np.concatenate([xyz, rng.random((rows, 3)).astype(np.float32) * 255], axis=1).astype(np.float32)
+    if canonical:
+        C = np.concatenate([np.zeros((rows, 1)), np.floor(xyz)], axis=1).astype(np.int64)
+        order = np.argsort(co.pack_keys(C), kind="stable")
+        pc = pc[order]
+        keep = np.concatenate([[True], np.diff(co.pack_keys(C)[order]) > 0])
+        pc = pc[keep]
+    keys, feats, b, flag = S.frame_intake(t(pc))
+    C = np.concatenate([np.zeros((len(pc), 1)), np.floor(pc[:, :3])], axis=1).astype(np.int64)
+    want = co.pack_keys(C)
+    assert np.array_equal(n(keys), want)
+    assert np.array_equal(n(feats), np.concatenate([np.ones((len(pc), 1), np.float32), pc[:, 3:6]], axis=1))
+    assert b.lo == tuple(C[:, 1:].min(0)) and b.hi == tuple(C[:, 1:].max(0)) and b.bmax == 0
+    assert flag == bool(np.all(np.diff(want) > 0)) == canonical
+
+
+def test_decode_finish_matches_the_torch_chain():
+    """`pcc_decode_finish` against `cat([C[:, 1:4].float(), clamp(round(255 F), 0, 255) / 255])` (`model/model.py:240-250`),
+    bit for bit: halves (round half to even), values outside [0, 1], NaN."""
+    S, L = _S()
+    keys = cloud_keys(3, 24, 0.3, 1)
+    m = len(keys)
+    rng = np.random.default_rng(5)
+    f = (rng.random((m, 3)).astype(np.float32) * 1.4 - 0.2).astype(np.float32)
+    f[:64] = (np.arange(64 * 3, dtype=np.float32).reshape(64, 3) + 0.5) / 255      # exact halves after the multiplication
+    f[64] = [np.nan, -3.0, 7.0]
+    out = torch.empty((m, 6), dtype=torch.float32, device=dev())
+    kt, ft = t(keys), t(f)                                      # (held: a temporary's memory is recycled by the next allocation)
+    L.call("pcc_decode_finish", L.ptr(kt), L.ptr(ft), m, L.ptr(out), L.stream())
+    C = t(co.unpack_keys(keys).astype(np.int32))
+    want = torch.cat([C[:, 1:4].to(torch.float32), torch.clamp(torch.round(ft * 255), 0.0, 255.0) / 255], dim=1)
+    assert np.array_equal(n(out), n(want), equal_nan=True)

@@ -70,6 +70,19 @@ class SparseTensor:
         t._C = None
         return t
 
+    @classmethod
+    def _from_frame(cls, pc, rows, feats):
+        """The tensor `SparseTensor(coordinates=[0, xyz], features=feats)` of a frame `pc` [n, 6] whose keys, bounds and
+        order flag are already known (`rows`: a `sparse.FrameRows`): same coordinate set, same row order (the caller's,
+        first duplicate wins), but `.C` is only materialised if somebody reads it (nothing on the compress path does)."""
+        cset, perm, keep = S.coordset_from_coords(rows, 1)
+        if keep is not None:
+            feats = feats[keep]
+        t = cls.__new__(cls)
+        t._cset, t._perm, t._F, t._Fc = cset, perm, feats, None
+        t._C, t._C_src = None, (pc, keep)
+        return t
+
     def _like(self, feats_canonical):
         """Same coordinates / row order, new canonical-order features (order-preserving ops)."""
         if self._perm is None:
@@ -78,6 +91,8 @@ class SparseTensor:
         user = torch.empty_like(feats_canonical)
         user[self._perm] = feats_canonical
         t._cset, t._perm, t._C, t._F, t._Fc = self._cset, self._perm, self._C, user, feats_canonical
+        if self._C is None:
+            t._C_src = getattr(self, "_C_src", None)
         return t
 
     def _canonical_features(self):
@@ -98,7 +113,16 @@ class SparseTensor:
     @property
     def C(self):
         if self._C is None:
-            self._C = self._cset.coords()
+            src = getattr(self, "_C_src", None)
+            if self._perm is not None and src is not None:      # user-ordered rows of a frame (`_from_frame`)
+                pc, keep = src
+                xyz = pc[:, :3] if keep is None else pc[keep, :3]
+                C = torch.cat([torch.zeros((xyz.shape[0], 1), dtype=torch.int32, device=xyz.device),
+                               xyz.floor().to(torch.int32)], dim=1).contiguous()
+                C._pcc_cset, C._pcc_perm = self._cset, self._perm
+                self._C = C
+            else:
+                self._C = self._cset.coords()
             self._C._pcc_version = self._C._version
         return self._C
 

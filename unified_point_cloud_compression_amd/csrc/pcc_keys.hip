@@ -738,6 +738,85 @@ extern "C" int pcc_coords_bounds(const void* coords, int32_t is_float, int64_t n
   return PCC_OK;
 }
 
+// ---- one-kernel intake of a frame and one-kernel hand-over of a decoded block ----------------------------------------------
+// `UnifiedModel.compress` turns the [n, 6] frame (x y z r g b) into coordinates [0, x, y, z] and features [1, r, g, b]
+// (reference `model/model.py:141-161`); the constructor of its sparse tensor then needs the bounds of the floored coordinates
+// and whether the rows already are in canonical order.  Ten element-wise launches (zeros, two concatenations, a cast, the key
+// packing, two fills, the bounds, the order check) in the host-bound opening of a step: one pass here.
+// out12: [0..3] min (b, x, y, z), [4..7] MINUS max (so that one 0x7F fill initialises all of it), [8] != 0: canonical order.
+__global__ void __launch_bounds__(256) k_frame_intake(const float* __restrict__ pc, long long n, long long* __restrict__ keys,
+                                                      float4* __restrict__ feats, int* __restrict__ out12) {
+  __shared__ int s_min[3], s_nmax[3];
+  if (threadIdx.x < 3) { s_min[threadIdx.x] = 0x7FFFFFFF; s_nmax[threadIdx.x] = 0x7FFFFFFF; }
+  __syncthreads();
+  int mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, nmx[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float2* r = reinterpret_cast<const float2*>(pc + i * 6);
+    const float2 a = r[0], b = r[1], c = r[2];                       // x y | z r | g b
+    const int x = (int)floorf(a.x), y = (int)floorf(a.y), z = (int)floorf(b.x);
+    const long long k = pack4(0, x, y, z);
+    keys[i] = k;
+    feats[i] = make_float4(1.f, b.y, c.x, c.y);
+    mn[0] = min(mn[0], x); mn[1] = min(mn[1], y); mn[2] = min(mn[2], z);
+    nmx[0] = min(nmx[0], -x); nmx[1] = min(nmx[1], -y); nmx[2] = min(nmx[2], -z);
+    if (i > 0) {
+      const float* q = pc + (i - 1) * 6;
+      bad |= k <= pack4(0, (int)floorf(q[0]), (int)floorf(q[1]), (int)floorf(q[2]));
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    for (int d = 32; d >= 1; d >>= 1) { mn[c] = min(mn[c], __shfl_xor(mn[c], d)); nmx[c] = min(nmx[c], __shfl_xor(nmx[c], d)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&s_min[c], mn[c]); atomicMin(&s_nmax[c], nmx[c]); }
+  }
+  if (bad) out12[8] = 0;                                              // benign race: every writer stores 0
+  __syncthreads();
+  if (threadIdx.x < 3) { atomicMin(&out12[1 + threadIdx.x], s_min[threadIdx.x]); atomicMin(&out12[5 + threadIdx.x], s_nmax[threadIdx.x]); }
+}
+
+extern "C" int pcc_frame_intake(const float* pc, int64_t n, int64_t* keys, float* feats, int32_t* out12, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(pc && keys && feats && out12 && n >= 1, "pcc_frame_intake: bad arguments");
+  PCC_REQUIRE((((uintptr_t)pc & 7) | ((uintptr_t)feats & 15)) == 0, "pcc_frame_intake: the frame must be 8-byte, the features 16-byte aligned");
+  PCC_CHECK_HIP(hipMemsetAsync(out12, 0x7F, 12 * sizeof(int), s));
+  const unsigned g = (unsigned)(pcc_cdiv(n, 256) < 512 ? pcc_cdiv(n, 256) : 512);     // 6 same-line atomics per workgroup
+  k_frame_intake<<<g, 256, 0, s>>>(pc, n, (long long*)keys, (float4*)feats, out12);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// `UnifiedModel.decompress` returns [x, y, z, clamp(round(255 f), 0, 255) / 255] (reference `model/model.py:240-250`): the
+// coordinates straight from the keys of the decoded set, the colours in the same fp32 operations as the torch chain
+// (round half to even; NaN stays NaN), one launch instead of nine.
+__global__ void __launch_bounds__(256) k_decode_finish(const long long* __restrict__ keys, const float* __restrict__ f, long long n,
+                                                       float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long k = keys[i];
+  float v[6];
+  v[0] = (float)((int)((k >> 32) & 0xFFFF) - (int)PCC_BIAS);
+  v[1] = (float)((int)((k >> 16) & 0xFFFF) - (int)PCC_BIAS);
+  v[2] = (float)((int)(k & 0xFFFF) - (int)PCC_BIAS);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float t = rintf(f[i * 3 + c] * 255.0f);
+    t = t < 0.0f ? 0.0f : t;
+    t = t > 255.0f ? 255.0f : t;
+    v[3 + c] = t * (1.0f / 255.0f);                     // (torch divides by a host scalar as a multiplication by its fp32 reciprocal)
+  }
+  float2* o = reinterpret_cast<float2*>(out + i * 6);
+  o[0] = make_float2(v[0], v[1]); o[1] = make_float2(v[2], v[3]); o[2] = make_float2(v[4], v[5]);
+}
+
+extern "C" int pcc_decode_finish(const int64_t* keys, const float* feats3, int64_t n, float* out6, void* stream) {
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(keys && feats3 && out6 && ((uintptr_t)out6 & 7) == 0, "pcc_decode_finish: bad arguments");
+  k_decode_finish<<<grid1(n), 256, 0, (hipStream_t)stream>>>((const long long*)keys, feats3, n, out6);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
 __global__ void __launch_bounds__(256) k_rows_gather(const float* __restrict__ src, const long long* __restrict__ idx, long long m,
                                                      int c, float* __restrict__ dst) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -230,12 +230,25 @@ class MeanScaleHyperprior(CompressionModel):
         main = torch.cuda.current_stream(device)
         side = L.side_stream(device)
         with torch.cuda.stream(side):
-            y_up = self.gaussian_conditional.upload_string(y_string, device)
             z_sym = eb.decompress_rows(z_string, int(shape[0]), eb.channels, device=device, check=check, status=status)
             ev = side.record_event()
-        for t in (y_up.device_buf, z_sym):          # allocated under the side stream, consumed on the main one
-            t.record_stream(main)
-        return z_sym, y_up, ev
+        z_sym.record_stream(main)                   # allocated under the side stream, consumed on the main one
+        return z_sym, None, ev
+
+    def predecode_upload(self, pre, symbols, device):
+        """Second half of `predecode`, called once the decoder's coordinate work is queued: y's string goes to the device on
+        the side stream (a pageable copy of ~1 MB keeps the host for ~0.1 ms -- time the main stream now spends on the
+        coordinate sets while the side stream decodes the hyper-latent)."""
+        if pre is None:
+            return None
+        z_sym, _, ev = pre
+        main = torch.cuda.current_stream(device)
+        side = L.side_stream(device)
+        with torch.cuda.stream(side):
+            y_up = self.gaussian_conditional.upload_string(symbols[0][0], device)
+            ev2 = side.record_event()
+        y_up.device_buf.record_stream(main)
+        return z_sym, y_up, (ev, ev2)
 
     def decompress(self, points, symbols, shape, q, check=None, pre=None):
         """points = [y CoordSet, z CoordSet]; symbols = strings [[y_string], [z_string]] (or the symbol tensors with
@@ -244,14 +257,18 @@ class MeanScaleHyperprior(CompressionModel):
         assert isinstance(points, list) and len(points) == 2
         y_cset, z_cset = points
         dev = y_cset.device
+        y_ready = None
         c_y = self.gaussian_conditional_channels()
         if self.entropy_coder == "symbols":
             y_sym, z_sym = symbols
         else:
             (y_string,), (z_string,) = symbols
             if pre is not None:
-                z_sym, y_string, ev = pre
-                torch.cuda.current_stream(dev).wait_event(ev)
+                z_sym, y_up, evs = pre
+                evs = evs if isinstance(evs, tuple) else (evs,)
+                torch.cuda.current_stream(dev).wait_event(evs[0])                 # the hyper-latent's symbols
+                if y_up is not None:
+                    y_string, y_ready = y_up, evs[1]
             else:
                 z_sym = self.entropy_bottleneck.decompress_rows(z_string, z_cset.n, self.entropy_bottleneck.channels,
                                                                 device=dev, check=check)
@@ -262,6 +279,8 @@ class MeanScaleHyperprior(CompressionModel):
         scale, rescale = self._gains(q, y_cset, c_y)
         if y_sym is None:
             idx = self.gaussian_conditional.index_rows(params, y_cset.keys, scale)
+            if y_ready is not None:
+                torch.cuda.current_stream(dev).wait_event(y_ready)               # y's string is on the device
             y_sym = self.gaussian_conditional.decompress_rows(y_string, y_cset.n, c_y, idx, check=check)
         if self.quantization_offset:
             c = y_sym.shape[1]

@@ -59,12 +59,15 @@ class UnifiedModel(CompressionModel):
     def stride_chain(self):
         """Tensor strides of the sets the encoder derives from the input one after the other (g_a's three stride-2
         convolutions, then h_a's two): the input set's constructor builds them all in its own batch of launches."""
-        chain, ts = [], 1
-        for m in list(self.g_a.modules()) + list(self.entropy_model.h_a.modules()):
-            if getattr(m, "stride", 1) != 1 and hasattr(m, "kernel_size"):
-                ts *= m.stride
-                chain.append(ts)
-        return tuple(chain)
+        chain = self.__dict__.get("_stride_chain")          # (the module tree does not change after construction)
+        if chain is None:
+            chain, ts = [], 1
+            for m in list(self.g_a.modules()) + list(self.entropy_model.h_a.modules()):
+                if getattr(m, "stride", 1) != 1 and hasattr(m, "kernel_size"):
+                    ts *= m.stride
+                    chain.append(ts)
+            chain = self.__dict__["_stride_chain"] = tuple(chain)
+        return chain
 
     def block_input(self, x_block, coords=None):
         """floor -> int32, de-duplicate (first wins), features [1, r, g, b] (`model/model.py:141-161`)."""
@@ -94,7 +97,11 @@ class UnifiedModel(CompressionModel):
     def compress_block(self, x_block, q, coords=None):
         """One block through g_a and the entropy model: (strings, shape, k, latent coordinates) -- the body of the block loop
         of `compress` (`model/model.py:137-176`)."""
-        x = self.block_input(x_block, coords=coords)
+        if isinstance(coords, tuple):                       # (FrameRows, features): the frame went through `frame_intake`
+            coords[0]._pcc_chain = self.stride_chain()
+            x = SparseTensor._from_frame(x_block, coords[0], coords[1])
+        else:
+            x = self.block_input(x_block, coords=coords)
         y, k = self.g_a(x)
         _, symbols, shape = self.entropy_model.compress(y, q)
         return symbols, shape, k, y.C
@@ -141,7 +148,13 @@ class UnifiedModel(CompressionModel):
         # reductions and its host read are skipped and the read below also serves the SparseTensor constructor.
         single = None
         n_pts = pointcloud.shape[0]
-        if n_pts > 1:
+        if n_pts > 1 and pointcloud.dtype == torch.float32 and pointcloud.dim() == 2 and pointcloud.shape[1] == 6 \
+                and pointcloud.is_contiguous() and pointcloud.data_ptr() % 8 == 0:
+            # keys, features [1, r, g, b], bounds and order flag in one kernel + one read (`pcc_frame_intake`)
+            keys, feats, b, canonical = S.frame_intake(pointcloud)
+            if max(b.hi[i] - b.lo[i] for i in range(3)) < block_size:
+                single = (S.FrameRows(n_pts, pointcloud.device, (keys, b, canonical)), feats)
+        elif n_pts > 1:
             c4 = torch.cat([torch.zeros((n_pts, 1), device=pointcloud.device, dtype=pointcloud.dtype), pointcloud[:, :3]], dim=1)
             keys = S.pack_keys(c4)
             b, canonical = S.bounds_of(c4, canon_keys=keys)
@@ -187,7 +200,7 @@ class UnifiedModel(CompressionModel):
                 c = c.to(device)
                 coordinates[i] = torch.cat([torch.zeros((c.shape[0], 1), dtype=c.dtype, device=device), c], dim=1)
                 q_vals[i] = q_vals[i].to(device)
-        feats, coords, status = [], [], []
+        feats, coords, status, blocks = [], [], [], []
         for i, (block_symbols, block_shape, block_coords, block_k) in enumerate(zip(strings, shape, coordinates, k)):
             pre = self.entropy_model.predecode(block_symbols, block_shape, device, check=status)
             y_cset = getattr(block_coords, "_pcc_cset", None)
@@ -207,10 +220,19 @@ class UnifiedModel(CompressionModel):
                 z_cset = S.resolve(y_cset.stride_begin(ts_z), *self.g_s.plan(y_cset))[0]
             if z_cset.n != int(block_shape[0]):
                 raise L.PccError(f"bitstream says {int(block_shape[0])} hyper-latent rows, the coordinates give {z_cset.n}")
+            pre = self.entropy_model.predecode_upload(pre, block_symbols, device)
             y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i], check=status, pre=pre)
             x_hat = self.g_s(y_hat, k=block_k, trace=trace, probe=probe)
-            feats.append(x_hat.F)
-            coords.append(x_hat.C)
+            blocks.append(x_hat)
+        out = None
+        if blocks and all(x._perm is None and x.F.dim() == 2 and x.F.shape[1] == 3 and x.F.is_contiguous()
+                          and x.F.dtype == torch.float32 for x in blocks):
+            # [x, y, z, clamp(round(255 f), 0, 255) / 255] in one launch per block
+            out = torch.empty((sum(x._cset.n for x in blocks), 6), dtype=torch.float32, device=device)
+            at = 0
+            for x in blocks:
+                L.call("pcc_decode_finish", L.ptr(x._cset.keys), L.ptr(x.F), x._cset.n, out.data_ptr() + at * 24, L.stream())
+                at += x._cset.n
         guard = L.h_guard(device)
         flags = torch.cat([s.reshape(-1)[:1].to(torch.int32) for s in status] + [guard]).tolist()   # one deferred read: rANS containers + range guard
         if any(flags[:-1]):
@@ -218,6 +240,11 @@ class UnifiedModel(CompressionModel):
         if flags[-1]:
             guard.zero_()
             raise L.RangeGuardTripped()
+        if out is not None:
+            return out
+        for x in blocks:
+            feats.append(x.F)
+            coords.append(x.C)
         f = torch.cat(feats, dim=0)
         c = torch.cat(coords, dim=0)
         f = torch.clamp(torch.round(f * 255), 0.0, 255.0) / 255

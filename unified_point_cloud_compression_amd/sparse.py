@@ -519,6 +519,29 @@ def bounds_of(coords, canon_keys=None):
     return b if canon_keys is None else (b, bool(v[8]))
 
 
+class FrameRows:
+    """Stand-in for the [n, 4] coordinate tensor of a frame whose keys / bounds / order flag `frame_intake` already
+    produced: what `coordset_from_coords` reads of its argument (row count, device, the hint, the stride chain)."""
+
+    def __init__(self, n, device, hint, chain=None):
+        self.shape = (n, 4)
+        self.device = device
+        self._pcc_hint = hint
+        self._pcc_chain = chain
+
+
+def frame_intake(pc):
+    """[n, 6] fp32 frame (x y z r g b) -> (keys int64 [n] of (0, floor xyz), features [n, 4] = (1, r, g, b), Bounds,
+    canonical?) with one kernel and one host read (`pcc_frame_intake`; reference `model/model.py:141-161`)."""
+    n = pc.shape[0]
+    keys = torch.empty(n, dtype=torch.int64, device=pc.device)
+    feats = torch.empty((n, 4), dtype=torch.float32, device=pc.device)
+    out = torch.empty(12, dtype=torch.int32, device=pc.device)
+    L.call("pcc_frame_intake", L.ptr(pc), n, L.ptr(keys), L.ptr(feats), L.ptr(out), L.stream())
+    v = out.tolist()                                      # one device->host read
+    return keys, feats, Bounds(0, v[1:4], [-x for x in v[5:8]]), bool(v[8])
+
+
 def coordset_from_coords(coords, tensor_stride, stride_chain=None):
     """Canonicalise user coordinates.  Returns (CoordSet, perm, keep):
     perm  None when the rows already are in canonical order, else int64 [n] with

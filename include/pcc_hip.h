@@ -331,10 +331,13 @@ int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* packed, const
  * Frame intake and hand-over of UnifiedModel.compress / decompress (model/model.py:141-161, 240-250), one launch each.
  * pcc_frame_intake: pc [n,6] fp32 rows (x y z r g b) -> keys of (0, floor x, floor y, floor z), features [n,4] = (1, r, g, b),
  *   out12 (device int32[12]): [1..3] min of the floored coordinates, [5..7] MINUS their max, [8] != 0: rows already in
- *   canonical (strictly ascending key) order; the other words are scratch.
+ *   canonical (strictly ascending key) order; the other words are not written.  ws: pcc_frame_intake_ws_bytes() (per-workgroup
+ *   partial results; no global atomics).
  * pcc_decode_finish: keys [n] + colour features [n,3] -> out [n,6] = (x, y, z, clamp(round(255 f), 0, 255) / 255).
  * ---------------------------------------------------------------------------------------- */
-int pcc_frame_intake(const float* pc, int64_t n, int64_t* keys, float* feats, int32_t* out12, void* stream);
+size_t pcc_frame_intake_ws_bytes(void);
+int pcc_frame_intake(const float* pc, int64_t n, int64_t* keys, float* feats, int32_t* out12, void* ws, size_t ws_bytes,
+                     void* stream);
 int pcc_decode_finish(const int64_t* keys, const float* feats3, int64_t n, float* out6, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -745,12 +745,10 @@ extern "C" int pcc_coords_bounds(const void* coords, int32_t is_float, int64_t n
 // packing, two fills, the bounds, the order check) in the host-bound opening of a step: one pass here.
 // out12: [0..3] min (b, x, y, z), [4..7] MINUS max (so that one 0x7F fill initialises all of it), [8] != 0: canonical order.
 __global__ void __launch_bounds__(256) k_frame_intake(const float* __restrict__ pc, long long n, long long* __restrict__ keys,
-                                                      float4* __restrict__ feats, int* __restrict__ out12) {
-  __shared__ int s_min[3], s_nmax[3];
-  if (threadIdx.x < 3) { s_min[threadIdx.x] = 0x7FFFFFFF; s_nmax[threadIdx.x] = 0x7FFFFFFF; }
-  __syncthreads();
+                                                      float4* __restrict__ feats, int* __restrict__ part) {
+  __shared__ int s_red[4][8];
   int mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, nmx[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
-  bool bad = false;
+  int ok = 1;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float2* r = reinterpret_cast<const float2*>(pc + i * 6);
     const float2 a = r[0], b = r[1], c = r[2];                       // x y | z r | g b
@@ -762,26 +760,56 @@ __global__ void __launch_bounds__(256) k_frame_intake(const float* __restrict__ 
     nmx[0] = min(nmx[0], -x); nmx[1] = min(nmx[1], -y); nmx[2] = min(nmx[2], -z);
     if (i > 0) {
       const float* q = pc + (i - 1) * 6;
-      bad |= k <= pack4(0, (int)floorf(q[0]), (int)floorf(q[1]), (int)floorf(q[2]));
+      if (k <= pack4(0, (int)floorf(q[0]), (int)floorf(q[1]), (int)floorf(q[2]))) ok = 0;
     }
   }
+  // one partial row per workgroup (no global atomics: 3 000 same-line atomics of the first version cost 60 us), reduced
+  // by k_frame_intake_reduce
+  int v[7] = {mn[0], mn[1], mn[2], nmx[0], nmx[1], nmx[2], ok};
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    for (int d = 32; d >= 1; d >>= 1) { mn[c] = min(mn[c], __shfl_xor(mn[c], d)); nmx[c] = min(nmx[c], __shfl_xor(nmx[c], d)); }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&s_min[c], mn[c]); atomicMin(&s_nmax[c], nmx[c]); }
+  for (int c = 0; c < 7; ++c) {
+    for (int d = 32; d >= 1; d >>= 1) v[c] = min(v[c], __shfl_xor(v[c], d));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][c] = v[c];
   }
-  if (bad) out12[8] = 0;                                              // benign race: every writer stores 0
   __syncthreads();
-  if (threadIdx.x < 3) { atomicMin(&out12[1 + threadIdx.x], s_min[threadIdx.x]); atomicMin(&out12[5 + threadIdx.x], s_nmax[threadIdx.x]); }
+  if (threadIdx.x < 7) {
+    const int c = threadIdx.x;
+    part[blockIdx.x * 8 + c] = min(min(s_red[0][c], s_red[1][c]), min(s_red[2][c], s_red[3][c]));
+  }
 }
 
-extern "C" int pcc_frame_intake(const float* pc, int64_t n, int64_t* keys, float* feats, int32_t* out12, void* stream) {
+__global__ void __launch_bounds__(256) k_frame_intake_reduce(const int* __restrict__ part, int nblk, int* __restrict__ out12) {
+  __shared__ int s_red[4][8];
+  int v[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) v[c] = 0x7FFFFFFF;
+  for (int b = threadIdx.x; b < nblk; b += 256)
+#pragma unroll
+    for (int c = 0; c < 7; ++c) v[c] = min(v[c], part[b * 8 + c]);
+#pragma unroll
+  for (int c = 0; c < 7; ++c) {
+    for (int d = 32; d >= 1; d >>= 1) v[c] = min(v[c], __shfl_xor(v[c], d));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][c] = v[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int c = threadIdx.x;
+    const int r = min(min(s_red[0][c], s_red[1][c]), min(s_red[2][c], s_red[3][c]));
+    out12[c < 3 ? 1 + c : (c < 6 ? 5 + (c - 3) : 8)] = r;
+  }
+}
+
+extern "C" size_t pcc_frame_intake_ws_bytes(void) { return (size_t)1024 * 8 * sizeof(int); }
+
+extern "C" int pcc_frame_intake(const float* pc, int64_t n, int64_t* keys, float* feats, int32_t* out12, void* ws, size_t ws_bytes,
+                                void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  PCC_REQUIRE(pc && keys && feats && out12 && n >= 1, "pcc_frame_intake: bad arguments");
+  PCC_REQUIRE(pc && keys && feats && out12 && ws && n >= 1, "pcc_frame_intake: bad arguments");
   PCC_REQUIRE((((uintptr_t)pc & 7) | ((uintptr_t)feats & 15)) == 0, "pcc_frame_intake: the frame must be 8-byte, the features 16-byte aligned");
-  PCC_CHECK_HIP(hipMemsetAsync(out12, 0x7F, 12 * sizeof(int), s));
-  const unsigned g = (unsigned)(pcc_cdiv(n, 256) < 512 ? pcc_cdiv(n, 256) : 512);     // 6 same-line atomics per workgroup
-  k_frame_intake<<<g, 256, 0, s>>>(pc, n, (long long*)keys, (float4*)feats, out12);
+  if (ws_bytes < pcc_frame_intake_ws_bytes()) { pcc_set_error("pcc_frame_intake: workspace too small"); return PCC_EWS; }
+  const unsigned g = (unsigned)(pcc_cdiv(n, 256) < 1024 ? pcc_cdiv(n, 256) : 1024);
+  k_frame_intake<<<g, 256, 0, s>>>(pc, n, (long long*)keys, (float4*)feats, (int*)ws);
+  k_frame_intake_reduce<<<1, 256, 0, s>>>((const int*)ws, (int)g, out12);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

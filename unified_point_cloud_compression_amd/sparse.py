@@ -537,7 +537,8 @@ def frame_intake(pc):
     keys = torch.empty(n, dtype=torch.int64, device=pc.device)
     feats = torch.empty((n, 4), dtype=torch.float32, device=pc.device)
     out = torch.empty(12, dtype=torch.int32, device=pc.device)
-    L.call("pcc_frame_intake", L.ptr(pc), n, L.ptr(keys), L.ptr(feats), L.ptr(out), L.stream())
+    ws = L.workspace(L.load().pcc_frame_intake_ws_bytes(), pc.device)
+    L.call("pcc_frame_intake", L.ptr(pc), n, L.ptr(keys), L.ptr(feats), L.ptr(out), L.ptr(ws), ws.numel(), L.stream())
     v = out.tolist()                                      # one device->host read
     return keys, feats, Bounds(0, v[1:4], [-x for x in v[5:8]]), bool(v[8])
 

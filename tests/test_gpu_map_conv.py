@@ -235,6 +235,27 @@ def test_gdn(c, inverse):
     assert_close(n(got), ops.gdn(x, beta, gamma, inverse), what="gdn")
 
 
+@pytest.mark.parametrize("rows,c,inverse", [(40_003, 128, False), (140_001, 128, True), (33_000, 192, True)])
+def test_gdn_large_sets_take_the_fused_kernel(rows, c, inverse):
+    """From 32 k rows on `pcc_gdn_fwd` runs `k_gdn_bf` (|x| split into bf16 planes while staging, no plane round trip):
+    against the oracle, and bit for bit against the general kernel -- a row's result does not depend on how many rows the
+    call has, so the first rows of the large call must equal a small call's (which takes the general kernel)."""
+    from unified_point_cloud_compression_amd.model.blocks import MinkowskiGDN
+    rng = np.random.default_rng(rows)
+    x = (rng.standard_normal((rows, c)) * np.exp(rng.uniform(-3, 3, (rows, 1)))).astype(np.float32)
+    g = MinkowskiGDN(c, inverse=inverse).to(dev()).eval()
+    beta = (np.sqrt(1 + ops.PEDESTAL) + rng.uniform(0, 0.3, c)).astype(np.float32)
+    gamma = (np.sqrt(0.1 * np.eye(c) + ops.PEDESTAL) + rng.uniform(-0.01, 0.05, (c, c))).astype(np.float32)
+    with torch.no_grad():
+        g.beta.copy_(t(beta)); g.gamma.copy_(t(gamma))
+        xt = t(x)
+        got = g.forward_rows(xt)
+        small = g.forward_rows(xt[:1500].contiguous())
+        tail = g.forward_rows(xt[rows - 1111:].contiguous())
+    assert_close(n(got)[::7], ops.gdn(x[::7], beta, gamma, inverse), what="gdn, fused kernel")
+    assert torch.equal(got[:1500], small) and torch.equal(got[rows - 1111:], tail)
+
+
 def test_weight_offset_order_hook():
     """`sparse.WEIGHT_OFFSET_ORDER = "z_fastest"` re-indexes checkpoint weights while packing (the SURVEY A.3 hedge):
     a module fed the z-fastest enumeration of the same kernel gives the same output, in inference and under autograd."""

@@ -1065,6 +1065,133 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
   }
 }
 
+// GDN / IGDN with the split folded into the staging (round 3): out = x / (beta + |x| gamma^T)  (or x * (...)).  The general
+// kernel above reads bf16 planes that a k_feat_split pass wrote first -- for this K = C, one-row-per-row product that pass and
+// the planes' round trip are more HBM traffic than the operation itself (205 k x 128 rows: 50 us split + 170 us product for
+// 205 MB of algorithmic traffic).  Here a thread loads the fp32 rows, takes |x| and splits in registers (the same bf_split2,
+// so planes, term order and chunk order are those of k_conv_mfma_bf: bit-identical results) and writes the LDS image itself.
+// TM = 2: 128-row tiles, TM = 1: 64-row tiles (more workgroups for the mid-sized sets).
+template <int TM, int MODE>
+__global__ void __launch_bounds__(256, 3) k_gdn_bf(ConvArgs a) {
+  static_assert(MODE == MODE_GDN || MODE == MODE_IGDN, "GDN modes only");
+  constexpr int WM = 2, WN = 2, TN = 2;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDU = 13;
+  __shared__ __attribute__((aligned(16))) uint4 As[BM * LDU];
+  __shared__ __attribute__((aligned(16))) uint4 Bs[BN * LDU];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cpx = gridDim.x >> 3;
+  const int wid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  const int gy = a.cout_pad / BN;
+  const int tile_id = wid / gy;
+  const int colblock = (wid - tile_id * gy) * BN;
+  const long long p0 = (long long)tile_id * BM;
+  if (p0 >= a.n_out) return;
+  const int pos0 = (int)p0;
+  const int npos = (int)min((long long)BM, a.n_out - p0);
+  const int nchunks = a.ppo;                                          // 32 channels per chunk
+
+  constexpr int NX = BM * 8 / 256, NB = (BN * 12 + 255) / 256;      // float4 of x / 16-byte weight units per thread and chunk
+  int x_row[NX], x_j[NX], b_row[NB], b_w[NB];
+#pragma unroll
+  for (int q = 0; q < NX; ++q) { const int u = q * 256 + tid; x_row[q] = u >> 3; x_j[q] = u & 7; }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) { const int u = q * 256 + tid; b_row[q] = u / 12; b_w[q] = u - b_row[q] * 12; if (u >= BN * 12) b_row[q] = -1; }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int wm = w / WN, wn = w % WN;
+  const int half = lane >> 5, r31 = lane & 31;
+
+  const float* wb = a.wp + a.wp_elems;                                // bf16 planes behind the fp32 image
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wb), (short)0, (int)(unsigned)((size_t)bf_plane_elems(a.wp_elems) * 4), 0x00020000);
+  const float* const xt = a.feat + (size_t)pos0 * a.cin;
+
+  float4 xv[NX];
+  uint4 bv[NB];
+  auto issue = [&](int cbi) {
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+      const int rc = min(x_row[q], npos - 1);                         // tail rows repeat the tile's last row (never stored)
+      xv[q] = *reinterpret_cast<const float4*>(xt + (size_t)rc * a.cin + cbi * 32 + x_j[q] * 4);
+    }
+    const unsigned wbase = (unsigned)(cbi * a.cout_pad + colblock) * 192u;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const unsigned off = b_row[q] >= 0 ? wbase + (unsigned)(q * 256 + tid) * 16u : BUF_OOB;
+      bv[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+    }
+  };
+  issue(0);
+  unsigned long long* const As64 = reinterpret_cast<unsigned long long*>(As);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      bf_split2(fabsf(xv[q].x), fabsf(xv[q].y), h0, m0, l0);
+      bf_split2(fabsf(xv[q].z), fabsf(xv[q].w), h1, m1, l1);
+      const int o = x_row[q] * (LDU * 2) + x_j[q];                    // 8-byte slots: plane p of the row starts at slot 8 p
+      As64[o] = (unsigned long long)h0 | ((unsigned long long)h1 << 32);
+      As64[o + 8] = (unsigned long long)m0 | ((unsigned long long)m1 << 32);
+      As64[o + 16] = (unsigned long long)l0 | ((unsigned long long)l1 << 32);
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      if (b_row[q] >= 0) Bs[b_row[q] * LDU + b_w[q]] = bv[q];
+    __syncthreads();
+    if (c + 1 < nchunks) issue(c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[p][i] = __builtin_bit_cast(bf16x8, As[((wm * TM + i) * 32 + r31) * LDU + p * 4 + ks * 2 + half]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bf[p][j] = __builtin_bit_cast(bf16x8, Bs[((wn * TN + j) * 32 + r31) * LDU + p * 4 + ks * 2 + half]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {           // smallest terms first (the order of k_conv_mfma_bf)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // ---- epilogue: out = x / (beta + acc)  or  x * (beta + acc) --------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = colblock + (wn * TN + j) * 32 + r31;
+    if (col >= a.cout) continue;
+    const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (r >= npos) continue;
+        const size_t o = (size_t)(pos0 + r) * a.cout + col;
+        const float v = acc[i][j][e] + b;
+        const float x = a.feat[o];
+        a.out[o] = (MODE == MODE_GDN) ? x / v : x * v;
+      }
+  }
+}
+
 // (Round 3, tools/gemm_h2_probe.py + PCC_DBG on the level-2 composite shape 58 051 x 128 x 21 952, and tools/write_probe.hip:
 //  the chip stores this 5.1 GB buffer in 0.90 ms at best (5.65 TB/s, this kernel's own store pattern, any occupancy); this
 //  kernel takes 1.68-1.78 = LDS skeleton 0.38 + loads 0.05 + MFMA 0.27 + stores 0.56 measured one at a time, but loads + stores
@@ -3870,6 +3997,22 @@ extern "C" int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* pa
   a.n_out = n; a.cin = c; a.cout = c; a.cout_pad = cout_pad_for(c);
   a.n_in = n; a.wp_elems = (long long)c * a.cout_pad;
   a.cb_log2 = cb_log2_for(c); a.ppo = c >> a.cb_log2; a.act = 0; a.slope = 0.f;
+  // large sets: split folded into the staging (k_gdn_bf), no plane round trip; small ones keep the general kernel (its
+  // smaller row tiles fill the chip better below ~30 k rows)
+  static const bool fused = getenv("PCC_GDN_FUSED") ? atoi(getenv("PCC_GDN_FUSED")) != 0 : true;
+  if (fused && split_ok(a) && c % 32 == 0 && (c & 3) == 0 && ((uintptr_t)x & 15) == 0 && n >= 32768) {
+    const int bn = bn_for(c);
+    if (bn == 128) {
+      const long long gy = a.cout_pad / 128;
+      const bool big = pcc_cdiv(n, 128) * gy >= 1024;
+      const long long tiles = pcc_cdiv(n, big ? 128 : 64);
+      const unsigned grid = (unsigned)((tiles * gy + 7) / 8 * 8);
+      if (big) { if (inverse) k_gdn_bf<2, MODE_IGDN><<<grid, 256, 0, s>>>(a); else k_gdn_bf<2, MODE_GDN><<<grid, 256, 0, s>>>(a); }
+      else { if (inverse) k_gdn_bf<1, MODE_IGDN><<<grid, 256, 0, s>>>(a); else k_gdn_bf<1, MODE_GDN><<<grid, 256, 0, s>>>(a); }
+      PCC_LAUNCH_CHECK();
+      return PCC_OK;
+    }
+  }
   if (inverse) return launch_mfma<MODE_IGDN>(a, 0, s);
   return launch_mfma<MODE_GDN>(a, 0, s);
 }

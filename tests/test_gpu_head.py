@@ -134,10 +134,11 @@ def test_thin_conv_from_grid_matches_oracle(ts, shift, cin, cout):
     assert torch.equal(got, again)
 
 
-@pytest.mark.parametrize("ts_in,shift", [(2, 0), (4, -3)])
-def test_composite_gather_presence_from_grid_equals_table_path(ts_in, shift):
+@pytest.mark.parametrize("ts_in,shift,cin,cout", [(2, 0, 16, 8), (4, -3, 16, 8), (2, -3, 32, 16), (4, 0, 32, 64), (2, 0, 32, 32)])
+def test_composite_gather_presence_from_grid_equals_table_path(ts_in, shift, cin, cout):
     """`pcc_convt_fwd_csr_grid` == `pcc_convt_fwd_csr` with the 3x3x3 neighbour table, bit for bit (same pair order, same
-    presence flags), on a two-batch input."""
+    presence flags), on a two-batch input.  8 channels: two lanes per row (loop form of the presence probe); 16 / 32 / 64:
+    4 / 8 / 16 lanes per row (branch-free windows, 3 / 2 / 1 columns per lane)."""
     from unified_point_cloud_compression_amd import sparse as S, lib as L
     import unified_point_cloud_compression_amd.MinkowskiEngine as ME
     rng = np.random.default_rng(ts_in)
@@ -148,7 +149,6 @@ def test_composite_gather_presence_from_grid_equals_table_path(ts_in, shift):
     out_set = cs.expand(5, ts_out, want_csr=False)
     assert out_set.grid() is not None
     csr7 = cs.csr_for(out_set.keys, out_set.n, 7, ts_out)
-    cin, cout = 16, 8
     x = t(rng.standard_normal((len(keys), cin)).astype(np.float32))
     gen = ME.MinkowskiGenerativeConvolutionTranspose(cin, cout, kernel_size=7, stride=2, bias=True, dimension=3).to(dev())
     ex_bias = t(rng.standard_normal((27, cout)).astype(np.float32))

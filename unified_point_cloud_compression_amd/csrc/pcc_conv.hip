@@ -3457,10 +3457,47 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
   // flags side by side and share them by ballot (one load per lane instead of ex_K dependent loads: the serial loop cost
   // 2.1 ms on the level-2 head in round 2)
   unsigned long long present = 0;
-  if (a.ex_grid.bits) {            // 3x3x3 presence straight from the output set's bitmap: the columns are dealt over the group's lanes
-    unsigned m = pcc_grid_nbr27(a.ex_grid, a.out_keys[o], cl, lpr < 9 ? lpr : 9, nullptr);
+  // 3x3x3 presence straight from the output set's bitmap, the nine (dx, dy) columns dealt over the row's lanes.  Branch-free
+  // (round 3): a lane's <= 3 columns are 64-bit windows that start at the 32-bit word of the column's first cell (the 3-bit z
+  // field never straddles), absent columns re-read cell 0 and are masked -- all of a lane's loads are in flight together and
+  // are consumed after the pair loop below.  (The loop form waited for each column's word in turn: three exposed L2 latencies
+  // per row on the last level, where a row has four lanes.)
+  unsigned pw_lo[3] = {0, 0, 0}, pw_hi[3] = {0, 0, 0};
+  int psh[3] = {64, 64, 64}, pcol[3] = {0, 0, 0};
+  int p_nz = 0, p_dz0 = 0;
+  if (a.ex_grid.bits && lpr < 4) {                                  // (<= 8 channels: a row has one or two lanes, the loop form)
+    unsigned m = pcc_grid_nbr27(a.ex_grid, a.out_keys[o], cl, lpr, nullptr);
     for (int d = lpr >> 1; d >= 1; d >>= 1) m |= __shfl_xor((int)m, d);
     present = m;
+  } else if (a.ex_grid.bits) {
+    const PccGrid& g = a.ex_grid;
+    const long long key = a.out_keys[o];
+    const int b = (int)(key >> 48);
+    const int cx = (((int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - g.lo[0]) >> g.ts_log2);
+    const int cy = (((int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - g.lo[1]) >> g.ts_log2);
+    const int cz = (((int)(key & 0xFFFF) - (int)PCC_BIAS - g.lo[2]) >> g.ts_log2);
+    const int z_lo = cz > 0 ? cz - 1 : 0, z_hi = cz + 1 < g.dims[2] ? cz + 1 : g.dims[2] - 1;
+    p_nz = z_hi - z_lo + 1;
+    p_dz0 = z_lo - cz + 1;
+    const long long col_stride = g.dims[2], slab_stride = (long long)g.dims[1] * g.dims[2];
+    const long long cell0 = (((long long)b * g.dims[0] + cx) * g.dims[1] + cy) * g.dims[2] + z_lo;
+    const long long cells = (long long)g.nbatch * g.dims[0] * slab_stride;
+    const long long last_dw = 2 * ((cells + 63) >> 6) - 2;
+    const unsigned* const bits32 = reinterpret_cast<const unsigned*>(g.bits);
+    const int step = lpr < 9 ? lpr : 9;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int c = cl + t * step;
+      const int dx = c % 3 - 1, dy = c / 3 - 1;
+      const int nx = cx + dx, ny = cy + dy;
+      const bool ok = c < 9 && (lpr >= 9 ? t == 0 : true) && nx >= 0 && ny >= 0 && nx < g.dims[0] && ny < g.dims[1];
+      const long long cell = ok ? cell0 + dx * slab_stride + dy * col_stride : 0ll;
+      const long long dw = cell >> 5, dw2 = dw < last_dw ? dw : last_dw;
+      psh[t] = ok ? (int)(cell & 31) + 32 * (int)(dw - dw2) : 64;
+      pcol[t] = c;
+      pw_lo[t] = bits32[dw2];
+      pw_hi[t] = bits32[dw2 + 1];
+    }
   } else if (a.ex_nbr) {
     for (int k0 = 0; k0 < a.ex_K; k0 += lpr) {
       const int k = k0 + cl;
@@ -3468,6 +3505,18 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
       const unsigned long long bal = __ballot(v);
       present |= ((bal >> ((lane >> a.lpr_log2) << a.lpr_log2)) & (lpr == 64 ? ~0ull : ((1ull << lpr) - 1ull))) << k0;
     }
+  }
+  if (a.ex_grid.bits && lpr >= 4) {                                  // finish the presence mask from the windows fetched above
+    unsigned pm = 0;
+    const unsigned fmask = (1u << p_nz) - 1u;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const unsigned long long w = (unsigned long long)pw_lo[t] | ((unsigned long long)pw_hi[t] << 32);
+      const unsigned f = psh[t] < 64 ? (unsigned)(w >> (psh[t] & 63)) & fmask : 0u;
+      pm |= ((f & 1u) | ((f & 2u) << 8) | ((f & 4u) << 16)) << (pcol[t] + 9 * p_dz0);     // bit t of the field -> k = c + 9 (dz0 + t)
+    }
+    for (int d = lpr >> 1; d >= 1; d >>= 1) pm |= __shfl_xor((int)pm, d);
+    present = pm;
   }
   for (int cv = cl; cv < cvec; cv += lpr) {
     VT acc;

@@ -330,12 +330,16 @@ int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* packed, const
 /* ------------------------------------------------------------------------------------------
  * Frame intake and hand-over of UnifiedModel.compress / decompress (model/model.py:141-161, 240-250), one launch each.
  * pcc_frame_intake: pc [n,6] fp32 rows (x y z r g b) -> keys of (0, floor x, floor y, floor z), features [n,4] = (1, r, g, b),
- *   out12 (device int32[12]): [1..3] min of the floored coordinates, [5..7] MINUS their max, [8] != 0: rows already in
- *   canonical (strictly ascending key) order; the other words are not written.  ws: pcc_frame_intake_ws_bytes() (per-workgroup
+ *   out12 (device int32[12]): [0..3] min of (b, floored x y z), [4..7] MINUS their max, [8] != 0: rows already in
+ *   canonical (strictly ascending key) order.  ws: pcc_frame_intake_ws_bytes() (per-workgroup
  *   partial results; no global atomics).
  * pcc_decode_finish: keys [n] + colour features [n,3] -> out [n,6] = (x, y, z, clamp(round(255 f), 0, 255) / 255).
  * ---------------------------------------------------------------------------------------- */
+/* pcc_coords_intake_i32: int32 [n,4] rows (b, x, y, z) -> keys, out12 as above with [0] / [4] = min b / MINUS max b (the latent
+ *   coordinates `decompress` is handed, model/model.py:218-229): pack + bounds + order check in one pass. */
 size_t pcc_frame_intake_ws_bytes(void);
+int pcc_coords_intake_i32(const int32_t* coords, int64_t n, int64_t* keys, int32_t* out12, void* ws, size_t ws_bytes,
+                          void* stream);
 int pcc_frame_intake(const float* pc, int64_t n, int64_t* keys, float* feats, int32_t* out12, void* ws, size_t ws_bytes,
                      void* stream);
 int pcc_decode_finish(const int64_t* keys, const float* feats3, int64_t n, float* out6, void* stream);

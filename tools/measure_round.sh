@@ -11,6 +11,7 @@ echo "layer report" >> $O/progress.txt
 timeout -k 10 200 python tools/layer_report.py 10 > $O/layer_report.txt 2>&1
 echo "pmc" >> $O/progress.txt
 timeout -k 10 400 python tools/pmc_traffic.py collect $O/pmc > $O/pmc.log 2>&1 && python tools/pmc_traffic.py parse $O/pmc $O/pmc_traffic.json >> $O/pmc.log 2>&1 && python tools/pmc_by_kernel.py $O/pmc > $O/pmc_by_kernel.txt 2>&1
+cp $O/pmc_traffic.json profiles/pmc_traffic.json   # (so that the bench line below carries the traffic of THIS code: bench.py reads the stamped file)
 echo "train step" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 tools/train_profile.py 10 > $O/train_profile.txt 2>&1 && python profiles/summarize.py $O/train 16 > $O/train_kernel_stats.txt 2>&1
 echo "eval frames" >> $O/progress.txt

@@ -743,12 +743,27 @@ extern "C" int pcc_coords_bounds(const void* coords, int32_t is_float, int64_t n
 // (reference `model/model.py:141-161`); the constructor of its sparse tensor then needs the bounds of the floored coordinates
 // and whether the rows already are in canonical order.  Ten element-wise launches (zeros, two concatenations, a cast, the key
 // packing, two fills, the bounds, the order check) in the host-bound opening of a step: one pass here.
-// out12: [0..3] min (b, x, y, z), [4..7] MINUS max (so that one 0x7F fill initialises all of it), [8] != 0: canonical order.
+// out12: [0..3] min (b, x, y, z), [4..7] MINUS max (everything is a minimum), [8] != 0: canonical order.
+// partial row of a workgroup: [0..3] min (b, x, y, z), [4..7] min of MINUS (b, x, y, z), [8] 1 unless some row is not above
+// its predecessor; 16 ints per workgroup, reduced by k_intake_reduce (no global atomics: 3 000 same-line atomics of the first
+// version cost 60 us)
+__device__ __forceinline__ void intake_block_reduce(int (&v)[9], int* __restrict__ part) {
+  __shared__ int s_red[4][9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    for (int d = 32; d >= 1; d >>= 1) v[c] = min(v[c], __shfl_xor(v[c], d));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][c] = v[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    const int c = threadIdx.x;
+    part[blockIdx.x * 16 + c] = min(min(s_red[0][c], s_red[1][c]), min(s_red[2][c], s_red[3][c]));
+  }
+}
+
 __global__ void __launch_bounds__(256) k_frame_intake(const float* __restrict__ pc, long long n, long long* __restrict__ keys,
                                                       float4* __restrict__ feats, int* __restrict__ part) {
-  __shared__ int s_red[4][8];
-  int mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, nmx[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
-  int ok = 1;
+  int v[9] = {0, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 1};
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float2* r = reinterpret_cast<const float2*>(pc + i * 6);
     const float2 a = r[0], b = r[1], c = r[2];                       // x y | z r | g b
@@ -756,50 +771,55 @@ __global__ void __launch_bounds__(256) k_frame_intake(const float* __restrict__ 
     const long long k = pack4(0, x, y, z);
     keys[i] = k;
     feats[i] = make_float4(1.f, b.y, c.x, c.y);
-    mn[0] = min(mn[0], x); mn[1] = min(mn[1], y); mn[2] = min(mn[2], z);
-    nmx[0] = min(nmx[0], -x); nmx[1] = min(nmx[1], -y); nmx[2] = min(nmx[2], -z);
+    v[1] = min(v[1], x); v[2] = min(v[2], y); v[3] = min(v[3], z);
+    v[5] = min(v[5], -x); v[6] = min(v[6], -y); v[7] = min(v[7], -z);
     if (i > 0) {
       const float* q = pc + (i - 1) * 6;
-      if (k <= pack4(0, (int)floorf(q[0]), (int)floorf(q[1]), (int)floorf(q[2]))) ok = 0;
+      if (k <= pack4(0, (int)floorf(q[0]), (int)floorf(q[1]), (int)floorf(q[2]))) v[8] = 0;
     }
   }
-  // one partial row per workgroup (no global atomics: 3 000 same-line atomics of the first version cost 60 us), reduced
-  // by k_frame_intake_reduce
-  int v[7] = {mn[0], mn[1], mn[2], nmx[0], nmx[1], nmx[2], ok};
-#pragma unroll
-  for (int c = 0; c < 7; ++c) {
-    for (int d = 32; d >= 1; d >>= 1) v[c] = min(v[c], __shfl_xor(v[c], d));
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][c] = v[c];
-  }
-  __syncthreads();
-  if (threadIdx.x < 7) {
-    const int c = threadIdx.x;
-    part[blockIdx.x * 8 + c] = min(min(s_red[0][c], s_red[1][c]), min(s_red[2][c], s_red[3][c]));
-  }
+  intake_block_reduce(v, part);
 }
 
-__global__ void __launch_bounds__(256) k_frame_intake_reduce(const int* __restrict__ part, int nblk, int* __restrict__ out12) {
-  __shared__ int s_red[4][8];
-  int v[7];
+// the same for an int32 [n, 4] coordinate tensor (b, x, y, z): what `decompress` receives for the latent
+__global__ void __launch_bounds__(256) k_coords_intake_i32(const int4* __restrict__ c4, long long n, long long* __restrict__ keys,
+                                                           int* __restrict__ part) {
+  int v[9] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 1};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int4 c = c4[i];
+    const long long k = pack4(c.x, c.y, c.z, c.w);
+    keys[i] = k;
+    v[0] = min(v[0], c.x); v[1] = min(v[1], c.y); v[2] = min(v[2], c.z); v[3] = min(v[3], c.w);
+    v[4] = min(v[4], -c.x); v[5] = min(v[5], -c.y); v[6] = min(v[6], -c.z); v[7] = min(v[7], -c.w);
+    if (i > 0) {
+      const int4 q = c4[i - 1];
+      if (k <= pack4(q.x, q.y, q.z, q.w)) v[8] = 0;
+    }
+  }
+  intake_block_reduce(v, part);
+}
+
+__global__ void __launch_bounds__(256) k_intake_reduce(const int* __restrict__ part, int nblk, int* __restrict__ out12) {
+  __shared__ int s_red[4][9];
+  int v[9];
 #pragma unroll
-  for (int c = 0; c < 7; ++c) v[c] = 0x7FFFFFFF;
+  for (int c = 0; c < 9; ++c) v[c] = 0x7FFFFFFF;
   for (int b = threadIdx.x; b < nblk; b += 256)
 #pragma unroll
-    for (int c = 0; c < 7; ++c) v[c] = min(v[c], part[b * 8 + c]);
+    for (int c = 0; c < 9; ++c) v[c] = min(v[c], part[b * 16 + c]);
 #pragma unroll
-  for (int c = 0; c < 7; ++c) {
+  for (int c = 0; c < 9; ++c) {
     for (int d = 32; d >= 1; d >>= 1) v[c] = min(v[c], __shfl_xor(v[c], d));
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][c] = v[c];
   }
   __syncthreads();
-  if (threadIdx.x < 7) {
+  if (threadIdx.x < 9) {
     const int c = threadIdx.x;
-    const int r = min(min(s_red[0][c], s_red[1][c]), min(s_red[2][c], s_red[3][c]));
-    out12[c < 3 ? 1 + c : (c < 6 ? 5 + (c - 3) : 8)] = r;
+    out12[c] = min(min(s_red[0][c], s_red[1][c]), min(s_red[2][c], s_red[3][c]));
   }
 }
 
-extern "C" size_t pcc_frame_intake_ws_bytes(void) { return (size_t)1024 * 8 * sizeof(int); }
+extern "C" size_t pcc_frame_intake_ws_bytes(void) { return (size_t)1024 * 16 * sizeof(int); }
 
 extern "C" int pcc_frame_intake(const float* pc, int64_t n, int64_t* keys, float* feats, int32_t* out12, void* ws, size_t ws_bytes,
                                 void* stream) {
@@ -809,7 +829,19 @@ extern "C" int pcc_frame_intake(const float* pc, int64_t n, int64_t* keys, float
   if (ws_bytes < pcc_frame_intake_ws_bytes()) { pcc_set_error("pcc_frame_intake: workspace too small"); return PCC_EWS; }
   const unsigned g = (unsigned)(pcc_cdiv(n, 256) < 1024 ? pcc_cdiv(n, 256) : 1024);
   k_frame_intake<<<g, 256, 0, s>>>(pc, n, (long long*)keys, (float4*)feats, (int*)ws);
-  k_frame_intake_reduce<<<1, 256, 0, s>>>((const int*)ws, (int)g, out12);
+  k_intake_reduce<<<1, 256, 0, s>>>((const int*)ws, (int)g, out12);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_coords_intake_i32(const int32_t* coords, int64_t n, int64_t* keys, int32_t* out12, void* ws, size_t ws_bytes,
+                                     void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(coords && keys && out12 && ws && n >= 1 && ((uintptr_t)coords & 15) == 0, "pcc_coords_intake_i32: bad arguments");
+  if (ws_bytes < pcc_frame_intake_ws_bytes()) { pcc_set_error("pcc_coords_intake_i32: workspace too small"); return PCC_EWS; }
+  const unsigned g = (unsigned)(pcc_cdiv(n, 256) < 1024 ? pcc_cdiv(n, 256) : 1024);
+  k_coords_intake_i32<<<g, 256, 0, s>>>((const int4*)coords, n, (long long*)keys, (int*)ws);
+  k_intake_reduce<<<1, 256, 0, s>>>((const int*)ws, (int)g, out12);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pcc_gdn_pack": (C.c_int, [_p, _p, _i32, _f32, _p, _i64, _p, _p]),
     "pcc_gdn_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p]),
     "pcc_frame_intake_ws_bytes": (_sz, []),
+    "pcc_coords_intake_i32": (C.c_int, [_p, _i64, _p, _p, _p, _sz, _p]),
     "pcc_frame_intake": (C.c_int, [_p, _i64, _p, _p, _p, _p, _sz, _p]),
     "pcc_decode_finish": (C.c_int, [_p, _p, _i64, _p, _p]),
     "pcc_topk_ws_bytes": (_sz, [_i64]),

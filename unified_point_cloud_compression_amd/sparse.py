@@ -543,6 +543,19 @@ def frame_intake(pc):
     return keys, feats, Bounds(0, v[1:4], [-x for x in v[5:8]]), bool(v[8])
 
 
+def coords_intake(coords):
+    """int32 [n, 4] coordinates (b, x, y, z) -> (keys, Bounds, canonical?) with one kernel pair and one read."""
+    n = coords.shape[0]
+    keys = torch.empty(n, dtype=torch.int64, device=coords.device)
+    out = torch.empty(12, dtype=torch.int32, device=coords.device)
+    ws = L.workspace(L.load().pcc_frame_intake_ws_bytes(), coords.device)
+    L.call("pcc_coords_intake_i32", L.ptr(coords), n, L.ptr(keys), L.ptr(out), L.ptr(ws), ws.numel(), L.stream())
+    v = out.tolist()                                      # one device->host read
+    if v[0] < 0:
+        raise L.PccError("negative batch index")
+    return keys, Bounds(-v[4], v[1:4], [-x for x in v[5:8]]), bool(v[8])
+
+
 def coordset_from_coords(coords, tensor_stride, stride_chain=None):
     """Canonicalise user coordinates.  Returns (CoordSet, perm, keep):
     perm  None when the rows already are in canonical order, else int64 [n] with
@@ -555,6 +568,8 @@ def coordset_from_coords(coords, tensor_stride, stride_chain=None):
     hint = getattr(coords, "_pcc_hint", None)             # (keys, bounds, canonical) already read by the caller (compress)
     if hint is not None:
         keys, b, canonical = hint[:3]
+    elif n > 1 and coords.dtype == torch.int32 and coords.is_contiguous() and coords.data_ptr() % 16 == 0:
+        keys, b, canonical = coords_intake(coords)
     else:
         keys = pack_keys(coords)
         b, canonical = bounds_of(coords, canon_keys=keys if n > 1 else None) if n > 1 else (bounds_of(coords), True)

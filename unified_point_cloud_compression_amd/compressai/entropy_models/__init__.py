@@ -13,6 +13,8 @@ build's own model uses and the [B, C, N] methods transpose around them.
 import ctypes as C
 import math
 
+import warnings
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -229,7 +231,14 @@ class EntropyModel(nn.Module):
         `decompress_rows` takes in place of the bytes -- so that a caller can start the copy early, on another stream."""
         if isinstance(data, UploadedString):
             return data
-        buf = torch.frombuffer(bytearray(data) + bytearray(8), dtype=torch.uint8).to(dev)
+        nb = len(data)
+        buf = torch.empty(nb + 8, dtype=torch.uint8, device=dev)
+        if nb:
+            with warnings.catch_warnings():          # (a read-only view of the bytes: no host-side copy before the upload)
+                warnings.simplefilter("ignore")
+                src = torch.frombuffer(data, dtype=torch.uint8)
+            buf[:nb].copy_(src)
+        buf[nb:].zero_()
         return UploadedString(data, buf)
 
     def _dec_table(self, dev):

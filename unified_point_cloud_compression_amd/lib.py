@@ -195,11 +195,12 @@ def stream():
 _side = {}
 
 
-def side_stream(device):
-    """A second HIP stream per device for work that is latency-bound on a handful of CUs and independent of what the main
-    stream is doing (the hyper-latent's rANS decode beside the decoder's coordinate work).  Tensors allocated under it must be
-    `record_stream`-ed on the stream that consumes them."""
-    key = torch.device(device).index or 0
+def side_stream(device, which=0):
+    """Extra HIP streams per device for work that is independent of what the main stream is doing: 0 = latency-bound kernels on a
+    handful of CUs (the hyper-latent's rANS decode beside the decoder's coordinate work), 1 = host->device uploads (a pageable
+    copy waits for everything queued before it on ITS stream, so it must not share one with a long kernel).  Tensors allocated
+    under a side stream must be `record_stream`-ed on the stream that consumes them."""
+    key = (torch.device(device).index or 0, which)
     st = _side.get(key)
     if st is None:
         st = _side[key] = torch.cuda.Stream(device=device)

@@ -243,7 +243,7 @@ class MeanScaleHyperprior(CompressionModel):
             return None
         z_sym, _, ev = pre
         main = torch.cuda.current_stream(device)
-        side = L.side_stream(device)
+        side = L.side_stream(device, 1)             # (its own stream: behind the hyper-latent's decode the copy would wait for it)
         with torch.cuda.stream(side):
             y_up = self.gaussian_conditional.upload_string(symbols[0][0], device)
             ev2 = side.record_event()

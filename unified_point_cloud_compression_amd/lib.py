@@ -211,8 +211,9 @@ _ws = {}
 
 
 def workspace(nbytes, device):
-    """One growing scratch buffer per device; calls are stream-ordered so it is shared."""
-    key = torch.device(device).index or 0
+    """One growing scratch buffer per (device, current stream); calls on a stream are ordered, so they share it -- and work on a
+    side stream gets a buffer of its own instead of racing the main stream's."""
+    key = (torch.device(device).index or 0, stream())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         _ws[key] = buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)

@@ -663,9 +663,11 @@ extern "C" int64_t pcc_rans_stream_symbols(int64_t n, int32_t channels, int32_t 
 // payload) and must pick the same count every time it sees the same symbols.
 __global__ void __launch_bounds__(256) k_rans_estimate(const int* __restrict__ sym, const int* __restrict__ idx, long long total,
                                                        int channels, RansTab t, unsigned long long* __restrict__ bits256) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  unsigned b = 0;
-  if (e < total) {
+  // grid-stride: one 64-bit atomic per workgroup at the end, and few workgroups (7 450 same-address atomics of the
+  // element-per-thread form cost ~75 of the kernel's 92 us; the sum is an integer, so its order does not matter)
+  unsigned long long acc = 0;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    unsigned b = 0;
     const int ci = idx ? idx[e] : (int)(e % channels);
     const int max_value = t.sizes[ci] - 2;
     int v = sym[e] - t.offsets[ci];
@@ -676,8 +678,9 @@ __global__ void __launch_bounds__(256) k_rans_estimate(const int* __restrict__ s
     const int freq = max(row[v + 1] - row[v], 1);
     b = (unsigned)__float2int_rn(256.f * (16.f - __log2f((float)freq)));
     if (v == max_value) b += 256u * 4u * (unsigned)((32 - __clz((int)(raw | 1u)) + 3) / 4 + 1);   // bypass digits, 4 bits each
+    acc += b;
   }
-  unsigned long long w = b;
+  unsigned long long w = acc;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) w += __shfl_xor(w, d, 64);
   __shared__ unsigned long long part[4];
@@ -695,7 +698,8 @@ extern "C" int pcc_rans_estimate_bits(const int32_t* sym, const int32_t* idx, in
   if (n == 0) return PCC_OK;
   RansTab t{cdf, cdf_stride, sizes, offsets};
   const long long total = (long long)n * channels;
-  k_rans_estimate<<<(unsigned)pcc_cdiv(total, 256), 256, 0, s>>>(sym, idx, total, channels, t, (unsigned long long*)d_bits256);
+  const long long blocks = pcc_cdiv(total, 256);
+  k_rans_estimate<<<(unsigned)(blocks < 1024 ? blocks : 1024), 256, 0, s>>>(sym, idx, total, channels, t, (unsigned long long*)d_bits256);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Copy the summaries of the last tools/measure_round.sh batch (gpurun_out/meas/) into profiles/ under the round's names.
+# usage: tools/publish_profiles.sh r03
+R=${1:-r03}; M=gpurun_out/meas; P=profiles
+cp $M/kernel_stats.txt $P/${R}_kernel_stats_bench_steps5_warm2.txt
+cp $M/gpu_idle.txt $P/${R}_gpu_idle_and_bookkeeping.txt
+cp $M/kernel_attribution.txt $P/${R}_kernel_attribution.txt
+cp $M/layer_report.txt $P/${R}_layer_report.txt
+cp $M/pmc_by_kernel.txt $P/${R}_pmc_fetch_write_by_kernel.txt
+cp $M/pmc_traffic.json $P/${R}_pmc_traffic.json
+cp $M/pmc_traffic.json $P/pmc_traffic.json
+tail -n 1 $M/bench.json > $P/${R}_bench_line_steps20_warm5.json
+cp $M/train_kernel_stats.txt $P/${R}_train_step_kernel_stats.txt
+grep -v amdgpu.ids $M/eval_frames.txt > $P/${R}_eval_frames_blocks_1gpu.txt
+[ -f $M/host_timeline.txt ] && cp $M/host_timeline.txt $P/${R}_host_timeline.txt
+ls -la $P | grep ${R}_ | wc -l

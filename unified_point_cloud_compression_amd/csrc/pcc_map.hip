@@ -897,17 +897,41 @@ __device__ __forceinline__ void csr_probe(const ExpandCsrArgs& a, long long o, F
   CsrCols<KS> c;
   csr_columns<KS>(a, o, c);
   if (c.b >= a.in.nbatch || c.cnt[2] == 0) return;
-  for (int jx = 0; jx < c.cnt[0]; ++jx)
-    for (int jy = 0; jy < c.cnt[1]; ++jy) {
-      const long long cell = (((long long)c.b * a.in.dims[0] + c.cell(0, jx)) * a.in.dims[1] + c.cell(1, jy)) * a.in.dims[2] + c.cell(2, 0);
-      long long wi; unsigned long long w0;
-      unsigned f = csr_field(a.in.bits, cell, c.cnt[2], &wi, &w0);
+  // The y columns of one x slab together (round 3): per column the aligned 64-bit word of its first cell, the 32 bits after it
+  // (a field of <= 4 bits never reaches past them) and the word's rank -- three unconditional loads, absent columns re-read
+  // cell 0 and are masked -- so a slab's <= 12-15 loads are in flight at once.  (The column-by-column loop waited for each
+  // column's word, and for its rank behind a branch: 16 exposed L2 latencies per row of the 7-wide lists.)
+  constexpr int MY = KS == 7 ? 4 : KS;                 // compatible offsets per axis: <= (KS + 1) / 2 at a pitch ratio of 2, KS at 1
+  const unsigned* const bits32 = reinterpret_cast<const unsigned*>(a.in.bits);
+  const long long cells = (long long)a.in.nbatch * a.in.dims[0] * a.in.dims[1] * a.in.dims[2];
+  const long long last_w = ((cells + 63) >> 6) - 1;
+  const unsigned fmask = (1u << c.cnt[2]) - 1u;
+  const int kzs = a.zk ? 1 : KS * KS;
+  for (int jx = 0; jx < c.cnt[0]; ++jx) {
+    unsigned long long w0[MY];
+    unsigned nx[MY];
+    int rk[MY], sh[MY];
+#pragma unroll
+    for (int jy = 0; jy < MY; ++jy) {
+      const bool ok = jy < c.cnt[1];
+      const long long cell = ok ? (((long long)c.b * a.in.dims[0] + c.cell(0, jx)) * a.in.dims[1] + c.cell(1, jy)) * a.in.dims[2] + c.cell(2, 0) : 0ll;
+      const long long wi = cell >> 6;
+      sh[jy] = ok ? (int)(cell & 63) : 64;
+      w0[jy] = a.in.bits[wi];
+      nx[jy] = bits32[2 * (wi < last_w ? wi + 1 : last_w)];          // (the last word has no successor: its field cannot straddle)
+      rk[jy] = a.in.rank[wi];
+    }
+#pragma unroll
+    for (int jy = 0; jy < MY; ++jy) {
+      if (sh[jy] >= 64) continue;
+      unsigned long long win = w0[jy] >> sh[jy];
+      if (sh[jy]) win |= (unsigned long long)nx[jy] << (64 - sh[jy]);
+      unsigned f = (unsigned)win & fmask;
       if (!f) continue;
-      // row of the first cell's position: rank of its word + set bits below it; later hits of the field follow consecutively
+      // row of the first hit: rank of the word + set bits below the field; later hits of the field follow consecutively
       // (the rank is cumulative across words, so a field that straddles two words needs nothing extra)
-      int i = a.in.rank[wi] + __popcll(w0 & ((1ull << (cell & 63)) - 1ull));
+      int i = rk[jy] + __popcll(w0[jy] & ((1ull << sh[jy]) - 1ull));
       const int kxy = a.zk ? KS * (c.idx(1, jy) + KS * c.idx(0, jx)) : c.idx(0, jx) + KS * c.idx(1, jy);
-      const int kzs = a.zk ? 1 : KS * KS;
       while (f) {
         const int t = __ffs((int)f) - 1;
         f &= f - 1;
@@ -915,6 +939,7 @@ __device__ __forceinline__ void csr_probe(const ExpandCsrArgs& a, long long o, F
         ++i;
       }
     }
+  }
 }
 
 // fill pass: the pair ids of a block's 256 rows occupy one contiguous range of pair_ids (first[] is a prefix sum), so

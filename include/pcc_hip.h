@@ -209,6 +209,10 @@ int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows
  * exact three-way bf16 split of both operands (six cross terms, fp32 accumulation: fp32 accuracy at 2.67x the fp32-MFMA
  * rate); 0 selects the fp32-input MFMA kernels.  Process-wide switch (tests compare both). */
 int pcc_set_mfma_split(int32_t on);
+/* 4-channel inputs (the codec's first layer, 4 -> 128, 5x5x5, stride 2): from `rows` output rows on, the (offset, channel)
+ * pairs are flattened into one reduction axis and the convolution runs in 32-wide chunks of 8 offsets on the six-term bf16
+ * form (default 65536; env PCC_IN4_MIN_ROWS; negative: never).  Tests lower it to reach the path on small inputs. */
+int pcc_set_in4_min_rows(int64_t rows);
 /* dense products of the generative transposed convolutions in scaled fp16 pairs (three MFMA terms; default on) or the
  * six-term bf16 form (0); both at fp32 accuracy, tests/test_gpu_map_conv.py::test_dense_products_accuracy. */
 int pcc_set_gemm_h(int32_t on);

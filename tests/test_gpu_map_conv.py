@@ -106,6 +106,39 @@ def test_conv_strided_k5(cin, cout, ks, stride):
     assert_close(n(got), want, what="strided conv")
 
 
+@pytest.mark.parametrize("ks,stride,cout,act", [(5, 2, 128, "none"), (5, 1, 128, "relu"), (3, 2, 256, "leaky")])
+def test_four_channel_input_layer_flattened_form(ks, stride, cout, act):
+    """`k_conv_in4_bf` (the codec's first layer: 4 input channels, the (offset, channel) pairs flattened into one 32-wide-chunk
+    reduction, six bf16 terms) against the oracle and against the offset-by-offset kernel it replaces on large inputs; two
+    batches, a ragged last tile, K * 4 not a multiple of 32 (5^3 -> 500, 3^3 -> 108), bias and fused activations."""
+    from unified_point_cloud_compression_amd import sparse as S, lib as L
+    keys = cloud_keys(17 + ks, 30, 0.12, 1, batch=2)
+    cs = _cs(keys, 1, 2)
+    out = cs if stride == 1 else cs.stride(stride)
+    rng = np.random.default_rng(ks)
+    f = np.concatenate([np.ones((len(keys), 1)), rng.random((len(keys), 3)) * 255], axis=1).astype(np.float32)   # [1, r, g, b]
+    K = ks ** 3
+    W = (rng.standard_normal((K, 4, cout)) / 40).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    m = cs.kernel_map(out, ks)
+    code = {"none": L.ACT_NONE, "relu": L.ACT_RELU, "leaky": L.ACT_LEAKY}[act]
+    fn = {"none": lambda v: v, "relu": lambda v: np.maximum(v, 0), "leaky": lambda v: np.where(v > 0, v, 0.01 * v)}[act]
+    packed = S.PackedConv().get(torch.nn.Parameter(t(W)))
+    ft, bt = t(f), t(b)
+    try:
+        L.call("pcc_set_in4_min_rows", 0)
+        got = S.conv_forward(ft, packed, bt, K, 4, cout, m, out.n, act=code)
+        L.call("pcc_set_in4_min_rows", -1)
+        old = S.conv_forward(ft, packed, bt, K, 4, cout, m, out.n, act=code)
+    finally:
+        L.call("pcc_set_in4_min_rows", 65536)
+    out_keys = keys if stride == 1 else co.stride_keys(keys, stride)
+    want = fn(ops.conv(f, W, b, co.kernel_map(keys, out_keys, ks, 1)))
+    scale = float(np.abs(want).max())
+    assert_close(n(got) / scale, want / scale, what="flattened 4-channel convolution vs oracle")
+    assert_close(n(got) / scale, n(old) / scale, atol=2e-6, rtol=0, what="flattened form vs the offset-by-offset kernel")
+
+
 @pytest.mark.parametrize("cin,cout,stride,bias,act", [(128, 128, 2, True, 1), (64, 64, 1, False, 0), (192, 256, 1, True, 2),
                                                        (128, 32, 2, False, 0)])
 def test_conv_pair_list_form(cin, cout, stride, bias, act):

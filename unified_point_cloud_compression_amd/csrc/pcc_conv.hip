@@ -1192,6 +1192,156 @@ __global__ void __launch_bounds__(256, 3) k_gdn_bf(ConvArgs a) {
   }
 }
 
+// The input layer (4 -> 128 channels, 5x5x5, stride 2: `g_a.down_conv_1[0]`) with its (offset, channel) pairs flattened into
+// ONE reduction axis of K * 4 <= 512 (round 3).  The general kernel walks the 125 offsets one at a time -- a 4-deep reduction per
+// staging round, 125 rounds of gather -> LDS -> barrier -> MFMA per tile: 2.8 us per round of pure latency, 22 TFLOP/s.  Here a
+// chunk is 8 offsets x 4 channels = the 32-wide piece the split kernels work on: a thread gathers the 16-byte feature rows of
+// (output row, offset) pairs through the map, splits them into bf16 planes in registers (as k_gdn_bf does) and writes the LDS
+// image; 16 rounds instead of 125, six bf16 MFMA terms per product.  Absent neighbours are out-of-range buffer loads (zeros).
+// Weights: planes [16 pieces][cout_pad][3][32] bf16 of the flattened kernel, converted from the packed fp32 image per call
+// (k_in4_weight_planes, 0.4 MB).  Map indices are fetched two chunks ahead, rows one chunk ahead.
+__global__ void __launch_bounds__(256) k_in4_weight_planes(const float* __restrict__ wp /*[K][cout_pad][4]*/, int K, int cout_pad,
+                                                           unsigned* __restrict__ planes /*[16][cout_pad][48 dwords]*/) {
+  const int t = blockIdx.x * 256 + threadIdx.x;                       // one pair of consecutive flat indices of one column
+  if (t >= 16 * cout_pad * 16) return;
+  const int cp = t & 15, col = (t >> 4) % cout_pad, piece = t / (16 * cout_pad);
+  const int f0 = piece * 32 + 2 * cp;                                 // flat index = 4 * offset + channel
+  const int k = f0 >> 2, c = f0 & 3;                                  // (f0 even: both elements of the pair belong to offset k)
+  float v0 = 0.f, v1 = 0.f;
+  if (k < K) { const float* w = wp + ((size_t)k * cout_pad + col) * 4 + c; v0 = w[0]; v1 = w[1]; }
+  unsigned h, m, l;
+  bf_split2(v0, v1, h, m, l);
+  unsigned* d = planes + ((size_t)piece * cout_pad + col) * 48 + cp;
+  d[0] = h; d[16] = m; d[32] = l;
+}
+
+template <int TM>
+__global__ void __launch_bounds__(256, 3) k_conv_in4_bf(ConvArgs a, const unsigned* __restrict__ wplanes, int K) {
+  constexpr int WM = 2, WN = 2, TN = 2;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDU = 13, NCHUNK = 16;
+  __shared__ __attribute__((aligned(16))) uint4 As[BM * LDU];
+  __shared__ __attribute__((aligned(16))) uint4 Bs[BN * LDU];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cpx = gridDim.x >> 3;
+  const int wid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  const int gy = a.cout_pad / BN;
+  const int tile_id = wid / gy;
+  const int colblock = (wid - tile_id * gy) * BN;
+  const long long p0 = (long long)tile_id * BM;
+  if (p0 >= a.n_out) return;
+  const int pos0 = (int)p0;
+  const int npos = (int)min((long long)BM, a.n_out - p0);
+  const int nchunks = (K * 4 + 31) / 32;                              // <= NCHUNK
+
+  constexpr int NX = BM * 8 / 256, NB = (BN * 12 + 255) / 256;
+  int x_row[NX], x_j[NX], b_row[NB], b_w[NB];
+#pragma unroll
+  for (int q = 0; q < NX; ++q) { const int u = q * 256 + tid; x_row[q] = u >> 3; x_j[q] = u & 7; }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) { const int u = q * 256 + tid; b_row[q] = u / 12; b_w[q] = u - b_row[q] * 12; if (u >= BN * 12) b_row[q] = -1; }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int wm = w / WN, wn = w % WN;
+  const int half = lane >> 5, r31 = lane & 31;
+
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned*>(wplanes), (short)0, (int)(unsigned)((size_t)NCHUNK * a.cout_pad * 192u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.feat), (short)0, (int)(unsigned)((size_t)a.n_in * 16u), 0x00020000);
+  const int* const nb0 = a.nbr + pos0;
+
+  int id[NX];
+  uint4 xv[NX], bv[NB];
+  auto load_idx = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+      const int k = c * 8 + x_j[q];
+      id[q] = (k < K && x_row[q] < npos) ? nb0[(long long)k * a.n_out + x_row[q]] : -1;
+    }
+  };
+  auto issue = [&](int c) {                                           // rows of chunk c (indices already in id[]) + its weights
+#pragma unroll
+    for (int q = 0; q < NX; ++q)
+      xv[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsX, id[q] >= 0 ? (unsigned)id[q] * 16u : BUF_OOB, 0, 0));
+    const unsigned wbase = (unsigned)(c * a.cout_pad + colblock) * 192u;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const unsigned off = b_row[q] >= 0 ? wbase + (unsigned)(q * 256 + tid) * 16u : BUF_OOB;
+      bv[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+    }
+  };
+  load_idx(0);
+  issue(0);
+  if (nchunks > 1) load_idx(1);
+  unsigned long long* const As64 = reinterpret_cast<unsigned long long*>(As);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      bf_split2(__uint_as_float(xv[q].x), __uint_as_float(xv[q].y), h0, m0, l0);
+      bf_split2(__uint_as_float(xv[q].z), __uint_as_float(xv[q].w), h1, m1, l1);
+      const int o = x_row[q] * (LDU * 2) + x_j[q];                    // 8-byte slots: plane p of the row starts at slot 8 p
+      As64[o] = (unsigned long long)h0 | ((unsigned long long)h1 << 32);
+      As64[o + 8] = (unsigned long long)m0 | ((unsigned long long)m1 << 32);
+      As64[o + 16] = (unsigned long long)l0 | ((unsigned long long)l1 << 32);
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      if (b_row[q] >= 0) Bs[b_row[q] * LDU + b_w[q]] = bv[q];
+    __syncthreads();
+    if (c + 1 < nchunks) {
+      issue(c + 1);                                                   // (its indices arrived during the previous chunk)
+      if (c + 2 < nchunks) load_idx(c + 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[p][i] = __builtin_bit_cast(bf16x8, As[((wm * TM + i) * 32 + r31) * LDU + p * 4 + ks * 2 + half]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bf[p][j] = __builtin_bit_cast(bf16x8, Bs[((wn * TN + j) * 32 + r31) * LDU + p * 4 + ks * 2 + half]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {           // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = colblock + (wn * TN + j) * 32 + r31;
+    if (col >= a.cout) continue;
+    const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (r >= npos) continue;
+        a.out[(size_t)(pos0 + r) * a.cout + col] = act1(acc[i][j][e] + b, a.act, a.slope);
+      }
+  }
+}
+
 // (Round 3, tools/gemm_h2_probe.py + PCC_DBG on the level-2 composite shape 58 051 x 128 x 21 952, and tools/write_probe.hip:
 //  the chip stores this 5.1 GB buffer in 0.90 ms at best (5.65 TB/s, this kernel's own store pattern, any occupancy); this
 //  kernel takes 1.68-1.78 = LDS skeleton 0.38 + loads 0.05 + MFMA 0.27 + stores 0.56 measured one at a time, but loads + stores
@@ -2647,6 +2797,10 @@ static int launch_project(const float* feat, int64_t n_in, const float* wt, int 
   return PCC_OK;
 }
 
+// 4-channel inputs: output rows from which the flattened form (k_conv_in4_bf) replaces the offset-by-offset kernel; negative = never
+static long long g_in4_min_rows = getenv("PCC_IN4_MIN_ROWS") ? atoll(getenv("PCC_IN4_MIN_ROWS")) : 65536;
+extern "C" int pcc_set_in4_min_rows(int64_t rows) { g_in4_min_rows = rows; return PCC_OK; }
+
 extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                             const float* bias, int32_t K, int32_t cout, const int32_t* hdr, const int32_t* nbr,
                             const int32_t* rows, int64_t n_out, float* out, int32_t act, float slope,
@@ -2669,6 +2823,20 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
     a.n_out = n_out; a.cin = cin; a.cout = cout; a.cout_pad = cout_pad_for(cout);
     a.n_in = n_in; a.wp_elems = (long long)K * cin * a.cout_pad;
     a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = act; a.slope = slope;
+    const bool in4 = g_in4_min_rows >= 0;
+    // the input layer: 4 channels, K * 4 <= 512 flattened into one reduction axis (k_conv_in4_bf); plain conv maps of >= 64 k
+    // output rows (one segment, canonical row order: what pcc_kernel_map_build makes for a non-transposed map)
+    if (in4 && cin == 4 && K * 4 <= 512 && K > 1 && hdr && !rows && bn_for(cout) == 128 && n_out >= g_in4_min_rows &&
+        n_in * 16 <= BUF_MAX_BYTES && n_out * (long long)K < (1ll << 31) && ((uintptr_t)feat_in & 15) == 0) {
+      void* wpl = nullptr;
+      PCC_TRY(lib_scratch_small((size_t)16 * a.cout_pad * 192, &wpl));
+      k_in4_weight_planes<<<(unsigned)pcc_cdiv(16 * a.cout_pad * 16, 256), 256, 0, s>>>(packed_w, K, a.cout_pad, (unsigned*)wpl);
+      const long long gy = a.cout_pad / 128;
+      const unsigned grid = (unsigned)((pcc_cdiv(n_out, 128) * gy + 7) / 8 * 8);
+      prof_note(PCC_FORM_CONV_BF, 0.0, 0.0);
+      k_conv_in4_bf<2><<<grid, 256, 0, s>>>(a, (const unsigned*)wpl, K);
+      PCC_LAUNCH_CHECK();
+    } else
     PCC_TRY(launch_mfma<MODE_CONV>(a, rows ? PCC_MAP_MAX_SEG : 0, s));
   } else if (kind == KIND_WAVE16) {
     Wave16Args a;

@@ -213,6 +213,10 @@ int pcc_set_mfma_split(int32_t on);
  * pairs are flattened into one reduction axis and the convolution runs in 32-wide chunks of 8 offsets on the six-term bf16
  * form (default 65536; env PCC_IN4_MIN_ROWS; negative: never).  Tests lower it to reach the path on small inputs. */
 int pcc_set_in4_min_rows(int64_t rows);
+/* pcc_conv_thin_grid_fwd with one output channel over 16 input channels (the last level's occupancy head): from `rows` rows on
+ * the projection pass pre-adds a column's three z terms for the middle row and the gather reads one value per (dx, dy) column
+ * (default 2^20; env PCC_THIN_Z_MIN_ROWS; negative: never).  Tests lower it to reach the path on small inputs. */
+int pcc_set_thin_z_min_rows(int64_t rows);
 /* dense products of the generative transposed convolutions in scaled fp16 pairs (three MFMA terms; default on) or the
  * six-term bf16 form (0); both at fp32 accuracy, tests/test_gpu_map_conv.py::test_dense_products_accuracy. */
 int pcc_set_gemm_h(int32_t on);

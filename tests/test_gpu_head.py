@@ -110,7 +110,7 @@ def _two_batch_keys(seed, ts, shift):
     return np.unique(co.pack_keys(np.concatenate(C)))
 
 
-@pytest.mark.parametrize("ts,shift,cin,cout", [(1, 0, 16, 1), (2, -5, 8, 3), (1, -3, 32, 4), (1, 0, 64, 1), (2, -5, 32, 1)])
+@pytest.mark.parametrize("ts,shift,cin,cout", [(1, 0, 16, 1), (2, -5, 16, 1), (2, -5, 8, 3), (1, -3, 32, 4), (1, 0, 64, 1), (2, -5, 32, 1)])
 def test_thin_conv_from_grid_matches_oracle(ts, shift, cin, cout):
     """`pcc_conv_thin_grid_fwd`: 3x3x3 conv to <= 4 channels, neighbour rows from the bitmap + rank (no kernel map);
     two batch entries, negative coordinates, rows on every face of the bounding lattice.  (cin 32 / 64 with one output
@@ -132,6 +132,16 @@ def test_thin_conv_from_grid_matches_oracle(ts, shift, cin, cout):
     want = ops.conv(x, n(conv.kernel), n(conv.bias), co.kernel_map(keys, keys, 3, ts))
     assert_close(n(got), want, what="thin conv from grid vs oracle")
     assert torch.equal(got, again)
+    if cin == 16 and cout == 1:        # the z-folded planes (large sets by default): same result up to the summation order
+        from unified_point_cloud_compression_amd import lib as L
+        try:
+            L.call("pcc_set_thin_z_min_rows", 0)
+            with torch.no_grad():
+                zf = S.conv_thin_grid_forward(t(x), w, conv.bias, cin, cout, cs)
+        finally:
+            L.call("pcc_set_thin_z_min_rows", 1 << 20)
+        assert_close(n(zf), want, what="thin conv, z-folded planes vs oracle")
+        assert_close(n(zf), n(got), atol=5e-6, rtol=1e-6, what="z-folded planes vs 27-plane form")
 
 
 @pytest.mark.parametrize("ts_in,shift,cin,cout", [(2, 0, 16, 8), (4, -3, 16, 8), (2, -3, 32, 16), (4, 0, 32, 64), (2, 0, 32, 32)])

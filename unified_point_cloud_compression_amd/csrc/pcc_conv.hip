@@ -4117,12 +4117,142 @@ __global__ void __launch_bounds__(256) k_thin_gather_grid1(ThinGridArgs a) {
   a.out[p] = acc + (a.bias ? a.bias[0] : 0.f);
 }
 
+// z-folded planes (round 3, one output channel over <= 16 hidden channels: the last level's head).  Canonical order is z fastest,
+// so the dz = -1 / +1 neighbours of row i inside a (x, y) column are rows i - 1 / i + 1.  The projection pass therefore pre-adds a
+// column's three terms for the row in the MIDDLE:   S_g[i] = <h_i, w(g,0)> + [i-1 adjacent] <h_{i-1}, w(g,-1)> + [i+1 adjacent]
+// <h_{i+1}, w(g,+1)>   (g = the 9 (dx, dy) columns), and keeps the dz = -1 / +1 single terms as U_g[i], D_g[i] for the rare
+// column whose middle cell is absent.  The gather then reads ONE value per column (9 x 4 B per row instead of 27 x 4 B, the
+// same 27 planes in memory): 2.0 -> ~1.0 GB of L2 / HBM reads on the last level.
+template <int CIN>
+__global__ void __launch_bounds__(256) k_thin_project_z(const float* __restrict__ feat, const long long* __restrict__ keys,
+                                                        long long n_in, long long ts, const float* __restrict__ wt,
+                                                        float* __restrict__ t) {
+  // A workgroup owns 256 consecutive rows (aligned 256-byte store runs per wave and plane).  Pass 1 projects every row on the
+  // 27 kernels into LDS (one column per row + one halo column each side: the rows just outside the workgroup are projected by
+  // 18 of its threads); pass 2 adds a column's neighbour terms from the adjacent LDS columns.  The loops over the kernels stay
+  // rolled: unrolled, the compiler keeps all 27 x CIN weights in registers (256 VGPRs + spills, one wave per SIMD: 1.6 ms).
+  extern __shared__ __attribute__((aligned(16))) float w_s[];          // 27 * CIN weights
+  __shared__ float sd[27][258];                                        // [kernel][1 + thread] (+ halo columns 0 and 257)
+  for (int i = threadIdx.x; i < 27 * CIN; i += 256) w_s[i] = wt[i];
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * 256;
+  const long long i = base + threadIdx.x;
+  const bool valid = i < n_in;
+  float4 x[CIN / 4];
+#pragma unroll
+  for (int c = 0; c < CIN / 4; ++c) x[c] = valid ? reinterpret_cast<const float4*>(feat + i * CIN)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long key = valid ? keys[i] : -(1ll << 62);
+  const bool adjm = valid && i > 0 && keys[i - 1] == key - ts;         // row i - 1 is the z - 1 cell of the same column
+  const bool adjp = valid && i + 1 < n_in && keys[i + 1] == key + ts;
+#pragma unroll 1
+  for (int k = 0; k < 27; ++k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN / 4; ++c) {
+      const float4 w = reinterpret_cast<const float4*>(w_s + k * CIN)[c];   // wave-uniform address: LDS broadcast
+      acc += x[c].x * w.x + x[c].y * w.y + x[c].z * w.z + x[c].w * w.w;
+    }
+    sd[k][1 + threadIdx.x] = acc;
+  }
+  // the rows just outside the workgroup: thread e < 9 projects row base - 1 on w(e, dz = -1), thread 9 + e row base + 256 on
+  // w(e, dz = +1) (same dot, same order of additions as above)
+  if (threadIdx.x < 18) {
+    const int e = threadIdx.x < 9 ? threadIdx.x : threadIdx.x - 9;
+    const long long r = threadIdx.x < 9 ? base - 1 : base + 256;
+    const int k = threadIdx.x < 9 ? e : e + 18;
+    float acc = 0.f;
+    if (r >= 0 && r < n_in) {
+#pragma unroll
+      for (int c = 0; c < CIN / 4; ++c) {
+        const float4 xv = reinterpret_cast<const float4*>(feat + r * CIN)[c];
+        const float4 w = reinterpret_cast<const float4*>(w_s + k * CIN)[c];
+        acc += xv.x * w.x + xv.y * w.y + xv.z * w.z + xv.w * w.w;
+      }
+    }
+    sd[k][threadIdx.x < 9 ? 0 : 257] = acc;
+  }
+  __syncthreads();
+  if (!valid) return;
+  const int col = 1 + threadIdx.x;
+#pragma unroll 1
+  for (int g = 0; g < 9; ++g) {
+    const float lo = sd[g][col], mid = sd[g + 9][col], hi = sd[g + 18][col];
+    const float from_dn = sd[g][col - 1];                               // <h_{i-1}, w(g, dz = -1)>
+    const float from_up = sd[g + 18][col + 1];                          // <h_{i+1}, w(g, dz = +1)>
+    t[(long long)g * n_in + i] = (mid + (adjm ? from_dn : 0.f)) + (adjp ? from_up : 0.f);
+    t[(long long)(9 + g) * n_in + i] = lo;
+    t[(long long)(18 + g) * n_in + i] = hi;
+  }
+}
+
+// gather over the z-folded planes: per column the middle cell's S value, or -- middle absent -- the U / D singles of the cells
+// below / above it.  Three buffer loads per column, at most two of them in range.
+__global__ void __launch_bounds__(256) k_thin_gather_grid1z(ThinGridArgs a) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n) return;
+  const PccGrid& g = a.g;
+  const long long key = a.keys[p];
+  const int b = (int)(key >> 48);
+  const int cx = (((int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - g.lo[0]) >> g.ts_log2);
+  const int cy = (((int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - g.lo[1]) >> g.ts_log2);
+  const int cz = (((int)(key & 0xFFFF) - (int)PCC_BIAS - g.lo[2]) >> g.ts_log2);
+  const int z_lo = cz > 0 ? cz - 1 : 0, z_hi = cz + 1 < g.dims[2] ? cz + 1 : g.dims[2] - 1;
+  const int nz = z_hi - z_lo + 1;
+  const int dz0 = z_lo - cz + 1;                                      // dz index (0, 1, 2 = -1, 0, +1) of the field's bit 0
+  unsigned long long w0[9], w1[9];
+  int rk[9], sh[9];
+  bool ok[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const int nx = cx + c % 3 - 1, ny = cy + c / 3 - 1;
+    ok[c] = !(nx < 0 || ny < 0 || nx >= g.dims[0] || ny >= g.dims[1]);
+    const long long cell = ok[c] ? (((long long)b * g.dims[0] + nx) * g.dims[1] + ny) * g.dims[2] + z_lo : 0ll;
+    const long long wi = cell >> 6;
+    sh[c] = (int)(cell & 63);
+    w0[c] = g.bits[wi];
+    rk[c] = g.rank[wi];
+    w1[c] = (sh[c] + nz > 64) ? g.bits[wi + 1] : 0ull;
+  }
+  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.t), (short)0,
+                                                                       (int)(unsigned)((size_t)27 * a.n * 4), 0x00020000);
+  const int tm = 1 - dz0;                                             // bit of the middle cell (dz0 <= 1: it is inside the field)
+  float v[27];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    unsigned long long f64 = w0[c] >> sh[c];
+    if (sh[c] + nz > 64) f64 |= w1[c] << (64 - sh[c]);
+    const unsigned f = ok[c] ? ((unsigned)f64 & ((1u << nz) - 1u)) : 0u;
+    const unsigned r = (unsigned)(rk[c] + __popcll(w0[c] & ((1ull << sh[c]) - 1ull)));
+    const bool mid = (f >> tm) & 1u;
+    const bool low = dz0 == 0 && (f & 1u);                            // the dz = -1 cell is bit 0, present only when z_lo = cz - 1
+    const int tu = 2 - dz0;                                           // bit of the dz = +1 cell (may lie past the field: then absent)
+    const bool upp = tu < nz && ((f >> tu) & 1u);
+    const unsigned row_mid = r + __popc(f & ((1u << tm) - 1u));
+    const unsigned row_up = r + __popc(f & ((1u << tu) - 1u));
+    const unsigned n = (unsigned)a.n;
+    const unsigned o_s = mid ? ((unsigned)c * n + row_mid) * 4u : BUF_OOB;
+    const unsigned o_u = (!mid && low) ? ((unsigned)(9 + c) * n + r) * 4u : BUF_OOB;
+    const unsigned o_d = (!mid && upp) ? ((unsigned)(18 + c) * n + row_up) * 4u : BUF_OOB;
+    v[c * 3 + 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, o_s, 0, 0));
+    v[c * 3 + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, o_u, 0, 0));
+    v[c * 3 + 2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, o_d, 0, 0));
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc += v[i];                    // fixed order: columns ascending (absent: + 0)
+  a.out[p] = acc + (a.bias ? a.bias[0] : 0.f);
+}
+
 // (Round 3 built a one-pass form of this convolution -- gather the 27 neighbours' hidden rows and dot them with w2 in
 //  registers, dz = +-1 terms taken from the adjacent candidate by lane shuffle -- three times: columns walked one after the
 //  other (latency-bound, +0.8 ms per step), all loads independent with index arithmetic per lane (issue-bound, +1.6 ms), index
 //  arithmetic once per row and four lanes per row for coalesced 64-byte loads (+1.1 ms: 1.59 ms on the last level against
 //  0.55 + 0.60 for project + gather).  Moving 9 x 64 B per output through L1 costs more than writing 27 floats per row and
 //  gathering 27 x 4 B: the two-kernel form stays.)
+// one-channel heads over 16 hidden channels: rows from which the z-folded planes are used (negative: never)
+static long long g_thin_z_min_rows = getenv("PCC_THIN_Z_MIN_ROWS") ? atoll(getenv("PCC_THIN_Z_MIN_ROWS")) : (1ll << 20);
+extern "C" int pcc_set_thin_z_min_rows(int64_t rows) { g_thin_z_min_rows = rows; return PCC_OK; }
+
 extern "C" size_t pcc_thin_grid_ws_bytes(int64_t n, int32_t cout) { return (size_t)27 * cout * (size_t)(n > 0 ? n : 1) * sizeof(float) + 256; }
 
 extern "C" int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin, const float* packed_w /*thin layout [27][cout][cin]*/,
@@ -4136,6 +4266,16 @@ extern "C" int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin,
   if (ws_bytes < pcc_thin_grid_ws_bytes(n, cout)) { pcc_set_error("pcc_conv_thin_grid_fwd: workspace too small"); return PCC_EWS; }
   float* t = (float*)ws;
   const int kc = 27 * cout;
+  if (g_thin_z_min_rows >= 0 && cout == 1 && cin == 16 && (size_t)27 * n * 4 <= (size_t)BUF_MAX_BYTES && n >= g_thin_z_min_rows) {
+    // narrow hidden layer over a large set (the last level): z-folded planes, one value per column in the gather
+    k_thin_project_z<16><<<(unsigned)pcc_cdiv(n, 256), 256, (size_t)27 * 16 * sizeof(float), s>>>(
+        feat, (const long long*)keys, n, (long long)h_grid[6], packed_w, t);
+    ThinGridArgs az;
+    az.t = t; az.bias = bias; az.keys = (const long long*)keys; az.g = grid_from_host(bits, rank, h_grid); az.out = out; az.n = n; az.cout = 1;
+    k_thin_gather_grid1z<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(az);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+  }
   switch (cin) {
     case 4: PCC_TRY(launch_project<4>(feat, n, packed_w, kc, t, s)); break;
     case 8: PCC_TRY(launch_project<8>(feat, n, packed_w, kc, t, s)); break;

@@ -57,6 +57,7 @@ SIGNATURES = {
     "pcc_map_to_dense": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_set_mfma_split": (C.c_int, [_i32]),
     "pcc_set_in4_min_rows": (C.c_int, [_i64]),
+    "pcc_set_thin_z_min_rows": (C.c_int, [_i64]),
     "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _i64, _p]),
     "pcc_conv_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),

@@ -615,8 +615,11 @@ static int make_planes_h(ConvArgs& a, hipStream_t s) {
   return PCC_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int MODE>
-__global__ void __launch_bounds__(256, 3) k_conv_mfma_bf(ConvArgs a) {
+// (launch bounds: the 128 x 128 tile needs ~240 registers; capped at 168 for three workgroups per CU it spilled 96 bytes per
+//  thread and reloaded loop-invariant offsets inside the chunk loop.  With two workgroups per CU nothing spills; measured equal
+//  (282 against 287 us on the last hyper-synthesis layer: that launch is bound by its L2 operand traffic).)
+template <int WM, int WN, int TM, int TN, int MODE, int MINWG = (TM * TN >= 4 ? 2 : 3)>
+__global__ void __launch_bounds__(256, MINWG) k_conv_mfma_bf(ConvArgs a) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   static_assert(WM * WN == 4, "4 waves per workgroup");

@@ -787,12 +787,18 @@ struct ExpandCsrArgs {
 // (Scalars, not per-cell arrays: the cells of an axis are consecutive and their offset indices step down by the pitch ratio,
 // so cell j is c0 + j with index i0 - step * j.  Arrays indexed by a loop counter went to scratch memory -- 188 bytes per
 // thread, 2.7 GB of scratch traffic per pass over the last level's 14.5 M rows.)
+// (Scalar members, round 3: as arrays c0[3] / i0[3] / cnt[3] the z entries still went through scratch memory -- a store and a
+//  dependent reload at the top of every thread of the count and fill passes.)
 template <int KS>
 struct CsrCols {
-  int c0[3], i0[3], cnt[3];
+  int c0x, c0y, c0z, i0x, i0y, i0z, nx, ny, nz;
   int step, b;
-  __device__ __forceinline__ int cell(int ax, int j) const { return c0[ax] + j; }
-  __device__ __forceinline__ int idx(int ax, int j) const { return i0[ax] - step * j; }
+  __device__ __forceinline__ int cell(int ax, int j) const { return (ax == 0 ? c0x : ax == 1 ? c0y : c0z) + j; }
+  __device__ __forceinline__ int idx(int ax, int j) const { return (ax == 0 ? i0x : ax == 1 ? i0y : i0z) - step * j; }
+  __device__ __forceinline__ int cnt(int ax) const { return ax == 0 ? nx : ax == 1 ? ny : nz; }
+  __device__ __forceinline__ void set(int ax, int c0, int i0, int n) {
+    if (ax == 0) { c0x = c0; i0x = i0; nx = n; } else if (ax == 1) { c0y = c0; i0y = i0; ny = n; } else { c0z = c0; i0z = i0; nz = n; }
+  }
 };
 
 template <int KS>
@@ -817,26 +823,23 @@ __device__ __forceinline__ void csr_columns(const ExpandCsrArgs& a, long long o,
       c0 = c0 < 0 ? 0 : c0;
       c1 = c1 >= a.in.dims[ax] ? a.in.dims[ax] - 1 : c1;
       const int m = c1 - c0 + 1;
-      c.cnt[ax] = (m > 0 && !(p[ax] & (a.ts_out - 1))) ? m : 0;      // (rows off the output lattice have no source)
-      c.c0[ax] = c0;
-      c.i0[ax] = P + H - 2 * c0;
+      c.set(ax, c0, P + H - 2 * c0, (m > 0 && !(p[ax] & (a.ts_out - 1))) ? m : 0);      // (rows off the output lattice have no source)
     }
     return;
   }
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) {
-    int m = 0;
-    c.c0[ax] = 0; c.i0[ax] = 0;
+    int m = 0, c0 = 0, i0 = 0;
 #pragma unroll
     for (int ia = KS - 1; ia >= 0; --ia) {
       const int rel = p[ax] - (ia - H) * a.ts_out;
       const int cc = rel >> a.in.ts_log2;
       if (rel >= 0 && !(rel & tm) && cc < a.in.dims[ax]) {
-        if (m == 0) { c.c0[ax] = cc; c.i0[ax] = ia; }
+        if (m == 0) { c0 = cc; i0 = ia; }
         ++m;
       }
     }
-    c.cnt[ax] = m;
+    c.set(ax, c0, i0, m);
   }
 }
 
@@ -863,29 +866,39 @@ __global__ void __launch_bounds__(256) k_expand_csr_count(ExpandCsrArgs a) {
   CsrCols<KS> c;
   csr_columns<KS>(a, o, c);
   int total = 0;
-  if (c.b < a.in.nbatch && c.cnt[2] > 0) {
+  if (c.b < a.in.nbatch && c.cnt(2) > 0) {
     // All (x, y) columns at once: a column's z field (<= 4 bits) is cut out of the 64-bit window that starts at the 32-bit
     // word holding its first cell -- it never straddles, so a column is ONE unconditional load (absent columns re-read cell 0
     // and are masked) and the <= 16 loads of a row are in flight together.  (The loop form waited for each column's word.)
     const unsigned* const bits32 = reinterpret_cast<const unsigned*>(a.in.bits);
     const long long cells = (long long)a.in.nbatch * a.in.dims[0] * a.in.dims[1] * a.in.dims[2];
     const long long last_dw = 2 * ((cells + 63) >> 6) - 2;       // last 32-bit word a 64-bit window may start at
-    const unsigned fmask = (1u << c.cnt[2]) - 1u;
-    unsigned long long w[M * M];
-    int sh[M * M];
+    const unsigned fmask = (1u << c.cnt(2)) - 1u;
+    // (cell of column (jx, jy) = cell of column (0, 0) + jx slabs + jy columns: one multiply chain per row, not per column)
+    const long long cell00 = (((long long)c.b * a.in.dims[0] + c.cell(0, 0)) * a.in.dims[1] + c.cell(1, 0)) * a.in.dims[2] + c.cell(2, 0);
+    const long long slab = (long long)a.in.dims[1] * a.in.dims[2];
+    // two x slabs (2 M windows) per trip: 8 loads in flight at 7-wide lists, and half the registers of all 16 at once
+    // (129 VGPRs = 3 waves per SIMD before; the pass is latency-bound, occupancy is what hides it)
+    constexpr int G = M >= 4 ? 2 : M;
+#pragma unroll 1
+    for (int jx0 = 0; jx0 < M; jx0 += G) {
+      unsigned long long w[G * M];
+      int sh[G * M];
 #pragma unroll
-    for (int jx = 0; jx < M; ++jx)
+      for (int gx = 0; gx < G; ++gx)
 #pragma unroll
-      for (int jy = 0; jy < M; ++jy) {
-        const bool ok = jx < c.cnt[0] && jy < c.cnt[1];
-        const long long cell = ok ? (((long long)c.b * a.in.dims[0] + c.cell(0, jx)) * a.in.dims[1] + c.cell(1, jy)) * a.in.dims[2] + c.cell(2, 0) : 0ll;
-        const long long dw = cell >> 5, dw2 = dw < last_dw ? dw : last_dw;
-        sh[jx * M + jy] = ok ? (int)(cell & 31) + 32 * (int)(dw - dw2) : 64;
-        const unsigned lo = bits32[dw2], hi = bits32[dw2 + 1];
-        w[jx * M + jy] = (unsigned long long)lo | ((unsigned long long)hi << 32);
-      }
+        for (int jy = 0; jy < M; ++jy) {
+          const int jx = jx0 + gx;
+          const bool ok = jx < c.cnt(0) && jy < c.cnt(1);
+          const long long cell = ok ? cell00 + jx * slab + (long long)jy * a.in.dims[2] : 0ll;
+          const long long dw = cell >> 5, dw2 = dw < last_dw ? dw : last_dw;
+          sh[gx * M + jy] = ok ? (int)(cell & 31) + 32 * (int)(dw - dw2) : 64;
+          const unsigned lo = bits32[dw2], hi = bits32[dw2 + 1];
+          w[gx * M + jy] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        }
 #pragma unroll
-    for (int i = 0; i < M * M; ++i) total += sh[i] < 64 ? __popc((unsigned)(w[i] >> (sh[i] & 63)) & fmask) : 0;
+      for (int i = 0; i < G * M; ++i) total += sh[i] < 64 ? __popc((unsigned)(w[i] >> (sh[i] & 63)) & fmask) : 0;
+    }
   }
   a.first[o] = total;
   if (o == a.n_out - 1) a.first[a.n_out] = 0;         // the scan runs over n_out + 1 entries (its last output = the pair total)
@@ -896,7 +909,7 @@ template <int KS, typename F>
 __device__ __forceinline__ void csr_probe(const ExpandCsrArgs& a, long long o, F&& on_hit) {
   CsrCols<KS> c;
   csr_columns<KS>(a, o, c);
-  if (c.b >= a.in.nbatch || c.cnt[2] == 0) return;
+  if (c.b >= a.in.nbatch || c.cnt(2) == 0) return;
   // The y columns of one x slab together (round 3): per column the aligned 64-bit word of its first cell, the 32 bits after it
   // (a field of <= 4 bits never reaches past them) and the word's rank -- three unconditional loads, absent columns re-read
   // cell 0 and are masked -- so a slab's <= 12-15 loads are in flight at once.  (The column-by-column loop waited for each
@@ -905,16 +918,18 @@ __device__ __forceinline__ void csr_probe(const ExpandCsrArgs& a, long long o, F
   const unsigned* const bits32 = reinterpret_cast<const unsigned*>(a.in.bits);
   const long long cells = (long long)a.in.nbatch * a.in.dims[0] * a.in.dims[1] * a.in.dims[2];
   const long long last_w = ((cells + 63) >> 6) - 1;
-  const unsigned fmask = (1u << c.cnt[2]) - 1u;
+  const unsigned fmask = (1u << c.cnt(2)) - 1u;
   const int kzs = a.zk ? 1 : KS * KS;
-  for (int jx = 0; jx < c.cnt[0]; ++jx) {
+  const long long cell00 = (((long long)c.b * a.in.dims[0] + c.cell(0, 0)) * a.in.dims[1] + c.cell(1, 0)) * a.in.dims[2] + c.cell(2, 0);
+  const long long slab = (long long)a.in.dims[1] * a.in.dims[2];
+  for (int jx = 0; jx < c.cnt(0); ++jx) {
     unsigned long long w0[MY];
     unsigned nx[MY];
     int rk[MY], sh[MY];
 #pragma unroll
     for (int jy = 0; jy < MY; ++jy) {
-      const bool ok = jy < c.cnt[1];
-      const long long cell = ok ? (((long long)c.b * a.in.dims[0] + c.cell(0, jx)) * a.in.dims[1] + c.cell(1, jy)) * a.in.dims[2] + c.cell(2, 0) : 0ll;
+      const bool ok = jy < c.cnt(1);
+      const long long cell = ok ? cell00 + jx * slab + (long long)jy * a.in.dims[2] : 0ll;
       const long long wi = cell >> 6;
       sh[jy] = ok ? (int)(cell & 63) : 64;
       w0[jy] = a.in.bits[wi];

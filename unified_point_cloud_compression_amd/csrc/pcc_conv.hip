@@ -3139,7 +3139,10 @@ struct PairReduceArgs {
   const float* T; const float* bias; const int* pos; float* out; long long n_out; int K, cout, act; float slope; int lpr_log2;
 };
 
-// LPR lanes per output row, 4 channels per lane and pass; pair rows of JB offsets loaded independently
+// LPR lanes per output row, 4 channels per lane and pass; pair rows of JB offsets loaded independently.
+// (Round 3: a form that fetches a row's K position entries side by side, finds the present ones by ballot and walks only those
+//  in batches of 8 product loads measured the same 117 us per launch: with 8 waves per SIMD the empty offsets' round trips are
+//  hidden, the kernel runs at the rate its T reads allow -- 3.7 TB/s.  Not kept.)
 __global__ void __launch_bounds__(256) k_pair_reduce(PairReduceArgs a) {
   constexpr int JB = 5;
   const int lane = threadIdx.x & 63;

@@ -46,6 +46,7 @@ struct ConvArgs {
   int ksplit = 1;                       // split path, map mode: the (offset, channel-block) reduction cut over ksplit workgroups
   float* part = nullptr;                //   partial tiles [ksplit][n_out][cout], summed in fixed order by k_splitk_reduce
   int dbg = 0;                          // diagnostics (env PCC_DBG): 1 = no output stores, 2 = no MFMA phase, 4 = no staging loads
+  int nt = 0;                           // non-temporal accesses of streamed buffers (g_nt): 1 = dense products' stores, 2 = pair products' stores
   bool wh_ok = false;                   // dense products: the pack carries scaled fp16 planes + column scales (split_planes_h)
   const unsigned char* feath = nullptr; //   scaled fp16 planes of feat, [n_in][cin/32][2][32] (k_feat_split_h)
   const float* frow_inv = nullptr;      //   and 1 / (power-of-two scale) of every feature row
@@ -1049,7 +1050,8 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float v = acc[i][j][e];          // (a bit_cast of the vector element itself compiles to element 0)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
+          if (a.nt & 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 2);   // non-temporal, as k_gemm_h2
+          else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
         }
       }
     return;
@@ -1466,6 +1468,10 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
       obase, (short)0, (int)(((unsigned)(npos - 1) * ncol + min((unsigned)BN, ncol - (unsigned)colblock)) * 4u), 0x00020000);
   const unsigned vO = ((unsigned)(wm * 64 + 4 * half) * ncol + (unsigned)(wn * 64 + r31)) * 4u;
   const bool full = npos == BM && (unsigned)colblock + BN <= ncol;
+  // The product buffer is written once and read back by the gather-sum long after it left the caches (5 GB per level):
+  // non-temporal stores keep it from evicting the operands this kernel re-reads from L2 (round 3: 3.4 -> 4.2 TB/s of
+  // algorithmic traffic on the composite levels, decode -0.6 ms; PCC_NT bit 0).
+  const bool nt = (a.nt & 1) != 0;
   const int row_lim = npos - wm * 64 - 4 * half;
   const int col_lim = (int)ncol - colblock - wn * 64 - r31;
   float guard_mr = 0.f;
@@ -1484,7 +1490,9 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float v = acc[i][j][e] * (rr[e1] * cs[j]);
-          if (full) {
+          if (full && nt) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 2);
+          } else if (full) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
           } else {                                           // last row tile / column block: invalid elements go out of range
             const unsigned off = (rrow < row_lim && j * 32 < col_lim) ? vO + (unsigned)j * 128u + so : BUF_OOB;
@@ -1620,7 +1628,9 @@ __global__ void __launch_bounds__(256, 3) k_pair_h2(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float v = acc[i][j][e] * (rr[e1] * cs[j]);
-          if (full) {
+          if (full && (a.nt & 2)) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 2);
+          } else if (full) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
           } else {
             const unsigned off = (j * 32 < col_lim) ? vO + (unsigned)j * 128u + so : BUF_OOB;
@@ -2558,6 +2568,9 @@ static bool g_gemm_persistent = getenv("PCC_GEMM_PERSISTENT") ? atoi(getenv("PCC
 static bool g_splitk_tiles = getenv("PCC_SPLITK_TILES") ? atoi(getenv("PCC_SPLITK_TILES")) != 0 : true;
 static int g_gemm2 = getenv("PCC_GEMM2") ? atoi(getenv("PCC_GEMM2")) : 1;       // 0: general kernel, 1: stripped dense-GEMM kernel
 static int g_dbg = getenv("PCC_DBG") ? atoi(getenv("PCC_DBG")) : 0;
+// non-temporal accesses of the streamed multi-GB buffers (bit 0 dense products' stores, 1 pair products' stores, 2 gather-sum
+// product loads, 3 gather-sum output stores, 4 projection-plane stores, 5 projection-plane gathers); env PCC_NT
+static int g_nt = getenv("PCC_NT") ? atoi(getenv("PCC_NT")) : 1;
 
 // persistent GEMM form (identity rows or pair lists; a.featb set): 2 workgroups per CU (the kernel needs ~200 VGPRs)
 template <int MODE>
@@ -2615,6 +2628,8 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
       (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8)) {      // (caller's planes: the caller chose the form)
     if (!a.feath) PCC_TRY(make_planes_h(a, s));
     a.dbg = g_dbg;
+  a.nt = g_nt;
+    a.nt = g_nt;
     const dim3 g2 = grid(128);
     prof_note(PCC_FORM_GEMM_H2, 2.0 * a.n_out * a.cin * a.cout, 4.0 * ((double)a.n_out * a.cin + (double)a.n_out * a.cout + (double)a.cin * a.cout));
     switch (a.ppo) {
@@ -2641,6 +2656,7 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
     if (ksplit > 1) { a.ksplit = ksplit; a.part = (float*)((char*)p + plane_bytes); }
   }
   a.dbg = g_dbg;
+  a.nt = g_nt;
   ksplit_grid = a.ksplit;
   if (split && !a.hdr && g_gemm_persistent) return launch_gemm_bf<MODE>(a, s);
   // plain dense products (generative transposed convolutions): the stripped GEMM kernel
@@ -3608,12 +3624,26 @@ __global__ void k_presence_tables(const float* __restrict__ ex_bias, int cout, f
   tab[t] = sum;
 }
 
+// non-temporal accesses of HIP's vector structs (the builtins take native vector types)
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load(const float4* p) {
+  const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float nt_load(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void nt_store(const float4& v, float4* p) {
+  const f32x4n w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<f32x4n*>(p));
+}
+__device__ __forceinline__ void nt_store(float v, float* p) { __builtin_nontemporal_store(v, p); }
+
 struct GatherCsrArgs {
   const float* T; const float* bias; const int* first; const int* pair_ids;
   float* out; long long n_out; int cout, act; float slope; int lpr_log2;
   const int* ex_nbr; const float* ex_bias; int ex_K;      // optional: + sum over the existing neighbours k of ex_bias[k]
   const float* ex_tab;                                    //   as subset-sum tables [4][128][cout] over 7+7+7+6 neighbour bits (k_presence_tables)
   PccGrid ex_grid; const long long* out_keys;             //   presence flags from a [K][n_out] table (ex_nbr) or the set's grid index
+  int nt;                                                 // g_nt: 4 = non-temporal product loads, 8 = non-temporal output stores
 };
 
 template <int VEC, int JB>
@@ -3702,8 +3732,13 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
 #pragma unroll
       for (int u = 0; u < JB; ++u) pid[u] = a.pair_ids[min(t + u, t1 - 1)];
       VT x[JB];
+      if (a.nt & 4) {
 #pragma unroll
-      for (int u = 0; u < JB; ++u) x[u] = reinterpret_cast<const VT*>(a.T + (long long)pid[u] * a.cout)[cv];
+        for (int u = 0; u < JB; ++u) x[u] = nt_load(reinterpret_cast<const VT*>(a.T + (long long)pid[u] * a.cout) + cv);
+      } else {
+#pragma unroll
+        for (int u = 0; u < JB; ++u) x[u] = reinterpret_cast<const VT*>(a.T + (long long)pid[u] * a.cout)[cv];
+      }
 #pragma unroll
       for (int u = 0; u < JB; ++u) thin_fma(acc, x[u], (t + u < t1) ? 1.f : 0.f);     // fixed order: pair id ascending
     }
@@ -3720,7 +3755,8 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
     if (a.bias) b = reinterpret_cast<const VT*>(a.bias)[cv];
     thin_acc(acc, b);
     thin_act(acc, a.act, a.slope);
-    reinterpret_cast<VT*>(a.out + o * a.cout)[cv] = acc;
+    if (a.nt & 8) nt_store(acc, reinterpret_cast<VT*>(a.out + o * a.cout) + cv);
+    else reinterpret_cast<VT*>(a.out + o * a.cout)[cv] = acc;
   }
 }
 
@@ -3761,7 +3797,7 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
   }
   GatherCsrArgs g;
   g.T = T; g.bias = bias; g.first = first; g.pair_ids = pair_ids; g.out = out; g.n_out = n_out; g.cout = cout;
-  g.act = act; g.slope = slope; g.ex_nbr = ex_nbr; g.ex_bias = ex_bias; g.ex_K = ex_K;
+  g.act = act; g.slope = slope; g.ex_nbr = ex_nbr; g.ex_bias = ex_bias; g.ex_K = ex_K; g.nt = g_nt;
   g.ex_grid.bits = nullptr; g.out_keys = nullptr;
   if (ex_grid) { g.ex_grid = *ex_grid; g.out_keys = ex_keys; g.ex_nbr = nullptr; }
   g.ex_tab = nullptr;

@@ -1050,7 +1050,7 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float v = acc[i][j][e];          // (a bit_cast of the vector element itself compiles to element 0)
-          if (a.nt & 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 2);   // non-temporal, as k_gemm_h2
+          if ((a.nt & 1) && NCH >= 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 2);   // non-temporal, as k_gemm_h2
           else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 0);
         }
       }
@@ -1471,7 +1471,9 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
   // The product buffer is written once and read back by the gather-sum long after it left the caches (5 GB per level):
   // non-temporal stores keep it from evicting the operands this kernel re-reads from L2 (round 3: 3.4 -> 4.2 TB/s of
   // algorithmic traffic on the composite levels, decode -0.6 ms; PCC_NT bit 0).
-  const bool nt = (a.nt & 1) != 0;
+  // (32-deep products have hardly any operand to protect, and as a pure stream non-temporal stores are the slower ones --
+  //  4.2 against 5.0 TB/s, tools/gemm_nt_probe.sh: the hint is taken from 64 input channels on; PCC_NT bit 6 forces it.)
+  const bool nt = (a.nt & 1) != 0 && (NCH >= 2 || (a.nt & 64));
   const int row_lim = npos - wm * 64 - 4 * half;
   const int col_lim = (int)ncol - colblock - wn * 64 - r31;
   float guard_mr = 0.f;

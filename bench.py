@@ -456,12 +456,13 @@ def main():
                 step(model, pc, q, **kw)
             d, te, _, _, _ = timed_loop(n, **kw)
             return d / n * 1e3, (d - te) / n * 1e3
-        lib.call("pcc_set_gemm_h", 0)
-        strict_ms, _ = quick()
-        lib.call("pcc_set_mfma_split", 0)
-        fp32_ms, _ = quick()
-        lib.call("pcc_set_mfma_split", 1)
-        lib.call("pcc_set_gemm_h", 1)
+        try:
+            lib.ARITH_FORCE = lib.ARITH_BF6               # (process-wide diagnostic override: encoder and decoder alike)
+            strict_ms, _ = quick()
+            lib.ARITH_FORCE = lib.ARITH_F32
+            fp32_ms, _ = quick()
+        finally:
+            lib.ARITH_FORCE = None
         _, cached_dec_ms = quick(reuse_encoder_sets=True)     # round-2 figure: decoder re-using the encoder's sets and maps
 
     # auxiliary (un-timed for `value`): the same step with integer symbols handed across the entropy-coder boundary,
@@ -505,7 +506,7 @@ def main():
               "d1_psnr_BA": m["BA_psnr_mse"], "y_psnr_sym": m["sym_y_psnr"], "oracle": oracle_figures(args.bits)}
 
     if rank == 0:
-        split_on = os.environ.get("PCC_MFMA_SPLIT", "1") != "0"
+        split_on = lib.ARITH_DEFAULT != lib.ARITH_F32
         ms_step = dt_max / args.steps * 1e3
         # ---- roofline: per kernel form, from the event-timed pass; the DOMINANT kernel is the form with the most time ----
         kernels = {}

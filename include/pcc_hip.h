@@ -178,7 +178,7 @@ int64_t pcc_convt_rows_t_elems(int64_t pairs, int32_t K, int32_t cout);
 int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias,
                        int32_t K, int32_t cout, const int32_t* first, const int32_t* pair_ids, int64_t n_out,
                        int64_t pairs, float* T, float* out, int32_t act, float slope, void* int_ws, size_t int_ws_bytes,
-                       void* stream);
+                       int32_t arith /*PCC_ARITH_*, see the convolution section*/, int32_t* d_guard /*nullable*/, void* stream);
 /* conv-form map (one segment, nbr[k*n_out + o] = input row or -1) from CSR pair lists: evaluates a transposed conv on a
  * subset of its output rows with pcc_conv_fwd / pcc_conv_fwd_pairs.  hdr: PCC_MAP_HDR_INTS ints, nbr: K*n_out ints. */
 int pcc_map_from_csr(const int32_t* first, const int32_t* pair_ids, int64_t n_out, int32_t kernel_size, int32_t* hdr,
@@ -205,10 +205,26 @@ int pcc_map_to_dense(const int32_t* hdr, const int32_t* nbr, const int32_t* rows
  *  model/transforms.py:33-43,127-166; model/entropy_models.py:178-190.)
  * Weights are consumed in a packed layout produced once per parameter update.
  * ---------------------------------------------------------------------------------------- */
-/* MFMA-path arithmetic: 1 (default; env PCC_MFMA_SPLIT) evaluates every fp32 product on the bf16 matrix pipe from an
- * exact three-way bf16 split of both operands (six cross terms, fp32 accumulation: fp32 accuracy at 2.67x the fp32-MFMA
- * rate); 0 selects the fp32-input MFMA kernels.  Process-wide switch (tests compare both). */
-int pcc_set_mfma_split(int32_t on);
+/* MFMA-path arithmetic is an ARGUMENT of every convolution entry point (`arith`), never process state: two threads, or the
+ * encoder and the decoder of one process, may use different forms at the same time, and a caller that must reproduce a result
+ * bit for bit elsewhere (the hyper-synthesis h_s, whose scales / means select the rANS table rows on both sides:
+ * model/entropy_models.py:371-400,438-484) names the form it was produced in.
+ *   PCC_ARITH_F32  fp32-input MFMA instructions only (v_mfma_f32_32x32x2_f32);
+ *   PCC_ARITH_BF6  every fp32 product on the bf16 matrix pipe from an exact three-way bf16 split of both operands (six cross
+ *                  terms, fp32 accumulation: 24 bits per element, no range condition, 2.67x the fp32-MFMA rate);
+ *   PCC_ARITH_H3   as BF6 for the gathered 3x3x3 convolutions and GDN; the products whose output row depends on ONE input row
+ *                  (dense products of the generative transposed convolutions, pair-list GEMMs) as row / column-scaled fp16
+ *                  pairs, three MFMA terms, under the range guard below.
+ * Range guard of the three-term form.  The form carries every element within 2^-18 of its row / column
+ * maximum to >= 22 bits and smaller ones with an absolute error of 2^-28 of that maximum, so a product of depth cin is off by
+ * at most cin * 2^-27 * max|row| * max|column| beyond fp32 behaviour.  With `d_guard` non-NULL every fp16-pair launch of the
+ * call ORs 1 into *d_guard (device int32, zeroed by the caller) when the scales of one of its tiles admit more than
+ * PCC_H_GUARD_BUDGET (absolute, in output units); the caller reads the word with a size it reads anyway and repeats THAT call
+ * with PCC_ARITH_BF6.  d_guard is ignored by the other two forms. */
+#define PCC_ARITH_F32 0
+#define PCC_ARITH_BF6 1
+#define PCC_ARITH_H3 2
+#define PCC_H_GUARD_BUDGET 2.5e-5f   /* a quarter of the 1e-4 parity bar: max|row| * max|column| > 26 at cin = 128 */
 /* 4-channel inputs (the codec's first layer, 4 -> 128, 5x5x5, stride 2): from `rows` output rows on, the (offset, channel)
  * pairs are flattened into one reduction axis and the convolution runs in 32-wide chunks of 8 offsets on the six-term bf16
  * form (default 65536; env PCC_IN4_MIN_ROWS; negative: never).  Tests lower it to reach the path on small inputs. */
@@ -217,16 +233,6 @@ int pcc_set_in4_min_rows(int64_t rows);
  * the projection pass pre-adds a column's three z terms for the middle row and the gather reads one value per (dx, dy) column
  * (default 2^20; env PCC_THIN_Z_MIN_ROWS; negative: never).  Tests lower it to reach the path on small inputs. */
 int pcc_set_thin_z_min_rows(int64_t rows);
-/* dense products of the generative transposed convolutions in scaled fp16 pairs (three MFMA terms; default on) or the
- * six-term bf16 form (0); both at fp32 accuracy, tests/test_gpu_map_conv.py::test_dense_products_accuracy. */
-int pcc_set_gemm_h(int32_t on);
-/* Range guard of the three-term fp16 form.  The form carries every element within 2^-18 of its row /
- * column maximum to >= 22 bits and smaller ones with an absolute error of 2^-28 of that maximum, so a product of depth cin is
- * off by at most cin * 2^-27 * max|row| * max|column| beyond fp32 behaviour.  With a guard word set, every fp16-pair launch
- * ORs 1 into *d_flag (device int32, zeroed by the caller) when the scales of one of its tiles admit more than `budget`
- * (absolute, in output units); the caller reads the word with a size it reads anyway and repeats the operation under
- * pcc_set_gemm_h(0) (six-term bf16 form: 24 bits per element, no range condition).  NULL switches the guard off. */
-int pcc_set_h_guard(int32_t* d_flag, float budget);
 int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
 /* W: ME layout [K, cin, cout] row-major (state_dict `kernel`).  packed_cap: floats available at
  * `packed`; a buffer smaller than pcc_conv_packed_elems(K, cin, cout) is refused (PCC_EWS), never written past. */
@@ -256,7 +262,7 @@ int pcc_band_tiles_build(const int64_t* keys, int64_t n, int32_t lo_x, int32_t n
 int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                  const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* hdr,
                  const int32_t* nbr, const int32_t* rows, int64_t n_out, float* out, int32_t act,
-                 float slope, void* ws, size_t ws_bytes, void* stream);
+                 float slope, void* ws, size_t ws_bytes, int32_t arith, int32_t* d_guard /*nullable*/, void* stream);
 /* Pair-list form of the same convolution for maps with mostly empty (offset, row) slots (5x5x5 kernels on surfaces):
  * the pairs of each offset are compacted and padded to 128-pair tiles, T[p] = feat[in(p)] @ W[k(p)] runs as a gathered
  * GEMM in which every MFMA row is a real pair, and out[o] = act(bias + sum_k T[pos(k,o)]) is summed in ascending k.
@@ -273,7 +279,7 @@ int pcc_pair_plan_fill(const int32_t* nbr, const int32_t* pos, const int32_t* ps
 int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias,
                        int32_t K, int32_t cout, const int32_t* pair_in, const int32_t* tile_k, const int64_t* d_info,
                        int64_t padded_pairs, const int32_t* pos, int64_t n_out, float* T, float* out, int32_t act,
-                       float slope, void* stream);
+                       float slope, int32_t arith, int32_t* d_guard /*nullable*/, void* stream);
 
 
 /* a3  generative transposed convolution, input stationary (ME.MinkowskiGenerativeConvolutionTranspose forward:
@@ -287,14 +293,14 @@ int pcc_convt_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout,
 int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                   const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* hdr,
                   const int32_t* nbr, const int32_t* rows, int64_t n_out, float* T, float* out, int32_t act,
-                  float slope, void* stream);
+                  float slope, int32_t arith, int32_t* d_guard /*nullable*/, void* stream);
 
 /* same with the CSR pair lists of pcc_coords_expand_csr (row pair_id of T); outputs in canonical row order */
 int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                       const float* bias /*nullable [cout]*/, int32_t K, int32_t cout, const int32_t* first,
                       const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
                       const int32_t* ex_nbr /*nullable [ex_K][n_out]*/, int32_t ex_K,
-                      const float* ex_bias /*[ex_K][cout]*/, void* stream);
+                      const float* ex_bias /*[ex_K][cout]*/, int32_t arith, int32_t* d_guard /*nullable*/, void* stream);
 
 /* pcc_convt_fwd_csr with the constant-per-existing-neighbour term (ex_bias [27][cout]) keyed on the OUTPUT set's own grid
  * index (out_keys + pcc_grid_build arrays) instead of a [27][n_out] neighbour table; and a 3x3x3 convolution to <= 4 channels
@@ -303,7 +309,8 @@ int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const flo
 int pcc_convt_fwd_csr_grid(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias /*nullable*/,
                            int32_t K, int32_t cout, const int32_t* first, const int32_t* pair_ids, int64_t n_out, float* T,
                            float* out, int32_t act, float slope, const int64_t* out_keys, const uint64_t* out_bits,
-                           const int32_t* out_rank, const int32_t* h_out, const float* ex_bias, void* stream);
+                           const int32_t* out_rank, const int32_t* h_out, const float* ex_bias, int32_t arith,
+                           int32_t* d_guard /*nullable*/, void* stream);
 /* Chunked form of pcc_convt_fwd_csr for 7x7x7 composite levels: the per-pair products never exist as a whole.  Parent rows
  * are processed in chunks whose products fit the Infinity Cache (pcc_set_t_chunk_bytes, default 96 MiB; env PCC_T_CHUNK_MIB):
  * GEMM chunk -> staging buffer T (pcc_convt_chunk_t_bytes) -> ordered gather-sum of the children that chunk reaches, partial
@@ -318,7 +325,8 @@ int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int32_t cin, c
                               const int64_t* in_keys, const int64_t* out_keys, int32_t ts_out, float* T, size_t t_bytes,
                               float* out, int32_t act, float slope, const uint64_t* out_bits /*nullable*/,
                               const int32_t* out_rank /*nullable*/, const int32_t* h_out /*nullable*/,
-                              const float* ex_bias /*nullable*/, void* ws, size_t ws_bytes, void* stream);
+                              const float* ex_bias /*nullable*/, void* ws, size_t ws_bytes, int32_t arith,
+                              int32_t* d_guard /*nullable*/, void* stream);
 size_t pcc_thin_grid_ws_bytes(int64_t n, int32_t cout);
 int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin, const float* packed_w, const float* bias /*nullable*/,
                            int32_t cout, const int64_t* keys, const uint64_t* bits, const int32_t* rank, const int32_t* h_grid,
@@ -333,7 +341,7 @@ int64_t pcc_gdn_packed_elems(int32_t c);
 int pcc_gdn_pack(const float* beta_raw, const float* gamma_raw, int32_t c, float beta_min,
                  float* packed, int64_t packed_cap, float* beta_eff, void* stream);
 int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* packed, const float* beta_eff,
-                int32_t inverse, float* out, void* stream);
+                int32_t inverse, float* out, int32_t arith, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Frame intake and hand-over of UnifiedModel.compress / decompress (model/model.py:141-161, 240-250), one launch each.

@@ -60,7 +60,7 @@ int main() {
   PCC_CALL(pcc_conv_pack_weights(d_W, 1, cin, cout, d_P, pe, stream));
   const size_t cws = pcc_conv_ws_bytes(m, 1, cin, cout);
   void* d_cws; HIP_OK(hipMalloc(&d_cws, cws));
-  PCC_CALL(pcc_conv_fwd(d_X, m, cin, d_P, d_B, 1, cout, nullptr, nullptr, nullptr, m, d_Y, PCC_ACT_RELU, 0.f, d_cws, cws, stream));
+  PCC_CALL(pcc_conv_fwd(d_X, m, cin, d_P, d_B, 1, cout, nullptr, nullptr, nullptr, m, d_Y, PCC_ACT_RELU, 0.f, d_cws, cws, PCC_ARITH_H3, nullptr, stream));
   HIP_OK(hipStreamSynchronize(stream));
   HIP_OK(hipMemcpy(Y.data(), d_Y, Y.size() * 4, hipMemcpyDeviceToHost));
   double worst = 0;

@@ -217,6 +217,18 @@ def test_deterministic_bitwise():
     ra = model.decompress(coordinates=a[3], strings=a[0], shape=a[1], k=a[2], q_vals=a[4])
     rb = model.decompress(coordinates=b[3], strings=b[0], shape=b[1], k=b[2], q_vals=b[4])
     assert torch.equal(ra, rb)
+    # the range-guard fallback (g_a / g_s in the six-term form, hyper-synthesis pinned): the symbols of the hyper-prior path
+    # do not move, the fallback is itself deterministic, and a stream coded under it decodes under the default form
+    from unified_point_cloud_compression_amd import lib as L
+    with L.arith_scope(L.ARITH_BF6):
+        c = model.compress(pc, q)
+        d = model.compress(pc, q)
+        rc = model.decompress(coordinates=c[3], strings=c[0], shape=c[1], k=c[2], q_vals=c[4])
+    assert torch.equal(c[0][0][0], d[0][0][0]) and torch.equal(c[0][0][1], d[0][0][1])
+    rd = model.decompress(coordinates=c[3], strings=c[0], shape=c[1], k=c[2], q_vals=c[4])     # decoder in the default form
+    with L.arith_scope(L.ARITH_BF6):
+        assert torch.equal(rc, model.decompress(coordinates=d[3], strings=d[0], shape=d[1], k=d[2], q_vals=d[4]))
+    assert rd.shape == rc.shape and torch.equal(rd[:, :3], rc[:, :3])                          # same geometry either way
 
 
 def count_bits(strings):

@@ -37,14 +37,10 @@ def _dense(x, w, arithmetic):
     W = torch.nn.Parameter(t(np.ascontiguousarray(w.reshape(cin, K, cout).transpose(1, 0, 2))))
     first = torch.arange(0, rows * K + 1, dtype=torch.int32, device=dev())
     pair_ids = torch.arange(0, rows * K, dtype=torch.int32, device=dev())
-    L.call("pcc_set_gemm_h", 1 if arithmetic == "h" else 0)
-    L.call("pcc_set_mfma_split", 0 if arithmetic == "f32" else 1)
-    try:
+    form = {"h": L.ARITH_H3, "bf": L.ARITH_BF6, "f32": L.ARITH_F32}[arithmetic]
+    with L.arith_scope(form):
         pk = S.PackedConv(True).get(W)
         got = S.convt_forward_csr(t(x), pk, None, K, cin, cout, (first, pair_ids), rows * K)
-    finally:
-        L.call("pcc_set_gemm_h", 1)
-        L.call("pcc_set_mfma_split", 1)
     return n(got).reshape(rows, ncol).astype(np.float64)
 
 
@@ -148,46 +144,137 @@ def test_range_guard_trips_exactly_when_the_scales_admit_more_than_the_budget():
     assert int(guard.item()) == 0
 
 
-def test_codec_repeats_a_call_in_the_six_term_form_when_the_guard_trips():
-    """End to end: scale one layer's weights so that its products leave the guarded range.  `decompress` must notice (no
-    extra host read: the flag travels with the deferred status check), run again under pcc_set_gemm_h(0) and return what a
-    six-term run returns -- bit for bit."""
+def _spread_model(coder="pcc_streams"):
+    """R2 architecture, random weights, with the last hyper-synthesis layer rescaled so that the predicted scales spread over
+    the whole scale table (random weights alone leave every sigma below the 0.11 bound: all indexes 0, nothing could flip)."""
     import copy
     from oracle import codec
     from tests.util import load_params
-    from unified_point_cloud_compression_amd import lib as L, synth
     from unified_point_cloud_compression_amd.model import UnifiedModel
     cfg = copy.deepcopy(codec.R2_CONFIG)
     P = codec.random_params(cfg, 0, gain=3.0)
     mcfg = copy.deepcopy(cfg)
-    mcfg["entropy_model"]["entropy_coder"] = "pcc_streams"
+    mcfg["entropy_model"]["entropy_coder"] = coder
     model = load_params(UnifiedModel(mcfg), P).to(dev()).eval()
     with torch.no_grad():
-        model.g_s.up_2[1].kernel.mul_(1024.0)               # level-2 up-sampling: max|row| * max|column| ~ 4 * 24 = 100 > 26
-        model.g_s.predict_2[0].kernel.mul_(1.0 / 1024.0)    # (keeps the level's logits in range)
+        last = model.entropy_model.h_s[4]
+        c = last.out_channels // 2
+        last.kernel[..., :c].mul_(3.0e2)                     # scales half: |sigma| from ~0 to a few tens
+        last.bias[..., :c].add_(0.5)
+    return model
+
+
+class _Tap:
+    """Records what the conditional model saw on each side: SHA of scales|means, the table indexes, the symbols."""
+
+    def __init__(self, model):
+        import hashlib
+        self.gc = model.entropy_model.gaussian_conditional
+        self.enc, self.dec = {}, {}
+        gc, sha = self.gc, lambda x: hashlib.sha256(x.detach().cpu().numpy().tobytes()).hexdigest()
+        self._orig = (gc.encode_rows, gc.index_rows, gc.decompress_rows)
+
+        def encode_rows(y, params, keys=None, gain=None, **kw):
+            out = self._orig[0](y, params, keys, gain, **kw)
+            if y is not None:                                # (index_rows goes through encode_rows with y = None)
+                self.enc = {"params": sha(params), "idx": out[1].clone(), "sym": out[0].clone()}
+            return out
+
+        def index_rows(params, keys=None, gain=None):
+            idx = self._orig[1](params, keys, gain)
+            self.dec["params"], self.dec["idx"] = sha(params), idx.clone()
+            return idx
+
+        def decompress_rows(*a, **kw):
+            sym = self._orig[2](*a, **kw)
+            self.dec["sym"] = sym.clone()
+            return sym
+        gc.encode_rows, gc.index_rows, gc.decompress_rows = encode_rows, index_rows, decompress_rows
+
+    def close(self):
+        self.gc.encode_rows, self.gc.index_rows, self.gc.decompress_rows = self._orig
+
+
+def _count_fallbacks(L):
+    """Spy on `arith_scope`: how many un-pinned six-term scopes (= range-guard fallbacks) were entered."""
+    seen = []
+    orig = L.arith_scope.__enter__
+
+    def enter(self):
+        if self.form == L.ARITH_BF6 and not self.pinned:
+            seen.append(1)
+        return orig(self)
+    L.arith_scope.__enter__ = enter
+    return seen, lambda: setattr(L.arith_scope, "__enter__", orig)
+
+
+@pytest.mark.parametrize("side", ["encoder", "decoder", "neither"])
+def test_guard_trip_on_one_side_only_keeps_encoder_and_decoder_in_step(side):
+    """VERDICT r3 item 1.  The range-guard fallback re-runs g_a (encoder) or g_s (decoder) in the six-term form; the
+    hyper-synthesis, whose scales / means select the rANS table rows on BOTH sides, is pinned to one form, so a trip on one
+    side only cannot desynchronise the streams.  Weights chosen so that the indexes span >= 30 table rows; byte strings go
+    through the GPU stream coder; the decoder must see the encoder's scales|means bit for bit (SHA), the same indexes and
+    decode the encoder's symbols.  Reference contract: `model/entropy_models.py:371-400,438-484`."""
+    from unified_point_cloud_compression_amd import lib as L, synth
+    model = _spread_model()
+    with torch.no_grad():
+        if side == "encoder":
+            model.g_a.down_conv_2[0].kernel.mul_(4096.0)         # pair-list 5x5x5 products: max|row| * max|column| far above 26
+            model.g_a.down_conv_2[0].bias.mul_(4096.0)
+            model.g_a.down_conv_2[1].beta.mul_(64.0)             # GDN: beta' = 4096 beta (beta = param^2 - 2^-36), so that
+            #                                                      x' / (beta' + gamma |x'|) = x / (beta + gamma |x|): the
+            #                                                      latents, hence the decoder's operands, keep their range
+        elif side == "decoder":
+            model.g_s.up_2[1].kernel.mul_(1024.0)                # level-2 up-sampling (today's case): ~100 > 26
+            model.g_s.predict_2[0].kernel.mul_(1.0 / 1024.0)     # (keeps the level's logits in range)
     model.update()
     pc = torch.from_numpy(synth.surface_cloud(0, 8)).to(dev())
     q = torch.tensor([[0.5, 0.5]], device=dev())
-    out = model.compress(pc, q)
-    calls = []
-    orig = L.call
-
-    def spy(name, *a):
-        if name == "pcc_set_gemm_h":
-            calls.append(a[0])
-        return orig(name, *a)
-    L.call = spy
+    tap = _Tap(model)
+    seen, restore = _count_fallbacks(L)
     try:
+        out = model.compress(pc, q)
+        enc_fallbacks = len(seen)
+        enc = dict(tap.enc)
         rec = model.decompress(coordinates=[c.clone() for c in out[3]], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
+        dec_fallbacks = len(seen) - enc_fallbacks
+        # the same decode with EVERY product of g_s forced to the six-term form: what the fallback must reproduce bit for bit
+        with L.arith_scope(L.ARITH_BF6):
+            ref = model.decompress(coordinates=[c.clone() for c in out[3]], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
     finally:
-        L.call = orig
-    assert calls == [0, 1], calls                            # tripped once, repeated in the six-term form, switched back
-    L.call("pcc_set_gemm_h", 0)
+        restore()
+        tap.close()
+    assert (enc_fallbacks, dec_fallbacks) == {"encoder": (1, 0), "decoder": (0, 1), "neither": (0, 0)}[side], (enc_fallbacks, dec_fallbacks)
+    rows = torch.unique(enc["idx"]).numel()
+    assert rows >= 30, f"indexes span only {rows} table rows: the test cannot see a flipped index"
+    assert enc["params"] == tap.dec["params"], "scales|means differ between encoder and decoder"
+    assert torch.equal(enc["idx"], tap.dec["idx"])
+    assert torch.equal(enc["sym"], tap.dec["sym"]), "the decoder did not reproduce the encoder's y symbols"
+    if side == "decoder":
+        assert torch.equal(rec, ref)                             # fallback == a six-term run of g_s, bit for bit
+    assert int(L.h_guard(dev()).item()) == 0                     # the guard word is left clean for the next call
+
+
+def test_hyper_synthesis_bits_do_not_depend_on_the_ambient_form():
+    """The pinned scope: scales|means from `_gaussian_params` are the same bits under every ambient form a caller may be in
+    (three-term default, six-term fallback) -- only the diagnostic process-wide override ARITH_FORCE changes them, on both
+    sides at once."""
+    import hashlib
+    from unified_point_cloud_compression_amd import lib as L, synth
+    model = _spread_model("symbols")
+    model.update()
+    pc = torch.from_numpy(synth.surface_cloud(1, 8)).to(dev())
+    q = torch.tensor([[0.5, 0.5]], device=dev())
+    tap = _Tap(model)
     try:
-        ref = model.decompress(coordinates=[c.clone() for c in out[3]], strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
+        shas = []
+        for form in (L.ARITH_H3, L.ARITH_BF6, L.ARITH_F32):
+            with L.arith_scope(form):
+                model.compress(pc, q)
+            shas.append(tap.enc["params"])
     finally:
-        L.call("pcc_set_gemm_h", 1)
-    assert torch.equal(rec, ref)
+        tap.close()
+    assert shas[0] == shas[1] == shas[2], shas
 
 
 def test_real_activations_level_by_level_against_the_fp32_input_path():
@@ -222,13 +309,11 @@ def test_real_activations_level_by_level_against_the_fp32_input_path():
         model.decompress(coordinates=[c.clone() for c in out[3]], strings=out[0], shape=out[1], k=out[2], q_vals=out[4], probe=probe)
 
     run("h")
-    L.call("pcc_set_gemm_h", 0)
-    L.call("pcc_set_mfma_split", 0)
+    L.ARITH_FORCE = L.ARITH_F32                              # every product of the process, the pinned hyper-synthesis included
     try:
         run("f32")
     finally:
-        L.call("pcc_set_gemm_h", 1)
-        L.call("pcc_set_mfma_split", 1)
+        L.ARITH_FORCE = None
     for lvl in range(3):
         a, b = logits["h"][lvl][0].double(), logits["f32"][lvl][0].double()
         assert a.shape == b.shape

@@ -379,12 +379,11 @@ def test_split_path_accuracy(cin, cout, ks):
     old_pair = S.PAIR_MIN_K
     S.PAIR_MIN_K = 1 << 30
     try:
-        L.call("pcc_set_mfma_split", 1)                               # (explicit: the environment may have selected the other path)
-        got_split = n(S.conv_forward(t(f), pk, t(b), K, cin, cout, m, cs.n))
-        L.call("pcc_set_mfma_split", 0)
-        got_fp32 = n(S.conv_forward(t(f), pk, t(b), K, cin, cout, m, cs.n))
+        with L.arith_scope(L.ARITH_BF6):                              # (explicit: the environment may have selected another form)
+            got_split = n(S.conv_forward(t(f), pk, t(b), K, cin, cout, m, cs.n))
+        with L.arith_scope(L.ARITH_F32):
+            got_fp32 = n(S.conv_forward(t(f), pk, t(b), K, cin, cout, m, cs.n))
     finally:
-        L.call("pcc_set_mfma_split", 1)
         S.PAIR_MIN_K = old_pair
     e_split = np.abs(got_split - want64).max() / scale
     e_fp32 = np.abs(got_fp32 - want64).max() / scale
@@ -423,13 +422,10 @@ def test_dense_products_accuracy(spread):
     first = torch.arange(0, n_rows * K + 1, dtype=torch.int32, device=dev())   # one pair per output row: T itself comes back
     pair_ids = torch.arange(0, n_rows * K, dtype=torch.int32, device=dev())
     res = {}
-    for name, env in (("h", 1), ("bf", 0)):
-        L.call("pcc_set_gemm_h", env)
-        try:
+    for name, form in (("h", L.ARITH_H3), ("bf", L.ARITH_BF6)):
+        with L.arith_scope(form):
             pk = S.PackedConv(True).get(W)
             got = S.convt_forward_csr(t(x), pk, None, K, cin, cout, (first, pair_ids), n_rows * K)
-        finally:
-            L.call("pcc_set_gemm_h", 1)
         res[name] = n(got).reshape(n_rows, ncol).astype(np.float64)
     scale = np.abs(want).max(1, keepdims=True) + 1e-300
     err = {k: (np.abs(v - want) / scale).max() for k, v in res.items()}
@@ -440,7 +436,7 @@ def test_dense_products_accuracy(spread):
 def test_pair_list_products_accuracy_with_spread_rows():
     """5x5x5 convolution in the pair-list form on scaled fp16 pairs (`k_pair_h2`): rows whose magnitudes spread over
     e^+-12 -- the scale is per input row and per (offset, column) of the weights -- against float64 and against the
-    six-term bf16 form (`pcc_set_gemm_h(0)`)."""
+    six-term bf16 form (`PCC_ARITH_BF6`)."""
     from unified_point_cloud_compression_amd import sparse as S, lib as L
     rng = np.random.default_rng(17)
     keys = cloud_keys(5, 40, 0.08, 1)
@@ -460,14 +456,11 @@ def test_pair_list_products_accuracy_with_spread_rows():
         want[o] += f64[nbr[k, o]] @ W64[k]
         mag[o, 0] = np.maximum(mag[o, 0], rowmax[nbr[k, o]])
     res = {}
-    for name, h in (("h", 1), ("bf", 0)):
-        L.call("pcc_set_gemm_h", h)
-        try:
+    for name, form in (("h", L.ARITH_H3), ("bf", L.ARITH_BF6)):
+        with L.arith_scope(form):
             pk = S.PackedConv().get(torch.nn.Parameter(t(W)))
             assert m.pair_plan() is not None                                   # sparse 5x5x5 map: the pair-list form runs
             res[name] = n(S.conv_forward(t(f), pk, None, K, cin, cout, m, cs.n)).astype(np.float64)
-        finally:
-            L.call("pcc_set_gemm_h", 1)
     scale = mag * np.abs(W64).max() * np.sqrt(cin) + 1e-300                    # size of one neighbour's contribution
     err = {k: (np.abs(v - want) / scale).max() for k, v in res.items()}
     assert err["h"] <= 2e-5 and err["h"] <= 4 * err["bf"] + 1e-7, err

@@ -24,7 +24,7 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"PCC_DBG={os.environ.get('PCC_DBG', '0')} split={os.environ.get('PCC_MFMA_SPLIT', '1')} n {n} cin {cin} ncol {ncol}: {ms:.3f} ms  "
+print(f"PCC_DBG={os.environ.get('PCC_DBG', '0')} arith={os.environ.get('PCC_ARITH', 'h3')} n {n} cin {cin} ncol {ncol}: {ms:.3f} ms  "
       f"{2.0 * n * cin * ncol / ms / 1e9:.1f} TFLOP/s  out {n * ncol * 4 / ms / 1e6:.0f} GB/s")
 if os.environ.get("PCC_DBG", "0") == "0":
     got = S.conv_forward(x, pk, None, 1, cin, ncol, None, n)

@@ -123,7 +123,7 @@ class GdnFn(torch.autograd.Function):
         out = torch.empty_like(x)
         packed, beta_eff = module._pack()
         L.call("pcc_gdn_fwd", L.ptr(x), x.shape[0], module.in_channels, L.ptr(packed), L.ptr(beta_eff),
-               1 if module.inverse else 0, L.ptr(out), L.stream())
+               1 if module.inverse else 0, L.ptr(out), L.arith(), L.stream())
         ctx.save_for_backward(x, beta_raw, gamma_raw)
         ctx.module = module
         return out

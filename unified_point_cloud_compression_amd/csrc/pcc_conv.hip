@@ -50,7 +50,8 @@ struct ConvArgs {
   bool wh_ok = false;                   // dense products: the pack carries scaled fp16 planes + column scales (split_planes_h)
   const unsigned char* feath = nullptr; //   scaled fp16 planes of feat, [n_in][cin/32][2][32] (k_feat_split_h)
   const float* frow_inv = nullptr;      //   and 1 / (power-of-two scale) of every feature row
-  int* guard = nullptr;                 //   range guard of the fp16-pair products (pcc_set_h_guard): set to 1 when a (row, column) pair of
+  int arith = PCC_ARITH_H3;             // arithmetic form of this call (include/pcc_hip.h PCC_ARITH_*): an argument of every entry point, no process state
+  int* guard = nullptr;                 //   range guard of the fp16-pair products (the entry point's d_guard): set to 1 when a (row, column) pair of
   float guard_lim = 0.f;                //   a tile has rinv * cinv * 8 * cin > guard_lim, i.e. max|row| * max|column| * cin * 2^-27 may exceed the budget
   int cin, cout, cout_pad;
   int cb_log2;            // log2(CB), CB = min(cin, 32)
@@ -586,15 +587,16 @@ static int make_planes(ConvArgs& a, bool take_abs, hipStream_t s) {
   return PCC_OK;
 }
 
-// Range guard of the fp16-pair products: a device word the kernels OR 1 into when a tile's scales admit an absolute product
-// error above `budget` (cin * 2^-27 * max|row| * max|column| > budget); NULL switches the guard off.  The caller zeroes the
-// word, reads it back with a size it reads anyway, and repeats the operation with pcc_set_gemm_h(0) when it is set.
-static int* g_h_guard = nullptr;
-static float g_h_guard_lim = 0.f;
-extern "C" int pcc_set_h_guard(int32_t* d_flag, float budget) {
-  PCC_REQUIRE(!d_flag || budget > 0.f, "pcc_set_h_guard: the budget must be positive");
-  g_h_guard = d_flag;
-  g_h_guard_lim = d_flag ? budget : 0.f;                   // compared with cin * 2^-27 * (rinv * 2^15) * (cinv * 2^15) = rinv * cinv * 8 * cin
+// Range guard of the fp16-pair products: a device word (the entry point's d_guard) the kernels OR 1 into when a tile's scales
+// admit an absolute product error above PCC_H_GUARD_BUDGET (cin * 2^-27 * max|row| * max|column| > budget); NULL = no guard.
+// The caller zeroes the word, reads it back with a size it reads anyway, and repeats the operation with PCC_ARITH_BF6 when it is
+// set.  The form and the guard word are ARGUMENTS of every call: the library keeps no arithmetic state (round 4; the process-wide
+// pcc_set_gemm_h / pcc_set_mfma_split / pcc_set_h_guard switches of rounds 2-3 are gone).
+static int set_arith(ConvArgs& a, int arith, int32_t* d_guard, const char* who) {
+  if (arith < PCC_ARITH_F32 || arith > PCC_ARITH_H3) { pcc_set_error("%s: arith=%d is not a PCC_ARITH_* form", who, arith); return PCC_EINVAL; }
+  a.arith = arith;
+  a.guard = arith == PCC_ARITH_H3 ? d_guard : nullptr;
+  a.guard_lim = PCC_H_GUARD_BUDGET;              // compared with cin * 2^-27 * (rinv * 2^15) * (cinv * 2^15) = rinv * cinv * 8 * cin
   return PCC_OK;
 }
 
@@ -611,8 +613,6 @@ static int make_planes_h(ConvArgs& a, hipStream_t s) {
   PCC_LAUNCH_CHECK();
   a.feath = (const unsigned char*)p;
   a.frow_inv = (const float*)((char*)p + plane_bytes);
-  a.guard = g_h_guard;
-  a.guard_lim = g_h_guard_lim;
   return PCC_OK;
 }
 
@@ -2536,13 +2536,10 @@ extern "C" int pcc_prof_collect_forms(double* h_ms, int64_t* h_launches, double*
 }
 
 static bool g_mfma_buf = getenv("PCC_MFMA_BUF") ? atoi(getenv("PCC_MFMA_BUF")) != 0 : true;
-// split path (fp32 products as six bf16 MFMA terms, k_conv_mfma_bf); PCC_MFMA_SPLIT=0 selects the fp32-input MFMA kernels
-static bool g_mfma_split = getenv("PCC_MFMA_SPLIT") ? atoi(getenv("PCC_MFMA_SPLIT")) != 0 : true;
-extern "C" int pcc_set_mfma_split(int32_t on) { g_mfma_split = on != 0; return PCC_OK; }
-static bool g_gemm_h = getenv("PCC_GEMM_H") ? atoi(getenv("PCC_GEMM_H")) != 0 : true;   // dense products in scaled fp16 pairs (k_gemm_h2)
-extern "C" int pcc_set_gemm_h(int32_t on) { g_gemm_h = on != 0; return PCC_OK; }
+// split path (fp32 products as six bf16 MFMA terms, k_conv_mfma_bf) unless the call asks for PCC_ARITH_F32 (fp32-input MFMA kernels);
+// dense / pair products in scaled fp16 pairs (k_gemm_h2, k_pair_h2) only under PCC_ARITH_H3
 static bool split_ok(const ConvArgs& a) {
-  return g_mfma_split && g_mfma_buf && a.cb_log2 == 5 && a.n_in > 0 && a.n_in * a.cin * 6 <= BUF_MAX_BYTES && a.wp_elems > 0 &&
+  return a.arith != PCC_ARITH_F32 && g_mfma_buf && a.cb_log2 == 5 && a.n_in > 0 && a.n_in * a.cin * 6 <= BUF_MAX_BYTES && a.wp_elems > 0 &&
          bf_plane_elems(a.wp_elems) * 4 <= BUF_MAX_BYTES;
 }
 
@@ -2625,12 +2622,11 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
     }
   }
   // dense products of the generative transposed convolutions whose pack carries fp16 planes: three-term fp16 form
-  if (split && g_gemm_h && a.wh_ok && MODE == MODE_CONV && !a.hdr && !a.pair_in && !a.rows && !a.bias && a.act == 0 && ksplit == 1 &&
+  if (split && a.arith == PCC_ARITH_H3 && a.wh_ok && MODE == MODE_CONV && !a.hdr && !a.pair_in && !a.rows && !a.bias && a.act == 0 && ksplit == 1 &&
       bn == 128 && (tiles(128) * gy >= want || a.feath) && (size_t)128 * a.cout * 4 < (1ull << 31) &&
       (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8)) {      // (caller's planes: the caller chose the form)
     if (!a.feath) PCC_TRY(make_planes_h(a, s));
     a.dbg = g_dbg;
-  a.nt = g_nt;
     a.nt = g_nt;
     const dim3 g2 = grid(128);
     prof_note(PCC_FORM_GEMM_H2, 2.0 * a.n_out * a.cin * a.cout, 4.0 * ((double)a.n_out * a.cin + (double)a.n_out * a.cout + (double)a.cin * a.cout));
@@ -2825,7 +2821,7 @@ extern "C" int pcc_set_in4_min_rows(int64_t rows) { g_in4_min_rows = rows; retur
 extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                             const float* bias, int32_t K, int32_t cout, const int32_t* hdr, const int32_t* nbr,
                             const int32_t* rows, int64_t n_out, float* out, int32_t act, float slope,
-                            void* ws, size_t ws_bytes, void* stream) {
+                            void* ws, size_t ws_bytes, int32_t arith, int32_t* d_guard, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0) return PCC_OK;
   PCC_REQUIRE(feat_in && packed_w && out && n_in > 0, "pcc_conv_fwd: NULL array");
@@ -2844,7 +2840,8 @@ extern "C" int pcc_conv_fwd(const float* feat_in, int64_t n_in, int32_t cin, con
     a.n_out = n_out; a.cin = cin; a.cout = cout; a.cout_pad = cout_pad_for(cout);
     a.n_in = n_in; a.wp_elems = (long long)K * cin * a.cout_pad;
     a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = act; a.slope = slope;
-    const bool in4 = g_in4_min_rows >= 0;
+    PCC_TRY(set_arith(a, arith, d_guard, "pcc_conv_fwd"));
+    const bool in4 = g_in4_min_rows >= 0 && arith != PCC_ARITH_F32;
     // the input layer: 4 channels, K * 4 <= 512 flattened into one reduction axis (k_conv_in4_bf); plain conv maps of >= 64 k
     // output rows (one segment, canonical row order: what pcc_kernel_map_build makes for a non-transposed map)
     if (in4 && cin == 4 && K * 4 <= 512 && K > 1 && hdr && !rows && bn_for(cout) == 128 && n_out >= g_in4_min_rows &&
@@ -3199,7 +3196,7 @@ extern "C" int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t ci
                                   const float* bias, int32_t K, int32_t cout, const int32_t* pair_in,
                                   const int32_t* tile_k, const int64_t* d_info, int64_t padded_pairs,
                                   const int32_t* pos, int64_t n_out, float* T, float* out, int32_t act, float slope,
-                                  void* stream) {
+                                  int32_t arith, int32_t* d_guard, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0) return PCC_OK;
   PCC_REQUIRE(feat_in && packed_w && pair_in && tile_k && d_info && pos && T && out, "pcc_conv_fwd_pairs: NULL array");
@@ -3213,6 +3210,7 @@ extern "C" int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t ci
     a.n_in = n_in; a.wp_elems = (long long)K * cin * a.cout_pad;
     a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
     a.pair_in = pair_in; a.tile_k = tile_k; a.n_tiles = (const long long*)d_info + 1;
+    PCC_TRY(set_arith(a, arith, d_guard, "pcc_conv_fwd_pairs"));
     hipEvent_t e0, e1;
     if (g_prof_on) PCC_TRY(prof_event(&e0, s));
     const int bn = bn_for(cout);
@@ -3220,7 +3218,7 @@ extern "C" int pcc_conv_fwd_pairs(const float* feat_in, int64_t n_in, int32_t ci
     const dim3 grid((unsigned)((padded_pairs / PAIR_BM * gy + 7) / 8 * 8));
     const bool buf = g_mfma_buf && n_in * cin * 4 <= BUF_MAX_BYTES && a.wp_elems * 4 <= BUF_MAX_BYTES;
     const bool split = split_ok(a);
-    const bool pair_h = split && g_gemm_h && conv_has_h(K, cin, cout) && (size_t)n_in * cin * 4 <= (size_t)BUF_MAX_BYTES &&
+    const bool pair_h = split && a.arith == PCC_ARITH_H3 && conv_has_h(K, cin, cout) && (size_t)n_in * cin * 4 <= (size_t)BUF_MAX_BYTES &&
                         (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8);
     prof_note(pair_h ? PCC_FORM_PAIR_H2 : split ? PCC_FORM_PAIR_BF : PCC_FORM_CONV_F32, 0.0, 0.0);
     if (pair_h) {                                   // scaled fp16 pairs, three MFMA terms (k_pair_h2)
@@ -3377,7 +3375,8 @@ extern "C" int64_t pcc_convt_rows_t_elems(int64_t pairs, int32_t K, int32_t cout
 extern "C" int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                                   const float* bias, int32_t K, int32_t cout, const int32_t* first,
                                   const int32_t* pair_ids, int64_t n_out, int64_t pairs, float* T, float* out,
-                                  int32_t act, float slope, void* int_ws, size_t int_ws_bytes, void* stream) {
+                                  int32_t act, float slope, void* int_ws, size_t int_ws_bytes, int32_t arith, int32_t* d_guard,
+                                  void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0) return PCC_OK;
   PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && out && int_ws, "pcc_convt_fwd_rows: NULL array");
@@ -3415,6 +3414,7 @@ extern "C" int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t ci
     a.n_in = n_in; a.wp_elems = (long long)K * cin * a.cout_pad;
     a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
     a.pair_in = pair_in; a.tile_k = tile_k; a.n_tiles = info + 1;
+    PCC_TRY(set_arith(a, arith, d_guard, "pcc_convt_fwd_rows"));
     hipEvent_t e0, e1;
     if (g_prof_on) PCC_TRY(prof_event(&e0, s));
     const int bn = bn_for(cout);
@@ -3422,7 +3422,7 @@ extern "C" int pcc_convt_fwd_rows(const float* feat_in, int64_t n_in, int32_t ci
     const dim3 grid((unsigned)((tiles_cap * gy + 7) / 8 * 8));
     const bool buf = g_mfma_buf && n_in * cin * 4 <= BUF_MAX_BYTES && a.wp_elems * 4 <= BUF_MAX_BYTES;
     const bool split = split_ok(a);
-    const bool pair_h = split && g_gemm_h && conv_has_h(K, cin, cout) && (size_t)n_in * cin * 4 <= (size_t)BUF_MAX_BYTES &&
+    const bool pair_h = split && a.arith == PCC_ARITH_H3 && conv_has_h(K, cin, cout) && (size_t)n_in * cin * 4 <= (size_t)BUF_MAX_BYTES &&
                         (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8);
     prof_note(pair_h ? PCC_FORM_PAIR_H2 : split ? PCC_FORM_PAIR_BF : PCC_FORM_CONV_F32, 0.0, 0.0);
     if (pair_h) {                                   // scaled fp16 pairs, three MFMA terms (k_pair_h2)
@@ -3573,7 +3573,8 @@ __global__ void __launch_bounds__(256) k_convt_gather(GatherArgs a) {
 
 extern "C" int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias,
                              int32_t K, int32_t cout, const int32_t* hdr, const int32_t* nbr, const int32_t* rows,
-                             int64_t n_out, float* T, float* out, int32_t act, float slope, void* stream) {
+                             int64_t n_out, float* T, float* out, int32_t act, float slope, int32_t arith, int32_t* d_guard,
+                             void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0 || n_in <= 0) return PCC_OK;
   PCC_REQUIRE(feat_in && packed_w && hdr && nbr && rows && T && out, "pcc_convt_fwd: NULL array");
@@ -3587,6 +3588,7 @@ extern "C" int pcc_convt_fwd(const float* feat_in, int64_t n_in, int32_t cin, co
   a.n_in = n_in; a.wp_elems = (long long)cin * a.cout_pad;
   a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
   a.wh_ok = convt_has_h(cin);
+  PCC_TRY(set_arith(a, arith, d_guard, "pcc_convt_fwd"));
   hipEvent_t e0, e1;
   if (g_prof_on) PCC_TRY(prof_event(&e0, s));
   PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));
@@ -3776,7 +3778,7 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
                               const float* bias, int32_t K, int32_t cout, const int32_t* first,
                               const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
                               const int32_t* ex_nbr, int32_t ex_K, const float* ex_bias, const PccGrid* ex_grid,
-                              const long long* ex_keys, void* stream) {
+                              const long long* ex_keys, int32_t arith, int32_t* d_guard, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0 || n_in <= 0) return PCC_OK;
   PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && out, "pcc_convt_fwd_csr: NULL array");
@@ -3790,6 +3792,7 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
   a.n_in = n_in; a.wp_elems = (long long)cin * a.cout_pad;
   a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
   a.wh_ok = convt_has_h(cin);
+  PCC_TRY(set_arith(a, arith, d_guard, "pcc_convt_fwd_csr"));
   hipEvent_t e0, e1;
   if (g_prof_on) PCC_TRY(prof_event(&e0, s));
   PCC_TRY(launch_mfma<MODE_CONV>(a, 0, s));
@@ -3824,9 +3827,10 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
 extern "C" int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
                                  const float* bias, int32_t K, int32_t cout, const int32_t* first,
                                  const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
-                                 const int32_t* ex_nbr, int32_t ex_K, const float* ex_bias, void* stream) {
+                                 const int32_t* ex_nbr, int32_t ex_K, const float* ex_bias, int32_t arith, int32_t* d_guard,
+                                 void* stream) {
   return convt_fwd_csr_impl(feat_in, n_in, cin, packed_w, bias, K, cout, first, pair_ids, n_out, T, out, act, slope, ex_nbr,
-                            ex_K, ex_bias, nullptr, nullptr, stream);
+                            ex_K, ex_bias, nullptr, nullptr, arith, d_guard, stream);
 }
 
 static int ilog2_i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -3845,11 +3849,11 @@ extern "C" int pcc_convt_fwd_csr_grid(const float* feat_in, int64_t n_in, int32_
                                       const float* bias, int32_t K, int32_t cout, const int32_t* first,
                                       const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
                                       const int64_t* out_keys, const uint64_t* out_bits, const int32_t* out_rank,
-                                      const int32_t* h_out, const float* ex_bias, void* stream) {
+                                      const int32_t* h_out, const float* ex_bias, int32_t arith, int32_t* d_guard, void* stream) {
   PCC_REQUIRE(out_keys && out_bits && out_rank && h_out && ex_bias, "pcc_convt_fwd_csr_grid: NULL array");
   const PccGrid ex = grid_from_host(out_bits, out_rank, h_out);
   return convt_fwd_csr_impl(feat_in, n_in, cin, packed_w, bias, K, cout, first, pair_ids, n_out, T, out, act, slope,
-                            nullptr, 27, ex_bias, &ex, (const long long*)out_keys, stream);
+                            nullptr, 27, ex_bias, &ex, (const long long*)out_keys, arith, d_guard, stream);
 }
 
 // ---- chunked form of the CSR generative transposed convolution --------------------------------------------------------
@@ -3980,7 +3984,8 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
                                          const int32_t* pair_ids, int64_t n_out, const int64_t* in_keys,
                                          const int64_t* out_keys, int32_t ts_out, float* T, size_t t_bytes, float* out,
                                          int32_t act, float slope, const uint64_t* out_bits, const int32_t* out_rank,
-                                         const int32_t* h_out, const float* ex_bias, void* ws, size_t ws_bytes, void* stream) {
+                                         const int32_t* h_out, const float* ex_bias, void* ws, size_t ws_bytes, int32_t arith,
+                                         int32_t* d_guard, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0 || n_in <= 0) return PCC_OK;
   PCC_REQUIRE(feat_in && packed_w && first && pair_ids && in_keys && out_keys && T && out && ws,
@@ -4005,10 +4010,11 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
   a.wp_elems = (long long)cin * a.cout_pad;
   a.cb_log2 = cb_log2_for(cin); a.ppo = cin >> a.cb_log2; a.act = 0; a.slope = 0.f;
   a.feat = feat_in; a.n_in = n_in; a.n_out = n_in;
+  PCC_TRY(set_arith(a, arith, d_guard, "pcc_convt_fwd_csr_chunked"));
   const bool split = split_ok(a);
   // the form the one-pass call would take for all rows (so that both give the same bits)
   const long long t128 = (pcc_cdiv(n_in, 128) + 7) / 8 * 8;
-  const bool use_h = split && g_gemm_h && convt_has_h(cin) && (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8) &&
+  const bool use_h = split && a.arith == PCC_ARITH_H3 && convt_has_h(cin) && (a.ppo == 1 || a.ppo == 2 || a.ppo == 4 || a.ppo == 6 || a.ppo == 8) &&
                      bn_for(a.cout) == 128 && t128 * (a.cout_pad / 128) >= 512;
   const unsigned char* planes = nullptr;
   const float* row_inv = nullptr;
@@ -4041,7 +4047,7 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
     const long long r0 = (long long)c * chunk_rows;
     const long long rows = r0 + chunk_rows < n_in ? chunk_rows : n_in - r0;
     a.feat = feat_in + r0 * cin; a.n_in = rows; a.n_out = rows;
-    if (use_h) { a.feath = planes + (size_t)r0 * cin * 4; a.frow_inv = row_inv + r0; a.guard = g_h_guard; a.guard_lim = g_h_guard_lim; }
+    if (use_h) { a.feath = planes + (size_t)r0 * cin * 4; a.frow_inv = row_inv + r0; }
     else a.featb = planes ? planes + (size_t)r0 * cin * 6 : nullptr;
     hipEvent_t e0, e1;
     if (g_prof_on) PCC_TRY(prof_event(&e0, s));
@@ -4388,7 +4394,7 @@ extern "C" int pcc_gdn_pack(const float* beta_raw, const float* gamma_raw, int32
 }
 
 extern "C" int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* packed, const float* beta_eff,
-                           int32_t inverse, float* out, void* stream) {
+                           int32_t inverse, float* out, int32_t arith, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n <= 0) return PCC_OK;
   PCC_REQUIRE(x && packed && beta_eff && out && x != out, "pcc_gdn_fwd: bad arguments");
@@ -4398,6 +4404,7 @@ extern "C" int pcc_gdn_fwd(const float* x, int64_t n, int32_t c, const float* pa
   a.n_out = n; a.cin = c; a.cout = c; a.cout_pad = cout_pad_for(c);
   a.n_in = n; a.wp_elems = (long long)c * a.cout_pad;
   a.cb_log2 = cb_log2_for(c); a.ppo = c >> a.cb_log2; a.act = 0; a.slope = 0.f;
+  PCC_TRY(set_arith(a, arith, nullptr, "pcc_gdn_fwd"));
   // large sets: split folded into the staging (k_gdn_bf), no plane round trip; small ones keep the general kernel (its
   // smaller row tiles fill the chip better below ~30 k rows)
   static const bool fused = getenv("PCC_GDN_FUSED") ? atoi(getenv("PCC_GDN_FUSED")) != 0 : true;

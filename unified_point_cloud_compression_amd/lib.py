@@ -6,6 +6,7 @@ call fails, this module raises.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -55,13 +56,12 @@ SIGNATURES = {
     "pcc_coords_expand_grid_csr": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "pcc_coords_expand_grid_csr_zk": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "pcc_map_to_dense": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
-    "pcc_set_mfma_split": (C.c_int, [_i32]),
     "pcc_set_in4_min_rows": (C.c_int, [_i64]),
     "pcc_set_thin_z_min_rows": (C.c_int, [_i64]),
     "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _i64, _p]),
     "pcc_conv_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
-    "pcc_conv_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _f32, _p, _sz, _p]),
+    "pcc_conv_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _f32, _p, _sz, _i32, _p, _p]),
     "pcc_conv_head_supported": (C.c_int, [_i32, _i32]),
     "pcc_conv_head_ws_bytes": (_sz, [_i64]),
     "pcc_conv_head_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -70,32 +70,30 @@ SIGNATURES = {
     "pcc_band_tiles_build": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
     "pcc_convt_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_convt_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _i64, _p]),
-    "pcc_convt_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _f32, _p]),
+    "pcc_convt_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _f32, _i32, _p, _p]),
     "pcc_convt_fwd_csr": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p, _i32, _p,
-                                    _p]),
+                                    _i32, _p, _p]),
     "pcc_convt_rows_int_ws_bytes": (_sz, [_i64, _i32]),
     "pcc_convt_rows_t_elems": (_i64, [_i64, _i32, _i32]),
     "pcc_convt_fwd_rows": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _i64, _p, _p, _i32, _f32, _p, _sz,
-                                     _p]),
+                                     _i32, _p, _p]),
     "pcc_map_from_csr": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "pcc_conv_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "pcc_conv_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_convt_scatter_rows": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
-    "pcc_convt_fwd_csr_grid": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p, _p, _p, C.POINTER(_i32), _p, _p]),
-    "pcc_set_gemm_h": (C.c_int, [_i32]),
-    "pcc_set_h_guard": (C.c_int, [_p, _f32]),
+    "pcc_convt_fwd_csr_grid": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p, _p, _p, C.POINTER(_i32), _p, _i32, _p, _p]),
     "pcc_set_t_chunk_bytes": (C.c_int, [_i64]),
     "pcc_convt_chunk_t_bytes": (_sz, [_i64, _i32, _i32]),
     "pcc_convt_chunk_ws_bytes": (_sz, [_i64, _i32, _i32]),
     "pcc_convt_fwd_csr_chunked": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _p, _sz, _p, _i32, _f32,
-                                            _p, _p, C.POINTER(_i32), _p, _p, _sz, _p]),
+                                            _p, _p, C.POINTER(_i32), _p, _p, _sz, _i32, _p, _p]),
     "pcc_thin_grid_ws_bytes": (_sz, [_i64, _i32]),
     "pcc_conv_thin_grid_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p, _p, C.POINTER(_i32), _p, _p, _sz, _p]),
     "pcc_gauss_lik_fwd": (C.c_int, [_p, _p, _p, _i64, _p, _p]),
     "pcc_gauss_lik_bwd": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "pcc_gdn_packed_elems": (_i64, [_i32]),
     "pcc_gdn_pack": (C.c_int, [_p, _p, _i32, _f32, _p, _i64, _p, _p]),
-    "pcc_gdn_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _p]),
+    "pcc_gdn_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p, _i32, _p]),
     "pcc_frame_intake_ws_bytes": (_sz, []),
     "pcc_coords_intake_i32": (C.c_int, [_p, _i64, _p, _p, _p, _sz, _p]),
     "pcc_frame_intake": (C.c_int, [_p, _i64, _p, _p, _p, _p, _sz, _p]),
@@ -133,7 +131,7 @@ SIGNATURES = {
     "pcc_pair_plan_rank": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _sz, _p]),
     "pcc_pair_plan_fill": (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p]),
     "pcc_conv_fwd_pairs": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32,
-                                     C.c_float, _p]),
+                                     C.c_float, _i32, _p, _p]),
     "pcc_nn_sorted_x": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p]),
     "pcc_prof_enable": (C.c_int, [_i32]),
     "pcc_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64)]),
@@ -285,11 +283,18 @@ def read_many(counters):
     return [read(t) for t in counters]
 
 
-# ---- range guard of the three-term fp16 products (include/pcc_hip.h: pcc_set_h_guard) ----------------
-H_GUARD_BUDGET = 2.5e-5     # absolute error the scales of a tile may admit before the operation is repeated in the six-term form:
-#                             a quarter of the 1e-4 parity bar (cin * 2^-27 * max|row| * max|column|: 26 for cin = 128; the
-#                             benchmark's layers stay below 0.5, tools/fp16_ranges.py)
-_guard = {}
+# ---- arithmetic form of the matrix products (include/pcc_hip.h PCC_ARITH_*) ----------------------------
+# The library keeps no arithmetic state: every convolution call names its form and its guard word.  On the host side the form
+# is a property of the calling THREAD's current scope (`arith_scope`), read by the wrappers in sparse.py at every call.
+ARITH_F32, ARITH_BF6, ARITH_H3 = 0, 1, 2
+H_GUARD_BUDGET = 2.5e-5     # PCC_H_GUARD_BUDGET: absolute error the scales of a tile may admit before the call is repeated in the
+#                             six-term form: a quarter of the 1e-4 parity bar (cin * 2^-27 * max|row| * max|column|: 26 for cin = 128;
+#                             the benchmark's layers stay below 0.5, tools/fp16_ranges.py)
+ARITH_DEFAULT = {"f32": ARITH_F32, "bf6": ARITH_BF6, "h3": ARITH_H3}[os.environ.get("PCC_ARITH", "h3")]
+# Diagnostic override (bench.py's `ms_per_step_strict` / `ms_per_step_fp32_mfma`, tests that compare forms): when not None EVERY
+# call of the process takes this form, pinned scopes included -- encoder and decoder alike, so the two stay in step.
+ARITH_FORCE = None
+_tls = threading.local()
 
 
 class RangeGuardTripped(Exception):
@@ -297,13 +302,54 @@ class RangeGuardTripped(Exception):
 
 
 def h_guard(device):
-    """The guard word of `device` (int32 [1], zero unless a launch tripped it), installed in the library on first use."""
-    key = torch.device(device).index or 0
-    g = _guard.get(key)
+    """The guard word of `device` for the calling thread (int32 [1], zero unless a launch of an H3 scope tripped it)."""
+    words = getattr(_tls, "guards", None)
+    if words is None:
+        words = _tls.guards = {}
+    g = words.get(device)
     if g is None:
-        g = _guard[key] = torch.zeros(1, dtype=torch.int32, device=device)
-        call("pcc_set_h_guard", g.data_ptr(), H_GUARD_BUDGET)
+        g = words[device] = torch.zeros(1, dtype=torch.int32, device=device)
+        words[device, "ptr"] = g.data_ptr()
     return g
+
+
+class arith_scope:
+    """`with arith_scope(ARITH_BF6): ...` -- the matrix products queued by this thread inside the block take that form.
+    `pinned=True` marks a scope whose form is part of a CONTRACT (the hyper-synthesis: encoder and decoder must produce the
+    same bits), which enclosing / fallback scopes must not change; only the diagnostic ARITH_FORCE overrides it."""
+
+    def __init__(self, form, pinned=False):
+        self.form, self.pinned = form, pinned
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "scope", None)
+        if self.prev is None or not self.prev[1]:          # inside a pinned scope nothing changes
+            _tls.scope = (self.form, self.pinned)
+        return self
+
+    def __exit__(self, *exc):
+        _tls.scope = self.prev
+        return False
+
+
+def arith():
+    """Form of the calling thread's current scope."""
+    if ARITH_FORCE is not None:
+        return ARITH_FORCE
+    sc = getattr(_tls, "scope", None)
+    return ARITH_DEFAULT if sc is None else sc[0]
+
+
+def arith_args(device):
+    """(arith, d_guard) -- the two arguments every convolution entry point takes before its stream."""
+    a = arith()
+    if a != ARITH_H3:
+        return a, None
+    words = getattr(_tls, "guards", None)
+    if words is None or (device, "ptr") not in words:
+        h_guard(device)
+        words = _tls.guards
+    return a, words[device, "ptr"]
 
 
 def call(name, *args):

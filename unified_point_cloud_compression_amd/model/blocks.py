@@ -42,7 +42,7 @@ class MinkowskiGDN(GDN):
         out = torch.empty_like(feats)
         packed, beta_eff = self._pack()
         L.call("pcc_gdn_fwd", L.ptr(feats), feats.shape[0], self.in_channels, L.ptr(packed), L.ptr(beta_eff),
-               1 if self.inverse else 0, L.ptr(out), L.stream())
+               1 if self.inverse else 0, L.ptr(out), L.arith(), L.stream())
         return out
 
     def forward(self, x):

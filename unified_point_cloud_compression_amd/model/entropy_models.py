@@ -131,6 +131,16 @@ class MeanScaleHyperprior(CompressionModel):
         return scale.to(torch.float32).contiguous(), rescale.to(torch.float32).contiguous()
 
     def _gaussian_params(self, z_hat, y_cset):
+        """scales | means of y from the decoded hyper-latent (`h_s` + `features_at_coordinates`).  In the codec both sides
+        must get the SAME BITS out of this (the scales pick the rANS table rows, `model/entropy_models.py:396-400,468-484`):
+        its products always run in the six-term form -- one form, no range condition, hence no guard and no fallback that
+        one side could take without the other (the scope is pinned: an enclosing fallback scope does not change it)."""
+        if torch.is_grad_enabled():
+            return self._gaussian_params_impl(z_hat, y_cset)
+        with L.arith_scope(L.ARITH_BF6, pinned=True):
+            return self._gaussian_params_impl(z_hat, y_cset)
+
+    def _gaussian_params_impl(self, z_hat, y_cset):
         if not torch.is_grad_enabled() and S.USE_GRID:
             # the last h_s layer is only ever read at y's coordinates (`features_at_coordinates`, a6): evaluate the
             # 3x3x3 convolution for those rows alone (13 k of the 56 k octree children) instead of everywhere + gather
@@ -166,6 +176,11 @@ class MeanScaleHyperprior(CompressionModel):
         scale, _ = self._gains(q, y._cset, y.F.shape[1])
         y_sym, idx, _ = self.gaussian_conditional.encode_rows(y._canonical_features(), params, y._cset.keys, scale,
                                                               want_likelihood=False)
+        if self.entropy_coder != "pcc_streams" and L.arith() == L.ARITH_H3:
+            guard = L.h_guard(z_sym.device)               # (the stream coder reads the guard with its container header)
+            if guard.item():
+                guard.zero_()
+                raise L.RangeGuardTripped()
         if self.entropy_coder == "symbols":
             return [y.C, z.C], [y_sym, z_sym], [z._cset.n]
         if self.entropy_coder == "pcc_streams":
@@ -225,7 +240,7 @@ class MeanScaleHyperprior(CompressionModel):
             z_string = zj.fetch()
             if yj.adaptive:
                 yj.launch_encode(zj.guest)
-        if zj.guest2:
+        if zj.guest2 and L.arith() == L.ARITH_H3:
             guard.zero_()
             raise L.RangeGuardTripped()
         return z_string, yj.fetch()
@@ -254,6 +269,8 @@ class MeanScaleHyperprior(CompressionModel):
         status = L.counter(1, torch.int32)
         main = torch.cuda.current_stream(device)
         side = L.side_stream(device)
+        side.wait_event(main.record_event())        # the counter block's zero fill (and whatever still uses a recycled
+        #                                             allocation) is ordered on the main stream
         with torch.cuda.stream(side):
             z_sym = eb.decompress_rows(z_string, int(shape[0]), eb.channels, device=device, check=check, status=status)
             ev = side.record_event()

@@ -96,7 +96,17 @@ class UnifiedModel(CompressionModel):
     @torch.no_grad()
     def compress_block(self, x_block, q, coords=None):
         """One block through g_a and the entropy model: (strings, shape, k, latent coordinates) -- the body of the block loop
-        of `compress` (`model/model.py:137-176`)."""
+        of `compress` (`model/model.py:137-176`).  The matrix products of g_a and h_a run in the three-term fp16 form under
+        its range guard: should a layer's operands leave the range the form's error bound covers, THIS
+        block is coded again with those products in the six-term 24-bit form.  The hyper-synthesis never changes form (its
+        scope is pinned, `MeanScaleHyperprior._gaussian_params`): the decoder reproduces its bits whatever happened here."""
+        try:
+            return self._compress_block(x_block, q, coords)
+        except L.RangeGuardTripped:
+            with L.arith_scope(L.ARITH_BF6):
+                return self._compress_block(x_block, q, coords)
+
+    def _compress_block(self, x_block, q, coords=None):
         if isinstance(coords, tuple):                       # (FrameRows, features): the frame went through `frame_intake`
             coords[0]._pcc_chain = self.stride_chain()
             x = SparseTensor._from_frame(x_block, coords[0], coords[1])
@@ -123,19 +133,7 @@ class UnifiedModel(CompressionModel):
 
     @torch.no_grad()
     def compress(self, pointcloud, q, path=None, block_size=1024, scaling_factor=1.0):
-        """`UnifiedModel.compress` (`model/model.py:94-187`).  The matrix products run in the three-term fp16 form under its
-        range guard: should a layer's operands leave the range the form's error bound covers, the
-        block is coded again with every product in the six-term 24-bit form."""
-        try:
-            return self._compress(pointcloud, q, path, block_size, scaling_factor)
-        except L.RangeGuardTripped:
-            L.call("pcc_set_gemm_h", 0)
-            try:
-                return self._compress(pointcloud, q, path, block_size, scaling_factor)
-            finally:
-                L.call("pcc_set_gemm_h", 1)
-
-    def _compress(self, pointcloud, q, path=None, block_size=1024, scaling_factor=1.0):
+        """`UnifiedModel.compress` (`model/model.py:94-187`); the range-guard fallback is per block (`compress_block`)."""
         if path and self.entropy_model.entropy_coder == "symbols":
             raise L.PccError("path= needs byte strings: build the model with entropy_coder 'pcc_streams' or 'ans'")
         if not pointcloud.is_cuda:
@@ -181,18 +179,9 @@ class UnifiedModel(CompressionModel):
     @torch.no_grad()
     def decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None, q_vals=None, trace=None,
                    probe=None):
-        """`UnifiedModel.decompress` (`model/model.py:189-250`), under the same range guard as `compress`."""
-        try:
-            return self._decompress(path, coordinates, strings, shape, k, q_vals, trace, probe)
-        except L.RangeGuardTripped:
-            L.call("pcc_set_gemm_h", 0)
-            try:
-                return self._decompress(path, coordinates, strings, shape, k, q_vals, trace, probe)
-            finally:
-                L.call("pcc_set_gemm_h", 1)
-
-    def _decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None, q_vals=None, trace=None,
-                    probe=None):
+        """`UnifiedModel.decompress` (`model/model.py:189-250`).  The synthesis transform runs under the same range guard as
+        the encoder's analysis: when it trips, g_s alone (never the entropy model: its hyper-synthesis is pinned to one form
+        on both sides) is evaluated again in the six-term form on the latents already decoded."""
         device = self.g_s.down_conv.kernel.device
         if path:
             coordinates, strings, shape, k, q_vals = self.load_bitstream(path)
@@ -200,8 +189,12 @@ class UnifiedModel(CompressionModel):
                 c = c.to(device)
                 coordinates[i] = torch.cat([torch.zeros((c.shape[0], 1), dtype=c.dtype, device=device), c], dim=1)
                 q_vals[i] = q_vals[i].to(device)
-        feats, coords, status, blocks = [], [], [], []
+        feats, coords, status, blocks, latents = [], [], [], [], []
         for i, (block_symbols, block_shape, block_coords, block_k) in enumerate(zip(strings, shape, coordinates, k)):
+            # (the stride-32 set cannot have more rows than the stride-8 one: a header that says otherwise is refused before
+            #  anything is sized by it)
+            if not 0 <= int(block_shape[0]) <= max(int(block_coords.shape[0]), 0):
+                raise L.PccError(f"bitstream says {int(block_shape[0])} hyper-latent rows for {int(block_coords.shape[0])} latent rows")
             pre = self.entropy_model.predecode(block_symbols, block_shape, device, check=status)
             y_cset = getattr(block_coords, "_pcc_cset", None)
             if (y_cset is None or y_cset.ts != 8 or y_cset.n != block_coords.shape[0]
@@ -224,6 +217,21 @@ class UnifiedModel(CompressionModel):
             y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i], check=status, pre=pre)
             x_hat = self.g_s(y_hat, k=block_k, trace=trace, probe=probe)
             blocks.append(x_hat)
+            latents.append((y_hat, block_k))
+        out = self._finish(blocks, device)
+        guard = L.h_guard(device)
+        flags = torch.cat([s.reshape(-1)[:1].to(torch.int32) for s in status] + [guard]).tolist()   # one deferred read: rANS containers + range guard
+        if any(flags[:-1]):
+            raise L.PccError("malformed rANS container in the bitstream")
+        if flags[-1] and L.arith() == L.ARITH_H3:
+            guard.zero_()
+            with L.arith_scope(L.ARITH_BF6):
+                blocks = [self.g_s(y_hat, k=block_k, trace=trace, probe=probe) for y_hat, block_k in latents]
+            out = self._finish(blocks, device)
+        return out
+
+    def _finish(self, blocks, device):
+        """[x, y, z, clamp(round(255 f), 0, 255) / 255] rows of the decoded blocks (`model/model.py:240-250`)."""
         out = None
         if blocks and all(x._perm is None and x.F.dim() == 2 and x.F.shape[1] == 3 and x.F.is_contiguous()
                           and x.F.dtype == torch.float32 for x in blocks):
@@ -233,15 +241,9 @@ class UnifiedModel(CompressionModel):
             for x in blocks:
                 L.call("pcc_decode_finish", L.ptr(x._cset.keys), L.ptr(x.F), x._cset.n, out.data_ptr() + at * 24, L.stream())
                 at += x._cset.n
-        guard = L.h_guard(device)
-        flags = torch.cat([s.reshape(-1)[:1].to(torch.int32) for s in status] + [guard]).tolist()   # one deferred read: rANS containers + range guard
-        if any(flags[:-1]):
-            raise L.PccError("malformed rANS container in the bitstream")
-        if flags[-1]:
-            guard.zero_()
-            raise L.RangeGuardTripped()
         if out is not None:
             return out
+        feats, coords = [], []
         for x in blocks:
             feats.append(x.F)
             coords.append(x.C)

@@ -707,13 +707,13 @@ def conv_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NON
             T = L.workspace(max(padded, 1) * cout * 4, feats.device)
             L.call("pcc_conv_fwd_pairs", L.ptr(feats), feats.shape[0], cin, L.ptr(packed_w), L.ptr(b), K, cout,
                    L.ptr(pair_in), L.ptr(tile_k), L.ptr(info), padded, L.ptr(pos), n_out, L.ptr(T), L.ptr(out), act,
-                   float(slope), L.stream())
+                   float(slope), *L.arith_args(feats.device), L.stream())
             return out
     ws = L.workspace(L.load().pcc_conv_ws_bytes(feats.shape[0], K, cin, cout), feats.device)
     L.call("pcc_conv_fwd", L.ptr(feats), feats.shape[0], cin, L.ptr(packed_w), L.ptr(b), K, cout,
            L.ptr(kmap.hdr) if kmap is not None else None, L.ptr(kmap.nbr) if kmap is not None else None,
            L.ptr(kmap.rows) if kmap is not None else None, n_out, L.ptr(out), act, float(slope), L.ptr(ws),
-           ws.numel(), L.stream())
+           ws.numel(), *L.arith_args(feats.device), L.stream())
     return out
 
 
@@ -745,7 +745,8 @@ def convt_forward(feats, packed_w, bias, K, cin, cout, kmap, n_out, act=L.ACT_NO
     T = torch.empty(n_in * K * cout, dtype=torch.float32, device=feats.device)
     b = bias.detach().reshape(-1).contiguous() if bias is not None else None
     L.call("pcc_convt_fwd", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(kmap.hdr),
-           L.ptr(kmap.nbr), L.ptr(kmap.rows), n_out, L.ptr(T), L.ptr(out), act, float(slope), L.stream())
+           L.ptr(kmap.nbr), L.ptr(kmap.rows), n_out, L.ptr(T), L.ptr(out), act, float(slope), *L.arith_args(feats.device),
+           L.stream())
     return out
 
 
@@ -765,7 +766,8 @@ def convt_forward_csr(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT
     eb = ex_bias.detach().to(torch.float32).contiguous() if ex_map is not None else None
     L.call("pcc_convt_fwd_csr", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first),
            L.ptr(pair_ids), n_out, L.ptr(T), L.ptr(out), act, float(slope),
-           L.ptr(ex_map.nbr) if ex_map is not None else None, ex_map.K if ex_map is not None else 0, L.ptr(eb), L.stream())
+           L.ptr(ex_map.nbr) if ex_map is not None else None, ex_map.K if ex_map is not None else 0, L.ptr(eb),
+           *L.arith_args(feats.device), L.stream())
     return out
 
 
@@ -783,7 +785,7 @@ def convt_forward_csr_grid(feats, packed_w, bias, K, cin, cout, csr, out_set, ac
     b = bias.detach().reshape(-1).contiguous() if bias is not None else None
     L.call("pcc_convt_fwd_csr_grid", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first), L.ptr(pair_ids),
            n_out, L.ptr(T), L.ptr(out), act, float(slope), L.ptr(out_set.keys), L.ptr(g[0]), L.ptr(g[1]), g[2],
-           L.ptr(ex_bias.detach().to(torch.float32).contiguous()), L.stream())
+           L.ptr(ex_bias.detach().to(torch.float32).contiguous()), *L.arith_args(feats.device), L.stream())
     return out
 
 
@@ -806,7 +808,8 @@ def convt_forward_csr_chunked(feats, packed_w, bias, K, cin, cout, csr, in_set, 
     eb = ex_bias.detach().to(torch.float32).contiguous() if ex_bias is not None else None
     L.call("pcc_convt_fwd_csr_chunked", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first), L.ptr(pair_ids),
            n_out, L.ptr(in_set.keys), L.ptr(out_set.keys), out_set.ts, ws.data_ptr() + wb, tb, L.ptr(out), act, float(slope),
-           L.ptr(g[0]) if g else None, L.ptr(g[1]) if g else None, g[2] if g else None, L.ptr(eb), ws.data_ptr(), wb, L.stream())
+           L.ptr(g[0]) if g else None, L.ptr(g[1]) if g else None, g[2] if g else None, L.ptr(eb), ws.data_ptr(), wb,
+           *L.arith_args(feats.device), L.stream())
     return out
 
 
@@ -840,7 +843,8 @@ def convt_forward_rows(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.AC
     ws = L.workspace(lib.pcc_convt_rows_int_ws_bytes(pairs, K), feats.device)
     b = bias.detach().reshape(-1).contiguous() if bias is not None else None
     L.call("pcc_convt_fwd_rows", L.ptr(feats), feats.shape[0], cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first),
-           L.ptr(pair_ids), n_out, pairs, L.ptr(T), L.ptr(out), act, float(slope), L.ptr(ws), ws.numel(), L.stream())
+           L.ptr(pair_ids), n_out, pairs, L.ptr(T), L.ptr(out), act, float(slope), L.ptr(ws), ws.numel(),
+           *L.arith_args(feats.device), L.stream())
     return out
 
 

@@ -433,6 +433,49 @@ def test_dense_products_accuracy(spread):
     assert err["h"] <= 3 * err["bf"] + 1e-7, err
 
 
+def _wide_product(rows=6000 + 77, cin=128, K=343, cout=16, seed=9):
+    """T = X Wflat of a composite level's shape (7x7x7 offsets x 16 channels = 5 488 columns: 21.5 column blocks of 256, the
+    last one half) through `pcc_convt_fwd_csr` with one pair per output row, so that the product buffer itself comes back."""
+    from unified_point_cloud_compression_amd import sparse as S
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((rows, cin)) * np.exp(rng.standard_normal((rows, 1)))).astype(np.float32)
+    w = (rng.standard_normal((cin, K * cout)) / np.sqrt(cin)).astype(np.float32)
+    W = torch.nn.Parameter(t(np.ascontiguousarray(w.reshape(cin, K, cout).transpose(1, 0, 2))))
+    first = torch.arange(0, rows * K + 1, dtype=torch.int32, device=dev())
+    pair_ids = torch.arange(0, rows * K, dtype=torch.int32, device=dev())
+    pk = S.PackedConv(True).get(W)
+    got = S.convt_forward_csr(t(x), pk, None, K, cin, cout, (first, pair_ids), rows * K)
+    return x, w, n(got).reshape(rows, K * cout)
+
+
+def _wide_product_sha():
+    import hashlib
+    return hashlib.sha256(_wide_product()[2].tobytes()).hexdigest()
+
+
+def test_wide_tile_dense_products_equal_the_128_wide_tile_bit_for_bit():
+    """Round 4: the composite levels' products take 128 x 256 tiles (`k_gemm_h2<NCH, 4>`).  Same chunk order, same term
+    order per element as the 128 x 128 tile, so the two must agree BIT FOR BIT (a child process runs the narrow tile:
+    `PCC_GEMM_WIDE` is a load-time switch); ragged last row tile, half-empty last column block; and against float64."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    x, w, got = _wide_product()
+    want = x.astype(np.float64) @ w.astype(np.float64)
+    scale = np.abs(want).max(1, keepdims=True) + 1e-300
+    assert (np.abs(got - want) / scale).max() <= 4e-6
+    if os.environ.get("PCC_GEMM_WIDE", "1") == "0":
+        pytest.skip("this process already runs the narrow tile")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "from tests.test_gpu_map_conv import _wide_product_sha; print('SHA', _wide_product_sha())"],
+                       cwd=root, env=dict(os.environ, PCC_GEMM_WIDE="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    narrow = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("SHA ")][-1]
+    assert narrow == hashlib.sha256(got.tobytes()).hexdigest()
+
+
 def test_pair_list_products_accuracy_with_spread_rows():
     """5x5x5 convolution in the pair-list form on scaled fp16 pairs (`k_pair_h2`): rows whose magnitudes spread over
     e^+-12 -- the scale is per input row and per (offset, column) of the weights -- against float64 and against the

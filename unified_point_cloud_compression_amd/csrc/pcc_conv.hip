@@ -25,6 +25,13 @@ static constexpr int MAXK = 128;    // kernel offsets per segment (K <= 125)
 static constexpr int MAXK_T = 512;  // offsets of the input-stationary transposed conv (a flat GEMM: 7^3 composites fit)
 
 enum { MODE_CONV = 0, MODE_GDN = 1, MODE_IGDN = 2 };
+// Phase switches of the GEMM kernels (tools/gemm_probe.py): compiled in only by `make DBG=1` (-DPCC_DBG_BUILD); in the shipped
+// library the tests are the constant 0 and the compiler drops them.
+#ifdef PCC_DBG_BUILD
+#define PCC_DBG_ON(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define PCC_DBG_ON(a, bit) false
+#endif
 static constexpr int PAIR_BM_C = 128;   // rows per pair tile (pair-list GEMMs)
 __device__ inline float act1(float v, int act, float slope);
 
@@ -45,7 +52,7 @@ struct ConvArgs {
   const unsigned char* featb = nullptr; // split path: bf16 planes of feat, [n_in][cin/32][3][32] (k_feat_split)
   int ksplit = 1;                       // split path, map mode: the (offset, channel-block) reduction cut over ksplit workgroups
   float* part = nullptr;                //   partial tiles [ksplit][n_out][cout], summed in fixed order by k_splitk_reduce
-  int dbg = 0;                          // diagnostics (env PCC_DBG): 1 = no output stores, 2 = no MFMA phase, 4 = no staging loads
+  int dbg = 0;                          // diagnostics (probe builds only, `make DBG=1` + env PCC_DBG): 1 = no output stores, 2 = no MFMA phase, 4 = no staging loads
   int nt = 0;                           // non-temporal accesses of streamed buffers (g_nt): 1 = dense products' stores, 2 = pair products' stores
   bool wh_ok = false;                   // dense products: the pack carries scaled fp16 planes + column scales (split_planes_h)
   const unsigned char* feath = nullptr; //   scaled fp16 planes of feat, [n_in][cin/32][2][32] (k_feat_split_h)
@@ -769,13 +776,13 @@ __global__ void __launch_bounds__(256, MINWG) k_conv_mfma_bf(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const unsigned off = rows[j] >= 0 ? (unsigned)rows[j] * row_bytes + (unsigned)cbi * 192u + (unsigned)a_w[j] * 16u : BUF_OOB;
-      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (a.dbg & 4) ? BUF_OOB : off, 0, 0));
+      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, PCC_DBG_ON(a, 4) ? BUF_OOB : off, 0, 0));
     }
     const unsigned wbase = (unsigned)((act_kid[ai] * a.ppo + cbi) * a.cout_pad + colblock) * 192u;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const unsigned off = b_row[j] >= 0 ? wbase + (unsigned)(j * 256 + tid) * 16u : BUF_OOB;
-      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (a.dbg & 4) ? BUF_OOB : off, 0, 0));
+      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, PCC_DBG_ON(a, 4) ? BUF_OOB : off, 0, 0));
     }
   };
 
@@ -816,7 +823,7 @@ __global__ void __launch_bounds__(256, MINWG) k_conv_mfma_bf(ConvArgs a) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs, not next to its use
-    if (a.dbg & 2) continue;
+    if (PCC_DBG_ON(a, 2)) continue;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[3][TM], bf[3][TN];
@@ -843,7 +850,7 @@ __global__ void __launch_bounds__(256, MINWG) k_conv_mfma_bf(ConvArgs a) {
     }
   }
 
-  if (a.dbg & 1) { if (acc[0][0][0] != 12345.678f) return; }
+  if (PCC_DBG_ON(a, 1)) { if (acc[0][0][0] != 12345.678f) return; }
   if (a.ksplit > 1) {                                 // raw partial sums; bias / activation are applied by k_splitk_reduce
     float* const part = a.part + (size_t)ks_id * (size_t)a.n_out * a.cout;
 #pragma unroll
@@ -974,10 +981,10 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
   auto issue = [&](int cbi) {
 #pragma unroll
     for (int j = 0; j < 6; ++j)
-      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (a.dbg & 4) ? BUF_OOB : vA[j] + (unsigned)cbi * 192u, 0, 0));
+      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, PCC_DBG_ON(a, 4) ? BUF_OOB : vA[j] + (unsigned)cbi * 192u, 0, 0));
 #pragma unroll
     for (int j = 0; j < 6; ++j)
-      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (a.dbg & 4) ? BUF_OOB : vB, (int)((unsigned)cbi * b_stride + (unsigned)j * 4096u), 0));
+      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, PCC_DBG_ON(a, 4) ? BUF_OOB : vB, (int)((unsigned)cbi * b_stride + (unsigned)j * 4096u), 0));
   };
 
   f32x16 acc[2][2];
@@ -1003,7 +1010,7 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
     __syncthreads();
     if (c + 1 < NCH) issue(c + 1);            // next chunk's global loads fly during this chunk's MFMAs
     __builtin_amdgcn_sched_barrier(0);
-    if (a.dbg & 2) continue;
+    if (PCC_DBG_ON(a, 2)) continue;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[3][2], bf[3][2];
@@ -1018,7 +1025,7 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {           // smallest terms first (same order as k_conv_mfma_bf: identical results)
-          if (!(a.dbg & 8)) {                  // (timing experiment: three of the six terms)
+          if (!PCC_DBG_ON(a, 8)) {                  // (timing experiment: three of the six terms)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
@@ -1029,7 +1036,7 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bf2(ConvArgs a) {
         }
     }
   }
-  if (a.dbg & 1) { if (acc[0][0][0] != 12345.678f) return; }
+  if (PCC_DBG_ON(a, 1)) { if (acc[0][0][0] != 12345.678f) return; }
 
   // ---- range guard: the elements of a row / column far below its maximum are carried with an
   //      ABSOLUTE error of 2^-28 of that maximum, so a product's error can reach cin * 2^-27 * max|row| * max|column|; the
@@ -1359,9 +1366,13 @@ __global__ void __launch_bounds__(256, 3) k_conv_in4_bf(ConvArgs a, const unsign
 // The dense products in scaled fp16 pairs (see k_feat_split_h): the structure of k_gemm_bf2 with two planes per operand
 // (8 units of 16 bytes per 32-channel piece, LDS rows of 9 units: 9 is odd, so a fragment read's 16 rows fall on 16 different
 // bank quads), three MFMA terms, and the row and column scales applied to the accumulators on the way out.
-template <int NCH>
-__global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
-  constexpr int BM = 128, BN = 128, LDU = 9;
+// TN = 32-column MFMA tiles per wave: 2 -> the 128 x 128 workgroup tile, 4 -> 128 x 256 (round 4).  Per tile the kernel reads
+// (128 + BN) operand rows of NCH * 128 B from L2 for 128 * BN * 4 B of products: 2 B read per B written at BN = 128, 1.5 at
+// BN = 256 -- with the product stores out of the operands' way (non-temporal) the L2 -> LDS operand stream is what is left to
+// shrink.  128 accumulator registers per lane, two workgroups per CU.
+template <int NCH, int TN = 2>
+__global__ void __launch_bounds__(256, TN == 2 ? 3 : 2) k_gemm_h2(ConvArgs a) {
+  constexpr int BM = 128, BN = 64 * TN, LDU = 9, NB = BN / 32;
   constexpr unsigned ROWB = NCH * 128u;                // bytes of a feature row's planes
   __shared__ __attribute__((aligned(16))) uint4 As[BM * LDU];
   __shared__ __attribute__((aligned(16))) uint4 Bs[BN * LDU];
@@ -1369,7 +1380,7 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int cpx = gridDim.x >> 3;
   const int wid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-  const int gy = a.cout_pad / BN;
+  const int gy = (a.cout_pad + BN - 1) / BN;
   int tile_id, colblock;
   if (gy > 8) {
     const int g = wid / (8 * gy), rem = wid - g * 8 * gy;
@@ -1389,84 +1400,94 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
   const unsigned char* wb = reinterpret_cast<const unsigned char*>(wplanes) + (size_t)colblock * 128u;
   const float* const cinv = wplanes + a.wp_elems;                                    // [cout_pad] column 1/scale
   const unsigned b_stride = (unsigned)a.cout_pad * 128u;
+  const int bcols = min(BN, a.cout_pad - colblock);                                  // (the last 256-wide block may hold 128 columns)
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(wb), (short)0, (int)((NCH - 1) * b_stride + BN * 128u), 0x00020000);
+      const_cast<unsigned char*>(wb), (short)0, (int)((NCH - 1) * b_stride + (unsigned)bcols * 128u), 0x00020000);
 
-  unsigned vA[4], ld[4];
+  unsigned vA[4], ld[NB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned u = (unsigned)(j * 256 + tid), row = u >> 3, wu = u & 7u;
-    vA[j] = row * ROWB + wu * 16u;
-    ld[j] = row * LDU + wu;
-  }
-  const unsigned vB = (unsigned)tid * 16u;
+  for (int j = 0; j < 4; ++j) vA[j] = (unsigned)((j * 256 + tid) >> 3) * ROWB + (unsigned)(tid & 7) * 16u;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) ld[j] = (unsigned)((j * 256 + tid) >> 3) * LDU + (unsigned)(tid & 7);
+  // column (tid >> 3) + 32 j of the block; columns past cout_pad (second half of the last wide block) read zeros
+  unsigned vB[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) vB[j] = ((tid >> 3) + 32 * j < bcols) ? (unsigned)tid * 16u + (unsigned)j * 4096u : BUF_OOB;
 
-  uint4 av[4], bv[4];
+  uint4 av[4], bv[NB];
   auto issue = [&](int cbi) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (a.dbg & 4) ? BUF_OOB : vA[j] + (unsigned)cbi * 128u, 0, 0));
+      av[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, PCC_DBG_ON(a, 4) ? BUF_OOB : vA[j] + (unsigned)cbi * 128u, 0, 0));
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (a.dbg & 4) ? BUF_OOB : vB, (int)((unsigned)cbi * b_stride + (unsigned)j * 4096u), 0));
+    for (int j = 0; j < NB; ++j) {
+      if constexpr (TN == 2) {
+        bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, PCC_DBG_ON(a, 4) ? BUF_OOB : vB[0], (int)((unsigned)cbi * b_stride + (unsigned)j * 4096u), 0));
+      } else {
+        bv[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (PCC_DBG_ON(a, 4) || vB[j] == BUF_OOB) ? BUF_OOB : vB[j] + (unsigned)cbi * b_stride, 0, 0));
+      }
+    }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int wm = w >> 1, wn = w & 1;
   const int half = lane >> 5, r31 = lane & 31;
-  const unsigned fa = (unsigned)((wm * 64 + r31) * LDU + half), fb = (unsigned)((wn * 64 + r31) * LDU + half);
+  const unsigned fa = (unsigned)((wm * 64 + r31) * LDU + half), fb = (unsigned)((wn * 32 * TN + r31) * LDU + half);
 
   issue(0);
   if (tid < BM) rs[tid] = tid < npos ? a.frow_inv[p0 + tid] : 0.f;
-  float cs[2];
+  float cs[TN];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) cs[j] = cinv[colblock + wn * 64 + j * 32 + r31];
+  for (int j = 0; j < TN; ++j) {
+    const int col = colblock + wn * 32 * TN + j * 32 + r31;
+    cs[j] = col < a.cout_pad ? cinv[col] : 0.f;
+  }
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     __syncthreads();   // previous chunk's fragment reads are done
 #pragma unroll
     for (int j = 0; j < 4; ++j) As[ld[j]] = av[j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) Bs[ld[j]] = bv[j];
+    for (int j = 0; j < NB; ++j) Bs[ld[j]] = bv[j];
     __syncthreads();
     if (c + 1 < NCH) issue(c + 1);            // next chunk's global loads fly during this chunk's MFMAs
     __builtin_amdgcn_sched_barrier(0);
-    if (a.dbg & 2) continue;
+    if (PCC_DBG_ON(a, 2)) continue;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      f16x8 af[2][2], bf[2][2];
+      f16x8 af[2][2], bf[2][TN];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[p][i] = __builtin_bit_cast(f16x8, As[fa + i * 32 * LDU + p * 4 + ks * 2]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[p][j] = __builtin_bit_cast(f16x8, Bs[fb + j * 32 * LDU + p * 4 + ks * 2]);
+        for (int j = 0; j < TN; ++j) bf[p][j] = __builtin_bit_cast(f16x8, Bs[fb + j * 32 * LDU + p * 4 + ks * 2]);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {           // small terms first
+        for (int j = 0; j < TN; ++j) {           // small terms first
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
         }
     }
   }
-  if (a.dbg & 1) { if (acc[0][0][0] != 12345.678f) return; }
+  if (PCC_DBG_ON(a, 1)) { if (acc[0][0][0] != 12345.678f) return; }
 
-  // ---- stores: element e of acc[i][j] is row wm*64 + i*32 + (e&3) + 8*(e>>2) + 4*half, column wn*64 + j*32 + r31 of the tile
+  // ---- stores: element e of acc[i][j] is row wm*64 + i*32 + (e&3) + 8*(e>>2) + 4*half, column wn*32*TN + j*32 + r31 of the tile
   const unsigned ncol = (unsigned)a.cout;
   float* const obase = a.out + (size_t)p0 * ncol + colblock;
   const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
       obase, (short)0, (int)(((unsigned)(npos - 1) * ncol + min((unsigned)BN, ncol - (unsigned)colblock)) * 4u), 0x00020000);
-  const unsigned vO = ((unsigned)(wm * 64 + 4 * half) * ncol + (unsigned)(wn * 64 + r31)) * 4u;
+  const unsigned vO = ((unsigned)(wm * 64 + 4 * half) * ncol + (unsigned)(wn * 32 * TN + r31)) * 4u;
   const bool full = npos == BM && (unsigned)colblock + BN <= ncol;
   // The product buffer is written once and read back by the gather-sum long after it left the caches (5 GB per level):
   // non-temporal stores keep it from evicting the operands this kernel re-reads from L2 (round 3: 3.4 -> 4.2 TB/s of
@@ -1475,8 +1496,10 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
   //  4.2 against 5.0 TB/s, tools/gemm_nt_probe.sh: the hint is taken from 64 input channels on; PCC_NT bit 6 forces it.)
   const bool nt = (a.nt & 1) != 0 && (NCH >= 2 || (a.nt & 64));
   const int row_lim = npos - wm * 64 - 4 * half;
-  const int col_lim = (int)ncol - colblock - wn * 64 - r31;
-  float guard_mr = 0.f;
+  const int col_lim = (int)ncol - colblock - wn * 32 * TN - r31;
+  float guard_mr = 0.f, guard_mc = 0.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) guard_mc = fmaxf(guard_mc, cs[j]);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1490,7 +1513,7 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
         const int rrow = i * 32 + e1 + 8 * e4;
         const unsigned so = (unsigned)rrow * ncol * 4u;      // scalar
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
           const float v = acc[i][j][e] * (rr[e1] * cs[j]);
           if (full && nt) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vO + (unsigned)j * 128u, (int)so, 2);
@@ -1506,7 +1529,7 @@ __global__ void __launch_bounds__(256, 3) k_gemm_h2(ConvArgs a) {
   // range guard: elements of a row / column far below its maximum are carried with an ABSOLUTE error of
   // 2^-28 of that maximum, so a product's error can reach cin * 2^-27 * max|row| * max|column|; the scales bound the maxima
   // (max < 2^15 / scale).  A lane's rows x a lane's columns are exactly its outputs.
-  if (a.guard && guard_mr * fmaxf(cs[0], cs[1]) * (8.f * (float)a.cin) > a.guard_lim) atomicOr(a.guard, 1);
+  if (a.guard && guard_mr * guard_mc * (8.f * (float)a.cin) > a.guard_lim) atomicOr(a.guard, 1);
 }
 
 // The gathered pair GEMM (pcc_conv_fwd_pairs, pcc_convt_fwd_rows: one kernel offset per 128-pair tile, T[pair] = x[in(pair)] W[k])
@@ -2628,8 +2651,22 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
     if (!a.feath) PCC_TRY(make_planes_h(a, s));
     a.dbg = g_dbg;
     a.nt = g_nt;
-    const dim3 g2 = grid(128);
     prof_note(PCC_FORM_GEMM_H2, 2.0 * a.n_out * a.cin * a.cout, 4.0 * ((double)a.n_out * a.cin + (double)a.n_out * a.cout + (double)a.cin * a.cout));
+    // 128 x 256 tiles for the wide products (the 7x7x7 composites: 5 488 / 21 952 columns) with enough tiles to fill the
+    // chip at two workgroups per CU: a quarter less operand traffic from L2 (env PCC_GEMM_WIDE=0: the 128 x 128 tile)
+    static const bool wide_on = getenv("PCC_GEMM_WIDE") ? atoi(getenv("PCC_GEMM_WIDE")) != 0 : true;
+    const long long gy2 = (a.cout_pad + 255) / 256;
+    if (wide_on && (a.ppo == 4 || a.ppo == 2) && a.cout_pad >= 2048 && (size_t)128 * a.cout * 4 + 1024 < (1ull << 31)) {
+      long long t2 = pcc_cdiv(a.n_out, 128);
+      if (gy2 > 8) t2 = (t2 + 7) / 8 * 8;
+      if (t2 * gy2 >= 1024) {
+        const dim3 gw((unsigned)((t2 * gy2 + 7) / 8 * 8));
+        if (a.ppo == 4) k_gemm_h2<4, 4><<<gw, 256, 0, s>>>(a); else k_gemm_h2<2, 4><<<gw, 256, 0, s>>>(a);
+        PCC_LAUNCH_CHECK();
+        return PCC_OK;
+      }
+    }
+    const dim3 g2 = grid(128);
     switch (a.ppo) {
       case 1: k_gemm_h2<1><<<g2, 256, 0, s>>>(a); break;
       case 2: k_gemm_h2<2><<<g2, 256, 0, s>>>(a); break;
@@ -3648,6 +3685,9 @@ struct GatherCsrArgs {
   const float* ex_tab;                                    //   as subset-sum tables [4][128][cout] over 7+7+7+6 neighbour bits (k_presence_tables)
   PccGrid ex_grid; const long long* out_keys;             //   presence flags from a [K][n_out] table (ex_nbr) or the set's grid index
   int nt;                                                 // g_nt: 4 = non-temporal product loads, 8 = non-temporal output stores
+  // k_convt_gather_csr_proj (16 output channels): the occupancy head's second convolution starts in the epilogue -- the 27
+  // projections t[k][o] = <out[o], w2[k]> of a finished row leave as planes [27][tstride]; `out` itself is not stored
+  const float* w2 = nullptr; float* t = nullptr; long long tstride = 0;
 };
 
 template <int VEC, int JB>
@@ -3764,6 +3804,122 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
   }
 }
 
+// Composite level with 16 hidden channels + the projections of the head's second convolution (round 4).  The hidden layer of a
+// composite level is read exactly once, by the 27 projections t[k][o] = <hidden[o], w2[k]> of the 16 -> 1 convolution that
+// follows it (model/transforms.py:141-160), so they are taken here, from the registers of the gather-sum, on the matrix pipe, and
+// the layer's 0.93 GB are neither written nor read back (k_thin_project_z read them to write the same 27 planes).
+// A wave owns 16 consecutive rows (four lanes per row, as in k_convt_gather_csr<4, 4>).  One lane permutation (lane i*4 + q ->
+// lane q*16 + i) turns "lane = (row, channel quad)" into the A layout of v_mfma_f32_16x16x4_f32 with reduction slice k <->
+// channels {4k + kk}; 4 MFMAs per block of 16 planes leave D[row 4q + v][plane] in lane (q, plane).  The workgroup's 64 rows x 27
+// planes meet in LDS and leave as 256 contiguous bytes per plane (whole cache lines: stored straight from the MFMA layout, 64-byte
+// half lines per wave, the kernel took 1.60 ms on the benchmark's last level against 1.13 for the plain gather-sum; with a wave
+// making four passes to collect whole lines in registers, 2.14 -- a quarter of the occupancy).
+__global__ void __launch_bounds__(256) k_convt_gather_csr_proj(GatherCsrArgs a) {
+  constexpr int JB = 4;
+  __shared__ __attribute__((aligned(16))) float ts[27][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, cl = lane & 3, ri = lane >> 2;
+  const long long wgbase = (long long)blockIdx.x * 64;
+  const int r16 = lane & 15, kq = lane >> 4;
+  float4 wv2[2];                                                     // this lane's B operands: plane r16 (+ 16), channels {4 kq + kk}
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    const int plane = jb * 16 + r16;
+    wv2[jb] = plane < 27 ? reinterpret_cast<const float4*>(a.w2 + plane * 16)[kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float4 bias4 = a.bias ? reinterpret_cast<const float4*>(a.bias)[cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const PccGrid& g = a.ex_grid;
+  const long long col_stride = g.dims[2], slab_stride = (long long)g.dims[1] * g.dims[2];
+  const long long cells = (long long)g.nbatch * g.dims[0] * slab_stride;
+  const long long last_dw = 2 * ((cells + 63) >> 6) - 2;
+  const unsigned* const bits32 = reinterpret_cast<const unsigned*>(g.bits);
+  {
+    const long long o_raw = wgbase + wv * 16 + ri;
+    const long long o = o_raw < a.n_out ? o_raw : a.n_out - 1;     // (tail rows repeat the last row; never stored)
+    const int t0 = a.first[o], t1 = a.first[o + 1];
+    // 3x3x3 presence from the output set's bitmap: this lane's (dx, dy) columns cl, cl + 4, cl + 8 as 64-bit windows (see
+    // k_convt_gather_csr), all loads in flight together and consumed after the pair loop
+    const long long key = a.out_keys[o];
+    const int b = (int)(key >> 48);
+    const int cx = (((int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - g.lo[0]) >> g.ts_log2);
+    const int cy = (((int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - g.lo[1]) >> g.ts_log2);
+    const int cz = (((int)(key & 0xFFFF) - (int)PCC_BIAS - g.lo[2]) >> g.ts_log2);
+    const int z_lo = cz > 0 ? cz - 1 : 0, z_hi = cz + 1 < g.dims[2] ? cz + 1 : g.dims[2] - 1;
+    const int p_nz = z_hi - z_lo + 1, p_dz0 = z_lo - cz + 1;
+    const long long cell0 = (((long long)b * g.dims[0] + cx) * g.dims[1] + cy) * g.dims[2] + z_lo;
+    unsigned pw_lo[3], pw_hi[3];
+    int psh[3], pcol[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int c = cl + t * 4;
+      const int dx = c % 3 - 1, dy = c / 3 - 1;
+      const int nx = cx + dx, ny = cy + dy;
+      const bool ok = c < 9 && nx >= 0 && ny >= 0 && nx < g.dims[0] && ny < g.dims[1];
+      const long long cell = ok ? cell0 + dx * slab_stride + dy * col_stride : 0ll;
+      const long long dw = cell >> 5, dw2 = dw < last_dw ? dw : last_dw;
+      psh[t] = ok ? (int)(cell & 31) + 32 * (int)(dw - dw2) : 64;
+      pcol[t] = c;
+      pw_lo[t] = bits32[dw2];
+      pw_hi[t] = bits32[dw2 + 1];
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = t0; t < t1; t += JB) {                              // branch-free batches, pair id ascending (as k_convt_gather_csr)
+      int pid[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) pid[u] = a.pair_ids[min(t + u, t1 - 1)];
+      float4 x[JB];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) x[u] = reinterpret_cast<const float4*>(a.T + (long long)pid[u] * 16)[cl];
+#pragma unroll
+      for (int u = 0; u < JB; ++u) thin_fma(acc, x[u], (t + u < t1) ? 1.f : 0.f);
+    }
+    unsigned pm = 0;
+    const unsigned fmask = (1u << p_nz) - 1u;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const unsigned long long w = (unsigned long long)pw_lo[t] | ((unsigned long long)pw_hi[t] << 32);
+      const unsigned f = psh[t] < 64 ? (unsigned)(w >> (psh[t] & 63)) & fmask : 0u;
+      pm |= ((f & 1u) | ((f & 2u) << 8) | ((f & 4u) << 16)) << (pcol[t] + 9 * p_dz0);
+    }
+    pm |= __shfl_xor((int)pm, 2);
+    pm |= __shfl_xor((int)pm, 1);
+    const float4* tb = reinterpret_cast<const float4*>(a.ex_tab);
+    thin_acc(acc, tb[(pm & 127u) * 4 + cl]);
+    thin_acc(acc, tb[(128u + ((pm >> 7) & 127u)) * 4 + cl]);
+    thin_acc(acc, tb[(256u + ((pm >> 14) & 127u)) * 4 + cl]);
+    thin_acc(acc, tb[(384u + ((pm >> 21) & 63u)) * 4 + cl]);
+    thin_acc(acc, bias4);
+    thin_act(acc, a.act, a.slope);
+    // lane i*4 + q holds channels 4q .. 4q+3 of wave row i; A operand of MFMA kk: lane (k*16 + i) = channel 4k + kk of row i
+    const int src = (r16 << 2) | kq;
+    const float hx = __shfl(acc.x, src), hy = __shfl(acc.y, src), hz = __shfl(acc.z, src), hw = __shfl(acc.w, src);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      f32x4 dd = {0.f, 0.f, 0.f, 0.f};
+      dd = __builtin_amdgcn_mfma_f32_16x16x4f32(hx, wv2[jb].x, dd, 0, 0, 0);   // fixed order: channel residues 0, 1, 2, 3
+      dd = __builtin_amdgcn_mfma_f32_16x16x4f32(hy, wv2[jb].y, dd, 0, 0, 0);
+      dd = __builtin_amdgcn_mfma_f32_16x16x4f32(hz, wv2[jb].z, dd, 0, 0, 0);
+      dd = __builtin_amdgcn_mfma_f32_16x16x4f32(hw, wv2[jb].w, dd, 0, 0, 0);
+      const int plane = jb * 16 + r16;                               // D[row 4 kq + v][plane]
+      if (plane < 27) *reinterpret_cast<float4*>(&ts[plane][wv * 16 + 4 * kq]) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+    }
+  }
+  __syncthreads();
+  // 27 planes x 16 pieces of 16 bytes: 256 contiguous bytes per plane
+  for (int idx = threadIdx.x; idx < 27 * 16; idx += 256) {
+    const int plane = idx >> 4, q4 = idx & 15;
+    const long long row = wgbase + 4 * q4;
+    const float4 val = *reinterpret_cast<const float4*>(&ts[plane][4 * q4]);
+    float* const dst = a.t + (long long)plane * a.tstride + row;
+    if (row + 3 < a.n_out) {
+      if (a.nt & 16) nt_store(val, reinterpret_cast<float4*>(dst));
+      else *reinterpret_cast<float4*>(dst) = val;
+    } else {
+      const float e4[4] = {val.x, val.y, val.z, val.w};
+      for (int e = 0; e < 4; ++e) if (row + e < a.n_out) dst[e] = e4[e];
+    }
+  }
+}
+
 static int presence_tables(const float* ex_bias, int cout, const float** tab, hipStream_t s) {
   void* p = nullptr;
   PCC_TRY(lib_scratch_small((size_t)512 * cout * 4, &p));
@@ -3778,10 +3934,11 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
                               const float* bias, int32_t K, int32_t cout, const int32_t* first,
                               const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
                               const int32_t* ex_nbr, int32_t ex_K, const float* ex_bias, const PccGrid* ex_grid,
-                              const long long* ex_keys, int32_t arith, int32_t* d_guard, void* stream) {
+                              const long long* ex_keys, int32_t arith, int32_t* d_guard, void* stream,
+                              const float* proj_w2 = nullptr, float* proj_t = nullptr, long long proj_stride = 0) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0 || n_in <= 0) return PCC_OK;
-  PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && out, "pcc_convt_fwd_csr: NULL array");
+  PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && (out || proj_t), "pcc_convt_fwd_csr: NULL array");
   PCC_REQUIRE(K >= 1 && K <= MAXK_T && mfma_ok(cin, K * cout), "pcc_convt_fwd_csr: unsupported shape K=%d cin=%d cout=%d", K, cin, cout);
   PCC_REQUIRE(!ex_nbr || (ex_bias && ex_K >= 1), "pcc_convt_fwd_csr: ex_nbr needs ex_bias and ex_K");
   PCC_REQUIRE(act >= 0 && act <= 2, "pcc_convt_fwd_csr: bad activation");
@@ -3817,7 +3974,12 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
   const int64_t waves = pcc_cdiv(n_out, 64 >> l);
   const unsigned gg = (unsigned)pcc_cdiv(waves, 4);
   // pair slots per batch of independent loads: narrow outputs (the last level, ~4 pairs per row) take 4, the others 8
-  if (vec == 4 && l <= 2) k_convt_gather_csr<4, 4><<<gg, 256, 0, s>>>(g);
+  if (proj_t) {
+    PCC_REQUIRE(cout == 16 && proj_w2 && proj_stride >= n_out && proj_stride % 4 == 0, "pcc_convt_fwd_csr: the fused head needs 16 hidden channels");
+    PCC_REQUIRE(g.ex_grid.bits && g.ex_tab && act >= 0, "pcc_convt_fwd_csr: the fused head needs the output set's grid index and the neighbour constants");
+    g.w2 = proj_w2; g.t = proj_t; g.tstride = proj_stride;
+    k_convt_gather_csr_proj<<<(unsigned)pcc_cdiv(n_out, 64), 256, 0, s>>>(g);
+  } else if (vec == 4 && l <= 2) k_convt_gather_csr<4, 4><<<gg, 256, 0, s>>>(g);
   else if (vec == 4) k_convt_gather_csr<4, 8><<<gg, 256, 0, s>>>(g);
   else k_convt_gather_csr<1, 8><<<gg, 256, 0, s>>>(g);
   PCC_LAUNCH_CHECK();
@@ -4069,6 +4231,7 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
 static bool g_thin_grid1 = getenv("PCC_THIN_GRID1") ? atoi(getenv("PCC_THIN_GRID1")) != 0 : true;
 struct ThinGridArgs {
   const float* t; const float* bias; const long long* keys; PccGrid g; float* out; long long n; int cout;
+  long long tstride = 0;          // k_thin_gather_grid1: elements between planes (0: n)
 };
 
 template <int COUT_MAX>
@@ -4144,8 +4307,9 @@ __global__ void __launch_bounds__(256) k_thin_gather_grid1(ThinGridArgs a) {
     rk[c] = g.rank[wi];
     w1[c] = (sh[c] + nz > 64) ? g.bits[wi + 1] : 0ull;        // (rare: the field straddles two words)
   }
+  const unsigned ts = (unsigned)(a.tstride ? a.tstride : a.n);
   const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.t), (short)0,
-                                                                       (int)(unsigned)((size_t)27 * a.n * 4), 0x00020000);
+                                                                       (int)(unsigned)((size_t)27 * ts * 4), 0x00020000);
   float v[27];
 #pragma unroll
   for (int c = 0; c < 9; ++c) {
@@ -4157,7 +4321,7 @@ __global__ void __launch_bounds__(256) k_thin_gather_grid1(ThinGridArgs a) {
     for (int t = 0; t < 3; ++t) {
       const int k = c + 9 * (dz0 + t);                         // (k < 27 whenever bit t can be set: t < nz)
       const unsigned row = (unsigned)(r + __popc(f & ((1u << t) - 1u)));
-      const unsigned off = ((f >> t) & 1u) ? ((unsigned)k * (unsigned)a.n + row) * 4u : BUF_OOB;
+      const unsigned off = ((f >> t) & 1u) ? ((unsigned)k * ts + row) * 4u : BUF_OOB;
       v[c * 3 + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, off, 0, 0));
     }
   }
@@ -4338,6 +4502,36 @@ extern "C" int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin,
   if (cout == 1 && (size_t)27 * n * 4 <= (size_t)BUF_MAX_BYTES && g_thin_grid1) k_thin_gather_grid1<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
   else if (cout == 1) k_thin_gather_grid<1><<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
   else k_thin_gather_grid<4><<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+// Composite level + the head's second convolution (round 4): pcc_convt_fwd_csr_grid for 16 hidden channels whose gather-sum
+// projects every finished row on the 27 kernels of the 16 -> 1 convolution (hidden layer never stored), followed by the
+// one-channel gather over the candidate set's grid index: logits[o] = bias2 + sum_k <relu(hidden[nbr_k(o)]), w2[k]>.
+extern "C" size_t pcc_convt_head_ws_bytes(int64_t n_out) { return (size_t)27 * (size_t)((n_out + 3) / 4 * 4 + 4) * sizeof(float) + 256; }
+
+extern "C" int pcc_convt_fwd_csr_grid_head(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
+                                           const float* bias, int32_t K, int32_t cout, const int32_t* first,
+                                           const int32_t* pair_ids, int64_t n_out, float* T, int32_t act, float slope,
+                                           const int64_t* out_keys, const uint64_t* out_bits, const int32_t* out_rank,
+                                           const int32_t* h_out, const float* ex_bias, const float* w2, const float* bias2,
+                                           float* logits, void* ws, size_t ws_bytes, int32_t arith, int32_t* d_guard,
+                                           void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out <= 0 || n_in <= 0) return PCC_OK;
+  PCC_REQUIRE(out_keys && out_bits && out_rank && h_out && ex_bias && w2 && logits && ws, "pcc_convt_fwd_csr_grid_head: NULL array");
+  PCC_REQUIRE(cout == 16, "pcc_convt_fwd_csr_grid_head: 16 hidden channels only (cout=%d)", cout);
+  if (ws_bytes < pcc_convt_head_ws_bytes(n_out)) { pcc_set_error("pcc_convt_fwd_csr_grid_head: workspace too small"); return PCC_EWS; }
+  const long long stride = (n_out + 3) / 4 * 4;
+  PCC_REQUIRE((size_t)27 * stride * 4 <= (size_t)BUF_MAX_BYTES, "pcc_convt_fwd_csr_grid_head: too many rows");
+  float* t = (float*)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+  const PccGrid ex = grid_from_host(out_bits, out_rank, h_out);
+  PCC_TRY(convt_fwd_csr_impl(feat_in, n_in, cin, packed_w, bias, K, cout, first, pair_ids, n_out, T, nullptr, act, slope, nullptr, 27,
+                             ex_bias, &ex, (const long long*)out_keys, arith, d_guard, stream, w2, t, stride));
+  ThinGridArgs a;
+  a.t = t; a.bias = bias2; a.keys = (const long long*)out_keys; a.g = ex; a.out = logits; a.n = n_out; a.cout = 1; a.tstride = stride;
+  k_thin_gather_grid1<<<(unsigned)pcc_cdiv(n_out, 256), 256, 0, s>>>(a);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

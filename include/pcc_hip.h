@@ -311,17 +311,6 @@ int pcc_convt_fwd_csr_grid(const float* feat_in, int64_t n_in, int32_t cin, cons
                            float* out, int32_t act, float slope, const int64_t* out_keys, const uint64_t* out_bits,
                            const int32_t* out_rank, const int32_t* h_out, const float* ex_bias, int32_t arith,
                            int32_t* d_guard /*nullable*/, void* stream);
-/* pcc_convt_fwd_csr_grid for 16 hidden channels followed by the occupancy head's second convolution (16 -> 1, 3x3x3;
- * model/transforms.py:141-160 `predict_i[2]`): the gather-sum projects each finished hidden row on the 27 kernels of w2 in its
- * epilogue (the hidden layer is never stored), then logits[o] = bias2 + sum_k <act(hidden[nbr_k(o)]), w2[k]> is gathered over the
- * candidate set's own grid index.  w2: pcc_conv_pack_weights(27, 16, 1) thin layout [27][16]; ws: pcc_convt_head_ws_bytes(n_out). */
-size_t pcc_convt_head_ws_bytes(int64_t n_out);
-int pcc_convt_fwd_csr_grid_head(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias /*nullable*/,
-                                int32_t K, int32_t cout /*16*/, const int32_t* first, const int32_t* pair_ids, int64_t n_out, float* T,
-                                int32_t act, float slope, const int64_t* out_keys, const uint64_t* out_bits, const int32_t* out_rank,
-                                const int32_t* h_out, const float* ex_bias, const float* w2, const float* bias2 /*nullable [1]*/,
-                                float* logits /*[n_out]*/, void* ws, size_t ws_bytes, int32_t arith, int32_t* d_guard /*nullable*/,
-                                void* stream);
 /* Chunked form of pcc_convt_fwd_csr for 7x7x7 composite levels: the per-pair products never exist as a whole.  Parent rows
  * are processed in chunks whose products fit the Infinity Cache (pcc_set_t_chunk_bytes, default 96 MiB; env PCC_T_CHUNK_MIB):
  * GEMM chunk -> staging buffer T (pcc_convt_chunk_t_bytes) -> ordered gather-sum of the children that chunk reaches, partial

@@ -2652,9 +2652,11 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
     a.dbg = g_dbg;
     a.nt = g_nt;
     prof_note(PCC_FORM_GEMM_H2, 2.0 * a.n_out * a.cin * a.cout, 4.0 * ((double)a.n_out * a.cin + (double)a.n_out * a.cout + (double)a.cin * a.cout));
-    // 128 x 256 tiles for the wide products (the 7x7x7 composites: 5 488 / 21 952 columns) with enough tiles to fill the
-    // chip at two workgroups per CU: a quarter less operand traffic from L2 (env PCC_GEMM_WIDE=0: the 128 x 128 tile)
-    static const bool wide_on = getenv("PCC_GEMM_WIDE") ? atoi(getenv("PCC_GEMM_WIDE")) != 0 : true;
+    // 128 x 256 tiles for the wide products (the 7x7x7 composites: 5 488 / 21 952 columns): a quarter less operand traffic from
+    // L2, bit-identical results -- and 2 % SLOWER on the benchmark's three levels (2.77 against 2.72 ms per step, round 4: two
+    // workgroups per CU instead of three; the kernel is bound by its product stores, not by the operand stream).  Off; env
+    // PCC_GEMM_WIDE=1 selects it (tests/test_gpu_map_conv.py runs it in a child process).
+    static const bool wide_on = getenv("PCC_GEMM_WIDE") ? atoi(getenv("PCC_GEMM_WIDE")) != 0 : false;
     const long long gy2 = (a.cout_pad + 255) / 256;
     if (wide_on && (a.ppo == 4 || a.ppo == 2) && a.cout_pad >= 2048 && (size_t)128 * a.cout * 4 + 1024 < (1ull << 31)) {
       long long t2 = pcc_cdiv(a.n_out, 128);
@@ -3685,9 +3687,6 @@ struct GatherCsrArgs {
   const float* ex_tab;                                    //   as subset-sum tables [4][128][cout] over 7+7+7+6 neighbour bits (k_presence_tables)
   PccGrid ex_grid; const long long* out_keys;             //   presence flags from a [K][n_out] table (ex_nbr) or the set's grid index
   int nt;                                                 // g_nt: 4 = non-temporal product loads, 8 = non-temporal output stores
-  // k_convt_gather_csr_proj (16 output channels): the occupancy head's second convolution starts in the epilogue -- the 27
-  // projections t[k][o] = <out[o], w2[k]> of a finished row leave as planes [27][tstride]; `out` itself is not stored
-  const float* w2 = nullptr; float* t = nullptr; long long tstride = 0;
 };
 
 template <int VEC, int JB>
@@ -3804,122 +3803,11 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
   }
 }
 
-// Composite level with 16 hidden channels + the projections of the head's second convolution (round 4).  The hidden layer of a
-// composite level is read exactly once, by the 27 projections t[k][o] = <hidden[o], w2[k]> of the 16 -> 1 convolution that
-// follows it (model/transforms.py:141-160), so they are taken here, from the registers of the gather-sum, on the matrix pipe, and
-// the layer's 0.93 GB are neither written nor read back (k_thin_project_z read them to write the same 27 planes).
-// A wave owns 16 consecutive rows (four lanes per row, as in k_convt_gather_csr<4, 4>).  One lane permutation (lane i*4 + q ->
-// lane q*16 + i) turns "lane = (row, channel quad)" into the A layout of v_mfma_f32_16x16x4_f32 with reduction slice k <->
-// channels {4k + kk}; 4 MFMAs per block of 16 planes leave D[row 4q + v][plane] in lane (q, plane).  The workgroup's 64 rows x 27
-// planes meet in LDS and leave as 256 contiguous bytes per plane (whole cache lines: stored straight from the MFMA layout, 64-byte
-// half lines per wave, the kernel took 1.60 ms on the benchmark's last level against 1.13 for the plain gather-sum; with a wave
-// making four passes to collect whole lines in registers, 2.14 -- a quarter of the occupancy).
-__global__ void __launch_bounds__(256) k_convt_gather_csr_proj(GatherCsrArgs a) {
-  constexpr int JB = 4;
-  __shared__ __attribute__((aligned(16))) float ts[27][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, cl = lane & 3, ri = lane >> 2;
-  const long long wgbase = (long long)blockIdx.x * 64;
-  const int r16 = lane & 15, kq = lane >> 4;
-  float4 wv2[2];                                                     // this lane's B operands: plane r16 (+ 16), channels {4 kq + kk}
-#pragma unroll
-  for (int jb = 0; jb < 2; ++jb) {
-    const int plane = jb * 16 + r16;
-    wv2[jb] = plane < 27 ? reinterpret_cast<const float4*>(a.w2 + plane * 16)[kq] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const float4 bias4 = a.bias ? reinterpret_cast<const float4*>(a.bias)[cl] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const PccGrid& g = a.ex_grid;
-  const long long col_stride = g.dims[2], slab_stride = (long long)g.dims[1] * g.dims[2];
-  const long long cells = (long long)g.nbatch * g.dims[0] * slab_stride;
-  const long long last_dw = 2 * ((cells + 63) >> 6) - 2;
-  const unsigned* const bits32 = reinterpret_cast<const unsigned*>(g.bits);
-  {
-    const long long o_raw = wgbase + wv * 16 + ri;
-    const long long o = o_raw < a.n_out ? o_raw : a.n_out - 1;     // (tail rows repeat the last row; never stored)
-    const int t0 = a.first[o], t1 = a.first[o + 1];
-    // 3x3x3 presence from the output set's bitmap: this lane's (dx, dy) columns cl, cl + 4, cl + 8 as 64-bit windows (see
-    // k_convt_gather_csr), all loads in flight together and consumed after the pair loop
-    const long long key = a.out_keys[o];
-    const int b = (int)(key >> 48);
-    const int cx = (((int)((key >> 32) & 0xFFFF) - (int)PCC_BIAS - g.lo[0]) >> g.ts_log2);
-    const int cy = (((int)((key >> 16) & 0xFFFF) - (int)PCC_BIAS - g.lo[1]) >> g.ts_log2);
-    const int cz = (((int)(key & 0xFFFF) - (int)PCC_BIAS - g.lo[2]) >> g.ts_log2);
-    const int z_lo = cz > 0 ? cz - 1 : 0, z_hi = cz + 1 < g.dims[2] ? cz + 1 : g.dims[2] - 1;
-    const int p_nz = z_hi - z_lo + 1, p_dz0 = z_lo - cz + 1;
-    const long long cell0 = (((long long)b * g.dims[0] + cx) * g.dims[1] + cy) * g.dims[2] + z_lo;
-    unsigned pw_lo[3], pw_hi[3];
-    int psh[3], pcol[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int c = cl + t * 4;
-      const int dx = c % 3 - 1, dy = c / 3 - 1;
-      const int nx = cx + dx, ny = cy + dy;
-      const bool ok = c < 9 && nx >= 0 && ny >= 0 && nx < g.dims[0] && ny < g.dims[1];
-      const long long cell = ok ? cell0 + dx * slab_stride + dy * col_stride : 0ll;
-      const long long dw = cell >> 5, dw2 = dw < last_dw ? dw : last_dw;
-      psh[t] = ok ? (int)(cell & 31) + 32 * (int)(dw - dw2) : 64;
-      pcol[t] = c;
-      pw_lo[t] = bits32[dw2];
-      pw_hi[t] = bits32[dw2 + 1];
-    }
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = t0; t < t1; t += JB) {                              // branch-free batches, pair id ascending (as k_convt_gather_csr)
-      int pid[JB];
-#pragma unroll
-      for (int u = 0; u < JB; ++u) pid[u] = a.pair_ids[min(t + u, t1 - 1)];
-      float4 x[JB];
-#pragma unroll
-      for (int u = 0; u < JB; ++u) x[u] = reinterpret_cast<const float4*>(a.T + (long long)pid[u] * 16)[cl];
-#pragma unroll
-      for (int u = 0; u < JB; ++u) thin_fma(acc, x[u], (t + u < t1) ? 1.f : 0.f);
-    }
-    unsigned pm = 0;
-    const unsigned fmask = (1u << p_nz) - 1u;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const unsigned long long w = (unsigned long long)pw_lo[t] | ((unsigned long long)pw_hi[t] << 32);
-      const unsigned f = psh[t] < 64 ? (unsigned)(w >> (psh[t] & 63)) & fmask : 0u;
-      pm |= ((f & 1u) | ((f & 2u) << 8) | ((f & 4u) << 16)) << (pcol[t] + 9 * p_dz0);
-    }
-    pm |= __shfl_xor((int)pm, 2);
-    pm |= __shfl_xor((int)pm, 1);
-    const float4* tb = reinterpret_cast<const float4*>(a.ex_tab);
-    thin_acc(acc, tb[(pm & 127u) * 4 + cl]);
-    thin_acc(acc, tb[(128u + ((pm >> 7) & 127u)) * 4 + cl]);
-    thin_acc(acc, tb[(256u + ((pm >> 14) & 127u)) * 4 + cl]);
-    thin_acc(acc, tb[(384u + ((pm >> 21) & 63u)) * 4 + cl]);
-    thin_acc(acc, bias4);
-    thin_act(acc, a.act, a.slope);
-    // lane i*4 + q holds channels 4q .. 4q+3 of wave row i; A operand of MFMA kk: lane (k*16 + i) = channel 4k + kk of row i
-    const int src = (r16 << 2) | kq;
-    const float hx = __shfl(acc.x, src), hy = __shfl(acc.y, src), hz = __shfl(acc.z, src), hw = __shfl(acc.w, src);
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-      f32x4 dd = {0.f, 0.f, 0.f, 0.f};
-      dd = __builtin_amdgcn_mfma_f32_16x16x4f32(hx, wv2[jb].x, dd, 0, 0, 0);   // fixed order: channel residues 0, 1, 2, 3
-      dd = __builtin_amdgcn_mfma_f32_16x16x4f32(hy, wv2[jb].y, dd, 0, 0, 0);
-      dd = __builtin_amdgcn_mfma_f32_16x16x4f32(hz, wv2[jb].z, dd, 0, 0, 0);
-      dd = __builtin_amdgcn_mfma_f32_16x16x4f32(hw, wv2[jb].w, dd, 0, 0, 0);
-      const int plane = jb * 16 + r16;                               // D[row 4 kq + v][plane]
-      if (plane < 27) *reinterpret_cast<float4*>(&ts[plane][wv * 16 + 4 * kq]) = make_float4(dd[0], dd[1], dd[2], dd[3]);
-    }
-  }
-  __syncthreads();
-  // 27 planes x 16 pieces of 16 bytes: 256 contiguous bytes per plane
-  for (int idx = threadIdx.x; idx < 27 * 16; idx += 256) {
-    const int plane = idx >> 4, q4 = idx & 15;
-    const long long row = wgbase + 4 * q4;
-    const float4 val = *reinterpret_cast<const float4*>(&ts[plane][4 * q4]);
-    float* const dst = a.t + (long long)plane * a.tstride + row;
-    if (row + 3 < a.n_out) {
-      if (a.nt & 16) nt_store(val, reinterpret_cast<float4*>(dst));
-      else *reinterpret_cast<float4*>(dst) = val;
-    } else {
-      const float e4[4] = {val.x, val.y, val.z, val.w};
-      for (int e = 0; e < 4; ++e) if (row + e < a.n_out) dst[e] = e4[e];
-    }
-  }
-}
-
+// (Round 4 built the head's 27 projections INTO this kernel for the 16-channel level -- from the gather-sum's registers, on the
+//  matrix pipe, hidden layer never stored -- three ways: stored straight from the MFMA layout (64-byte half lines per wave) 1.60 ms,
+//  a wave making four passes to collect whole lines in registers 2.14 (a quarter of the occupancy), the workgroup's planes staged
+//  through LDS 1.76 -- against 1.13 for this kernel + 0.58 for k_thin_project_z.  The gather-sum is latency-bound: every
+//  instruction added behind its loads costs more than the streaming projection pass saves.  Removed; round-4 history.)
 static int presence_tables(const float* ex_bias, int cout, const float** tab, hipStream_t s) {
   void* p = nullptr;
   PCC_TRY(lib_scratch_small((size_t)512 * cout * 4, &p));
@@ -3934,11 +3822,10 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
                               const float* bias, int32_t K, int32_t cout, const int32_t* first,
                               const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
                               const int32_t* ex_nbr, int32_t ex_K, const float* ex_bias, const PccGrid* ex_grid,
-                              const long long* ex_keys, int32_t arith, int32_t* d_guard, void* stream,
-                              const float* proj_w2 = nullptr, float* proj_t = nullptr, long long proj_stride = 0) {
+                              const long long* ex_keys, int32_t arith, int32_t* d_guard, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0 || n_in <= 0) return PCC_OK;
-  PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && (out || proj_t), "pcc_convt_fwd_csr: NULL array");
+  PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && out, "pcc_convt_fwd_csr: NULL array");
   PCC_REQUIRE(K >= 1 && K <= MAXK_T && mfma_ok(cin, K * cout), "pcc_convt_fwd_csr: unsupported shape K=%d cin=%d cout=%d", K, cin, cout);
   PCC_REQUIRE(!ex_nbr || (ex_bias && ex_K >= 1), "pcc_convt_fwd_csr: ex_nbr needs ex_bias and ex_K");
   PCC_REQUIRE(act >= 0 && act <= 2, "pcc_convt_fwd_csr: bad activation");
@@ -3974,12 +3861,7 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
   const int64_t waves = pcc_cdiv(n_out, 64 >> l);
   const unsigned gg = (unsigned)pcc_cdiv(waves, 4);
   // pair slots per batch of independent loads: narrow outputs (the last level, ~4 pairs per row) take 4, the others 8
-  if (proj_t) {
-    PCC_REQUIRE(cout == 16 && proj_w2 && proj_stride >= n_out && proj_stride % 4 == 0, "pcc_convt_fwd_csr: the fused head needs 16 hidden channels");
-    PCC_REQUIRE(g.ex_grid.bits && g.ex_tab && act >= 0, "pcc_convt_fwd_csr: the fused head needs the output set's grid index and the neighbour constants");
-    g.w2 = proj_w2; g.t = proj_t; g.tstride = proj_stride;
-    k_convt_gather_csr_proj<<<(unsigned)pcc_cdiv(n_out, 64), 256, 0, s>>>(g);
-  } else if (vec == 4 && l <= 2) k_convt_gather_csr<4, 4><<<gg, 256, 0, s>>>(g);
+  if (vec == 4 && l <= 2) k_convt_gather_csr<4, 4><<<gg, 256, 0, s>>>(g);
   else if (vec == 4) k_convt_gather_csr<4, 8><<<gg, 256, 0, s>>>(g);
   else k_convt_gather_csr<1, 8><<<gg, 256, 0, s>>>(g);
   PCC_LAUNCH_CHECK();
@@ -4231,7 +4113,6 @@ extern "C" int pcc_convt_fwd_csr_chunked(const float* feat_in, int64_t n_in, int
 static bool g_thin_grid1 = getenv("PCC_THIN_GRID1") ? atoi(getenv("PCC_THIN_GRID1")) != 0 : true;
 struct ThinGridArgs {
   const float* t; const float* bias; const long long* keys; PccGrid g; float* out; long long n; int cout;
-  long long tstride = 0;          // k_thin_gather_grid1: elements between planes (0: n)
 };
 
 template <int COUT_MAX>
@@ -4307,9 +4188,8 @@ __global__ void __launch_bounds__(256) k_thin_gather_grid1(ThinGridArgs a) {
     rk[c] = g.rank[wi];
     w1[c] = (sh[c] + nz > 64) ? g.bits[wi + 1] : 0ull;        // (rare: the field straddles two words)
   }
-  const unsigned ts = (unsigned)(a.tstride ? a.tstride : a.n);
   const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.t), (short)0,
-                                                                       (int)(unsigned)((size_t)27 * ts * 4), 0x00020000);
+                                                                       (int)(unsigned)((size_t)27 * a.n * 4), 0x00020000);
   float v[27];
 #pragma unroll
   for (int c = 0; c < 9; ++c) {
@@ -4321,7 +4201,7 @@ __global__ void __launch_bounds__(256) k_thin_gather_grid1(ThinGridArgs a) {
     for (int t = 0; t < 3; ++t) {
       const int k = c + 9 * (dz0 + t);                         // (k < 27 whenever bit t can be set: t < nz)
       const unsigned row = (unsigned)(r + __popc(f & ((1u << t) - 1u)));
-      const unsigned off = ((f >> t) & 1u) ? ((unsigned)k * ts + row) * 4u : BUF_OOB;
+      const unsigned off = ((f >> t) & 1u) ? ((unsigned)k * (unsigned)a.n + row) * 4u : BUF_OOB;
       v[c * 3 + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, off, 0, 0));
     }
   }
@@ -4502,36 +4382,6 @@ extern "C" int pcc_conv_thin_grid_fwd(const float* feat, int64_t n, int32_t cin,
   if (cout == 1 && (size_t)27 * n * 4 <= (size_t)BUF_MAX_BYTES && g_thin_grid1) k_thin_gather_grid1<<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
   else if (cout == 1) k_thin_gather_grid<1><<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
   else k_thin_gather_grid<4><<<(unsigned)pcc_cdiv(n, 256), 256, 0, s>>>(a);
-  PCC_LAUNCH_CHECK();
-  return PCC_OK;
-}
-
-// Composite level + the head's second convolution (round 4): pcc_convt_fwd_csr_grid for 16 hidden channels whose gather-sum
-// projects every finished row on the 27 kernels of the 16 -> 1 convolution (hidden layer never stored), followed by the
-// one-channel gather over the candidate set's grid index: logits[o] = bias2 + sum_k <relu(hidden[nbr_k(o)]), w2[k]>.
-extern "C" size_t pcc_convt_head_ws_bytes(int64_t n_out) { return (size_t)27 * (size_t)((n_out + 3) / 4 * 4 + 4) * sizeof(float) + 256; }
-
-extern "C" int pcc_convt_fwd_csr_grid_head(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w,
-                                           const float* bias, int32_t K, int32_t cout, const int32_t* first,
-                                           const int32_t* pair_ids, int64_t n_out, float* T, int32_t act, float slope,
-                                           const int64_t* out_keys, const uint64_t* out_bits, const int32_t* out_rank,
-                                           const int32_t* h_out, const float* ex_bias, const float* w2, const float* bias2,
-                                           float* logits, void* ws, size_t ws_bytes, int32_t arith, int32_t* d_guard,
-                                           void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  if (n_out <= 0 || n_in <= 0) return PCC_OK;
-  PCC_REQUIRE(out_keys && out_bits && out_rank && h_out && ex_bias && w2 && logits && ws, "pcc_convt_fwd_csr_grid_head: NULL array");
-  PCC_REQUIRE(cout == 16, "pcc_convt_fwd_csr_grid_head: 16 hidden channels only (cout=%d)", cout);
-  if (ws_bytes < pcc_convt_head_ws_bytes(n_out)) { pcc_set_error("pcc_convt_fwd_csr_grid_head: workspace too small"); return PCC_EWS; }
-  const long long stride = (n_out + 3) / 4 * 4;
-  PCC_REQUIRE((size_t)27 * stride * 4 <= (size_t)BUF_MAX_BYTES, "pcc_convt_fwd_csr_grid_head: too many rows");
-  float* t = (float*)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
-  const PccGrid ex = grid_from_host(out_bits, out_rank, h_out);
-  PCC_TRY(convt_fwd_csr_impl(feat_in, n_in, cin, packed_w, bias, K, cout, first, pair_ids, n_out, T, nullptr, act, slope, nullptr, 27,
-                             ex_bias, &ex, (const long long*)out_keys, arith, d_guard, stream, w2, t, stride));
-  ThinGridArgs a;
-  a.t = t; a.bias = bias2; a.keys = (const long long*)out_keys; a.g = ex; a.out = logits; a.n = n_out; a.cout = 1; a.tstride = stride;
-  k_thin_gather_grid1<<<(unsigned)pcc_cdiv(n_out, 256), 256, 0, s>>>(a);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

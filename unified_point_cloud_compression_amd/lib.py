@@ -82,9 +82,6 @@ SIGNATURES = {
     "pcc_conv_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_convt_scatter_rows": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_convt_fwd_csr_grid": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p, _p, _p, C.POINTER(_i32), _p, _i32, _p, _p]),
-    "pcc_convt_head_ws_bytes": (_sz, [_i64]),
-    "pcc_convt_fwd_csr_grid_head": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _i32, _f32, _p, _p, _p, C.POINTER(_i32), _p,
-                                              _p, _p, _p, _p, _sz, _i32, _p, _p]),
     "pcc_set_t_chunk_bytes": (C.c_int, [_i64]),
     "pcc_convt_chunk_t_bytes": (_sz, [_i64, _i32, _i32]),
     "pcc_convt_chunk_ws_bytes": (_sz, [_i64, _i32, _i32]),

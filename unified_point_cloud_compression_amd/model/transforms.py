@@ -256,20 +256,14 @@ class SparseSynthesisTransform(nn.Module):
         if from_grid:
             # the candidate set's own bitmap + rank give the 27 neighbours of a row directly: no 3x3x3 kernel map of the
             # (large) candidate set is built, written and re-read for the presence flags and for the 1-channel convolution
-            w2 = c2._packed.get(c2.kernel, state_dict_order=True)
-            chunked = S.T_CHUNKED and cs_in.n * 343 * c0.out_channels * 4 >= S.T_CHUNKED_MIN_BYTES
-            if S.HEAD_IN_GATHER and not chunked and c0.out_channels == 16 and c2.out_channels == 1:
-                # narrow hidden layer: its 27 projections leave the gather-sum directly, the layer itself is never stored
-                logit = S.convt_forward_csr_grid_head(feats, packedM, c0.bias, 343, gen.in_channels, 16, csr7, out_set,
-                                                      L.ACT_RELU, cb, w2, c2.bias)
+            if S.T_CHUNKED and cs_in.n * 343 * c0.out_channels * 4 >= S.T_CHUNKED_MIN_BYTES:
+                h = S.convt_forward_csr_chunked(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, cs_in,
+                                                out_set, L.ACT_RELU, cb)
             else:
-                if chunked:
-                    h = S.convt_forward_csr_chunked(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, cs_in,
-                                                    out_set, L.ACT_RELU, cb)
-                else:
-                    h = S.convt_forward_csr_grid(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, out_set,
-                                                 L.ACT_RELU, cb)
-                logit = S.conv_thin_grid_forward(h, w2, c2.bias, c0.out_channels, c2.out_channels, out_set)
+                h = S.convt_forward_csr_grid(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, out_set,
+                                             L.ACT_RELU, cb)
+            w2 = c2._packed.get(c2.kernel, state_dict_order=True)
+            logit = S.conv_thin_grid_forward(h, w2, c2.bias, c0.out_channels, c2.out_channels, out_set)
         else:
             kmap3 = out_set.kernel_map(out_set, 3)
             h = S.convt_forward_csr(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, out_set.n,

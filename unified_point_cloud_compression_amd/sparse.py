@@ -789,30 +789,6 @@ def convt_forward_csr_grid(feats, packed_w, bias, K, cin, cout, csr, out_set, ac
     return out
 
 
-HEAD_IN_GATHER = os.environ.get("PCC_HEAD_IN_GATHER", "1") != "0"
-
-
-def convt_forward_csr_grid_head(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, w2, bias2, slope=0.01):
-    """Composite level + the head's second convolution in one call (16 hidden channels, one logit): the hidden layer is
-    projected on w2's 27 kernels inside the gather-sum and never stored.  Returns logits [n_out, 1]."""
-    feats = feats.contiguous()
-    n_in, n_out = feats.shape[0], out_set.n
-    logits = torch.empty((n_out, 1), dtype=torch.float32, device=feats.device)
-    if n_out == 0 or n_in == 0:
-        return logits
-    first, pair_ids = csr
-    g = out_set.grid()
-    T = torch.empty(n_in * K * cout, dtype=torch.float32, device=feats.device)
-    ws = L.workspace(L.load().pcc_convt_head_ws_bytes(n_out), feats.device)
-    b = bias.detach().reshape(-1).contiguous() if bias is not None else None
-    b2 = bias2.detach().reshape(-1).contiguous() if bias2 is not None else None
-    L.call("pcc_convt_fwd_csr_grid_head", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first), L.ptr(pair_ids),
-           n_out, L.ptr(T), act, float(slope), L.ptr(out_set.keys), L.ptr(g[0]), L.ptr(g[1]), g[2],
-           L.ptr(ex_bias.detach().to(torch.float32).contiguous()), L.ptr(w2), L.ptr(b2), L.ptr(logits), L.ptr(ws), ws.numel(),
-           *L.arith_args(feats.device), L.stream())
-    return logits
-
-
 def convt_forward_csr_chunked(feats, packed_w, bias, K, cin, cout, csr, in_set, out_set, act, ex_bias=None, slope=0.01):
     """`convt_forward_csr` / `convt_forward_csr_grid` without the whole per-pair buffer: parent rows go through in chunks
     whose products fit the Infinity Cache (staging buffer in the shared workspace), partial sums carried in the output."""

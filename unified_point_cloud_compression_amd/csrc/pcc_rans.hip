@@ -143,10 +143,15 @@ RANS_HD unsigned* r_encode(const int* sym, const int* idx, int ch0, long long n,
 
 // The decoder keeps the next 32-bit word in a register (`nw`), re-loading right after it is consumed, so the
 // renormalisation read is off the state's critical path.
-RANS_HD unsigned r_get_bits(unsigned long long& x, const unsigned*& ptr, unsigned& nw) {
+// `last`: the last word that may be read (the buffer's final word).  A well-formed stream never gets there; a corrupt one
+// re-reads it instead of running past the buffer, and the caller sees from the returned pointer that more was consumed than
+// the stream holds.
+RANS_HD unsigned r_next(const unsigned*& ptr, const unsigned* last) { ++ptr; return *(ptr <= last ? ptr : last); }
+
+RANS_HD unsigned r_get_bits(unsigned long long& x, const unsigned*& ptr, unsigned& nw, const unsigned* last) {
   const unsigned v = (unsigned)(x & R_MAXB);
   x >>= R_BYP;
-  if (x < R_L) { x = (x << 32) | nw; nw = *++ptr; }
+  if (x < R_L) { x = (x << 32) | nw; nw = r_next(ptr, last); }
   return v;
 }
 
@@ -156,11 +161,11 @@ RANS_HD unsigned r_get_bits(unsigned long long& x, const unsigned*& ptr, unsigne
 // is one LDS look-up plus a short LDS scan; without it every symbol costs a binary search of dependent global loads.
 struct RansDecTab { const int* row_off; const unsigned short* lut; const unsigned short* cdf16; };
 
-RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int ch0, long long n, int gl, long long stride,
-                                 RansTab t, RansDecTab d, int* out) {
-  unsigned long long x = (unsigned long long)ptr[0] | ((unsigned long long)ptr[1] << 32);
-  ptr += 2;
-  unsigned nw = *ptr;                                 // look-ahead word (the buffer is padded by one word)
+RANS_HD const unsigned* r_decode(const unsigned* ptr, const unsigned* last, const int* idx, int ch0, long long n, int gl,
+                                 long long stride, RansTab t, RansDecTab d, int* out) {
+  unsigned long long x = (unsigned long long)ptr[0] | ((unsigned long long)ptr[1] << 32);   // (callers check: >= 2 words)
+  ++ptr;
+  unsigned nw = r_next(ptr, last);                    // look-ahead word
   const long long gm = (1ll << gl) - 1;
   for (long long base = 0; base < n; base += RB) {
     int ci[RB], size[RB], off[RB];
@@ -196,14 +201,14 @@ RANS_HD const unsigned* r_decode(const unsigned* ptr, const int* idx, int ch0, l
         start = (unsigned)c[lo]; freq = (unsigned)(c[lo + 1] - c[lo]);
       }
       x = (unsigned long long)freq * (x >> R_PREC) + cum - start;
-      if (x < R_L) { x = (x << 32) | nw; nw = *++ptr; }
+      if (x < R_L) { x = (x << 32) | nw; nw = r_next(ptr, last); }
       int value = lo;
       if (value == max_value) {
-        unsigned val = r_get_bits(x, ptr, nw);
+        unsigned val = r_get_bits(x, ptr, nw, last);
         int nb = (int)val;
-        while (val == R_MAXB) { val = r_get_bits(x, ptr, nw); nb += (int)val; }
-        unsigned raw = 0;
-        for (int j = 0; j < nb; ++j) raw |= r_get_bits(x, ptr, nw) << (j * R_BYP);
+        while (val == R_MAXB && nb < 64) { val = r_get_bits(x, ptr, nw, last); nb += (int)val; }   // (the encoder writes <= 8 digits:
+        unsigned raw = 0;                                                                         //  more is a corrupt stream, bounded)
+        for (int j = 0; j < nb; ++j) { const unsigned b = r_get_bits(x, ptr, nw, last); if (j < 8) raw |= b << (j * R_BYP); }
         value = (int)(raw >> 1);
         value = (raw & 1) ? -value - 1 : value + max_value;
       }
@@ -330,10 +335,12 @@ extern "C" int pcc_rans_decode_host(const uint8_t* h_data, int64_t nbytes, const
                                     const int32_t* h_offsets, int32_t* h_sym) {
   PCC_REQUIRE(h_data && h_cdf && h_sizes && h_offsets && (n == 0 || (h_sym && h_idx)), "pcc_rans_decode_host: NULL");
   PCC_REQUIRE(nbytes >= 8 && nbytes % 4 == 0, "pcc_rans_decode_host: truncated stream");
-  std::vector<unsigned> buf((size_t)nbytes / 4 + 4, 0u);     // zero padding: a corrupt stream cannot read out of bounds far
+  const size_t words = (size_t)nbytes / 4;
+  std::vector<unsigned> buf(words + 1, 0u);                  // + the look-ahead word of a stream consumed to its end
   memcpy(buf.data(), h_data, (size_t)nbytes);
   RansTab t{h_cdf, cdf_stride, h_sizes, h_offsets};
-  r_decode(buf.data(), h_idx, 0, n, 0, 1, t, RansDecTab{nullptr, nullptr, nullptr}, h_sym);
+  const unsigned* p = r_decode(buf.data(), buf.data() + words, h_idx, 0, n, 0, 1, t, RansDecTab{nullptr, nullptr, nullptr}, h_sym);
+  PCC_REQUIRE(p <= buf.data() + words, "pcc_rans_decode_host: corrupt stream (it ends before its symbols do)");
   return PCC_OK;
 }
 
@@ -621,8 +628,8 @@ __global__ void __launch_bounds__(64) k_rans_decode_global(const unsigned* __res
   long long rows = (long long)g.n - (long long)seg * g.R;
   rows = rows < 0 ? 0 : (rows > g.R ? g.R : rows);
   const long long e0 = (long long)seg * g.R * g.channels + ((long long)grp << g.gl);
-  const unsigned* p = r_decode(data + off, idx ? idx + e0 : nullptr, grp << g.gl, rows << g.gl, g.gl, g.channels, t,
-                               RansDecTab{nullptr, nullptr, nullptr}, out + e0);
+  const unsigned* p = r_decode(data + off, data + nwords_total - 1, idx ? idx + e0 : nullptr, grp << g.gl, rows << g.gl, g.gl,
+                               g.channels, t, RansDecTab{nullptr, nullptr, nullptr}, out + e0);
   if (p - (data + off) > len) *status = 3;
 }
 

@@ -380,6 +380,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    from unified_point_cloud_compression_amd import frames as _frames
+    cores = _frames.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else []
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -487,6 +489,10 @@ def main():
     dt_max = float(tt.item())
     recs = frames.gather_records([(rank, n_points, t_enc / args.steps, (dt - t_enc) / args.steps, 0.0, rec.shape[0])],
                                  device)
+    # per-rank diagnostics for the first real multi-GPU run: where each rank's step went, on which cores it ran
+    steps_ms = [(b - a) * 1e3 for a, b in zip(step_marks[:-1], step_marks[1:])]
+    diag = frames.gather_records([(rank, t_enc / args.steps * 1e3, (dt - t_enc) / args.steps * 1e3, dt / args.steps * 1e3, min(steps_ms),
+                                   max(steps_ms), len(cores), cores[0] if cores else -1)], device, n_fields=8)
     total_points = sum(r[1] for r in recs)
 
     def count_bits(strings):   # `utils.count_bits` (utils.py:30-48)
@@ -583,6 +589,9 @@ def main():
                        "rate_distortion": rd, "ms_per_step_without_entropy_coder": hot_ms,
                        "frames_per_step": world, "encode_ms": recs[0][2] * 1e3, "decode_ms": recs[0][3] * 1e3,
                        "step_ms_rank0": [round((b - a) * 1e3, 2) for a, b in zip(step_marks[:-1], step_marks[1:])],
+                       "per_rank": [{"rank": int(d[0]), "encode_ms": round(d[1], 3), "decode_ms": round(d[2], 3), "ms_per_step": round(d[3], 3),
+                                     "step_ms_min": round(d[4], 3), "step_ms_max": round(d[5], 3), "host_cores": int(d[6]),
+                                     "first_core": int(d[7])} for d in diag],
                        "device": arch, "cus": cu},
             "roofline": roof,
         }

@@ -123,3 +123,97 @@ def test_block_items_sharded_over_3_ranks_gloo():
     whole = [sum(v) for _, v in sorted(FRAME_BLOCKS.items())]
     fl = [sum(whole[i] for i in r) for r in frames.assign(whole, world)]
     assert max(fl) / (sum(fl) / world) > 1.15
+
+
+# ---- BASELINE configs[4] at its real size: 8 vox10 + 8 vox11 frames over 8 ranks (gloo) ------------------------------------------
+def _config4_worker(rank, world, port, q):
+    """Rank r partitions frames r (vox10, block_size 1024) and 8 + r (vox11, block_size 512: `evaluate.py:39-46`) with the
+    oracle's `partition_blocks` on the CPU -- the real work list of configs[4] -- then the list is all-gathered, the items are
+    assigned and 'coded' by a stand-in that returns the records a GPU rank would."""
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cores = frames.pin_rank(rank, world, max_threads=1)
+    from oracle import codec
+    from unified_point_cloud_compression_amd import synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    local = {}
+    for f, bits, bs in ((rank, 10, 1024), (8 + rank, 11, 512)):
+        _, counts = codec.partition_blocks(synth.surface_cloud(seed=f, bits=bits), bs)
+        local[f] = [int(c) for c in counts]
+    sizes = frames.gather_block_sizes(local, dev, rank, world)
+    done = []
+
+    def process(f, b):
+        n = sizes[f][b]
+        done.append((f, b))
+        if os.environ.get("PCC_TEST_FAIL_ITEM") == f"{f},{b}":
+            raise ValueError("stand-in failure")
+        return (f, b, n, 5e-9 * n, 1.4e-8 * n, 8.0 * n, n, 0.25 * n, n, 0.5 * n, n)
+
+    try:
+        recs, totals = frames.run_sharded_blocks(sizes, process, dev, rank, world)
+        q.put((rank, sizes, done, totals, cores, None))
+    except RuntimeError as e:
+        q.put((rank, sizes, done, None, cores, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_config4(env=None):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        procs = [ctx.Process(target=_config4_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in range(world):
+            r = q.get(timeout=600)
+            res[r[0]] = r[1:]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return world, res
+
+
+def test_config4_work_list_over_8_ranks_gloo():
+    """the real (frame, block) list of BASELINE configs[4] -- 8 vox10 frames as one block each, 8 vox11
+    frames as ~13 blocks each -- through gather_block_sizes -> run_sharded_blocks -> frame_totals on 8 gloo ranks: every item
+    coded exactly once, identical totals everywhere, point load max / mean <= 1.10; each rank pinned to its own cores."""
+    world, res = _run_config4()
+    sizes = res[0][0]
+    assert sorted(sizes) == list(range(16))
+    assert all(len(sizes[f]) == 1 for f in range(8)) and all(len(sizes[f]) >= 8 for f in range(8, 16))
+    for r in range(world):
+        assert res[r][0] == sizes and res[r][2] == res[0][2] and res[r][4] is None
+    done = sorted(x for r in range(world) for x in res[r][1])
+    assert done == [(f, b) for f, s in sorted(sizes.items()) for b in range(len(s))]
+    loads = [sum(sizes[f][b] for f, b in res[r][1]) for r in range(world)]
+    balance = max(loads) / (sum(loads) / world)
+    print(f"configs[4] work list: {len(done)} items, {sum(loads)} points, per-rank loads {loads}, max/mean {balance:.3f}")
+    assert balance <= 1.10
+    totals = res[0][2]
+    for f, s in sizes.items():
+        assert totals[f]["n_points"] == sum(s) == totals[f]["n_decoded"] and totals[f]["blocks"] == len(s)
+    if hasattr(os, "sched_getaffinity") and len(os.sched_getaffinity(0)) >= world:
+        cores = [set(res[r][3]) for r in range(world)]
+        assert all(cores[r] for r in range(world))
+        assert all(not (cores[a] & cores[b]) for a in range(world) for b in range(a + 1, world))      # disjoint shares
+
+
+def test_a_failing_item_fails_every_rank_after_the_collective():
+    """a rank whose item raises must still reach the all_gather (the others would hang in it) -- and then every
+    rank reports the failure."""
+    world, res = _run_config4({"PCC_TEST_FAIL_ITEM": "9,2"})
+    assert all(res[r][2] is None and "(9, 2)" in res[r][4] for r in range(world))

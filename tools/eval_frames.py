@@ -23,6 +23,7 @@ ap.add_argument("--block-size", type=int, default=None, help="default: 1024 for 
 args = ap.parse_args()
 rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
 if world > 1:
+    frames.pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))    # own cores, before the first GPU call
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 torch.cuda.set_device(local)
@@ -30,7 +31,6 @@ dev = torch.device("cuda", local)
 model = bench.build_model(dev)
 q = torch.tensor([[0.5, 0.5]], device=dev)
 clouds = {}
-torch.set_num_threads(max(1, (os.cpu_count() or 1) // max(world, 1)))        # the host cores are shared by the ranks of the node
 
 
 def cloud(i):

@@ -11,6 +11,25 @@ import torch.distributed as dist
 RECORD_FIELDS = ("frame", "n_points", "t_encode", "t_decode", "bits", "n_decoded")
 
 
+def pin_rank(local_rank, local_world, max_threads=4):
+    """Give this rank its own share of the host cores BEFORE its first GPU call.  The codec step is host-sensitive (~90 library
+    calls of ~17 us of Python each): eight ranks migrating over the same cores, or eight OpenMP pools of
+    `nproc` threads each, stretch every launch gap.  The cores this process may run on are cut into `local_world` contiguous
+    shares; torch's intra-op pool is capped at min(share, max_threads).  Returns the list of cores (empty when the platform has
+    no affinity call or the share would be empty: then nothing is changed)."""
+    import os
+    if not hasattr(os, "sched_getaffinity") or local_world < 1:
+        return []
+    cpus = sorted(os.sched_getaffinity(0))
+    share = len(cpus) // local_world
+    if share < 1:
+        return []
+    mine = cpus[local_rank * share:(local_rank + 1) * share]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(share, max_threads)))
+    return mine
+
+
 def assign(sizes, world_size):
     """Static longest-first greedy assignment of work items to ranks.  Returns a list (per rank) of item indices.
     Deterministic on every rank, so no scatter of the work list is needed."""
@@ -78,8 +97,17 @@ def run_sharded_blocks(frame_block_sizes, process, device, rank=0, world_size=1,
     records.  Returns (block records, per-frame totals of `frame_totals`)."""
     items = block_items(frame_block_sizes)
     mine = assign([n for _, _, n in items], world_size)[rank]
-    recs = [tuple(float(v) for v in process(items[i][0], items[i][1])) for i in mine]
+    recs, failure = [], None
+    for i in mine:
+        try:
+            recs.append(tuple(float(v) for v in process(items[i][0], items[i][1])))
+        except Exception as e:          # a rank that dies before the collective leaves the others hanging in it: keep going to the
+            failure = failure or e      # all_gather, mark the item (n_points = -1), and fail on EVERY rank afterwards
+            recs.append((float(items[i][0]), float(items[i][1]), -1.0) + (0.0,) * (len(BLOCK_FIELDS) - 3))
     allr = gather_records(recs, device, group, n_fields=len(BLOCK_FIELDS))
+    bad = [(int(r[0]), int(r[1])) for r in allr if r[2] < 0]
+    if bad:
+        raise RuntimeError(f"(frame, block) items {bad} failed on their rank") from failure
     return allr, frame_totals(allr)
 
 

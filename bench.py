@@ -104,6 +104,18 @@ def pmc_traffic(kernel="k_gemm_h2"):
                                             f"{k['read'] / 1e9:.3f} GB read + {k['write'] / 1e9:.3f} GB written per launch of {kernel}")
 
 
+def pmc_total(kernel):
+    """(HBM bytes of ALL launches of `kernel` in the PMC run, launches) or (None, 0) -- for sums over the kernels of a unit."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, PMC_FILE)))
+    except Exception:
+        return None, 0
+    k = (rec.get("by_kernel") or {}).get(kernel)
+    if rec.get("csrc_sha") != csrc_sha() or k is None:
+        return None, 0
+    return float(k["read"] + k["write"]) * k["launches"], int(k["launches"])
+
+
 def mfma_shape(cin, cout):
     return cout > 4 and (cin in (4, 8, 16) or (cin >= 32 and cin % 32 == 0))
 
@@ -156,6 +168,7 @@ def account_flops(model, pc, q):
         seq = (C.c_int32 * 4096)()
         nseq = L.load().pcc_prof_sequence(seq, 4096)
         forms = [L.FORM_NAMES[seq[i]] for i in range(min(nseq, 4096))]
+        forms = [f for f in forms if f != "k_convt_gather_csr"]        # (timed, but not an MFMA launch: accounted with its unit below)
     finally:
         L.call("pcc_prof_enable", 0)
         S.COUNT_PAIRS = False
@@ -176,11 +189,15 @@ def account_flops(model, pc, q):
         fl = 2.0 * p * cin * cout
         flops += fl
         exec_flops += fl * FORM_TERMS[form]
-        f = by_form.setdefault(form, {"flops": 0.0, "launches": 0})
+        # compulsory traffic of the layer (SURVEY 8d): every feature row, weight, map entry, coordinate touched once
+        by8d = 4.0 * (n_in * cin + n_out * cout + K * cin * cout) + 8.0 * p + 16.0 * (n_in + n_out)
+        f = by_form.setdefault(form, {"flops": 0.0, "launches": 0, "bytes_8d": 0.0, "layers": []})
         f["flops"] += fl
         f["launches"] += 1
-        # compulsory traffic of the layer (SURVEY 8d): every feature row, weight, map entry, coordinate touched once
-        alg_bytes += 4.0 * (n_in * cin + n_out * cout + K * cin * cout) + 8.0 * p + 16.0 * (n_in + n_out)
+        f["bytes_8d"] += by8d
+        f["layers"].append({"n_in": int(n_in), "n_out": int(n_out), "K": K, "cin": int(cin), "cout": int(cout), "pairs": int(p),
+                            "alg_gflop": fl / 1e9, "alg_gbytes_8d": by8d / 1e9})
+        alg_bytes += by8d
         pairs_total += p
         launches += 1
     return flops, launches, pairs_total, alg_bytes, exec_flops, by_form
@@ -514,24 +531,31 @@ def main():
     if rank == 0:
         split_on = lib.ARITH_DEFAULT != lib.ARITH_F32
         ms_step = dt_max / args.steps * 1e3
-        # ---- roofline: per kernel form, from the event-timed pass; the DOMINANT kernel is the form with the most time ----
+        # ---- roofline (SURVEY 8d accounting) ----------------------------------------------------------------
+        # Every event-timed kernel form is priced with the ALGORITHMIC work of the layers it ran: FLOP = 2 P Cin Cout and
+        # BYTES = 4 (N_in Cin + N_out Cout + K Cin Cout) + 8 P + 16 (N_in + N_out) -- the layer's compulsory traffic; buffers
+        # the design adds (the per-pair products T) count as `traffic`, never as useful bytes.  The DOMINANT kernel is the form
+        # with the most time per step; `unit` prices the SURVEY 8d unit it belongs to (a composite level = dense products +
+        # ordered gather-sum) the same way.
         kernels = {}
         for nme, f in forms.items():
-            if f["launches_per_step"] <= 0:
+            if f["launches_per_step"] <= 0 or nme == "k_convt_gather_csr":
                 continue
-            fl = flops_by_form.get(nme, {}).get("flops", 0.0)                 # algorithmic FLOPs per step (pair counts read back)
+            bf = flops_by_form.get(nme, {})
+            fl, by8 = bf.get("flops", 0.0), bf.get("bytes_8d", 0.0)           # per step (one accounting step)
+            sec = f["ms_per_step"] * 1e-3
+            roof_t = PEAK_BF16_MFMA_TFLOPS / FORM_TERMS[nme]
             k = {"ms_per_step": f["ms_per_step"], "launches_per_step": f["launches_per_step"],
-                 "alg_tflops": fl / (f["ms_per_step"] * 1e-3) / 1e12 if f["ms_per_step"] > 0 else None,
-                 "mfma_roof_tflops": PEAK_BF16_MFMA_TFLOPS / FORM_TERMS[nme]}
-            k["mfma_frac"] = k["alg_tflops"] / k["mfma_roof_tflops"] if k["alg_tflops"] else None
-            if f["bytes"] > 0:                                                  # dense products: the library knows their operand / result bytes
-                k["alg_gbs"] = f["bytes"] / (f["ms_per_step"] * 1e-3) / 1e9
-                k["hbm_frac"] = k["alg_gbs"] / PEAK_HBM_GBS
-                k["flop_per_byte"] = f["flops"] / f["bytes"]
-                ridge = k["mfma_roof_tflops"] * 1e12 / (PEAK_HBM_GBS * 1e9)
-                k["bound"] = "hbm" if k["flop_per_byte"] < ridge else "mfma"
-            else:
-                k["bound"] = "mfma"                                             # gathered forms: priced against the matrix roof only
+                 "alg_tflops": fl / sec / 1e12 if sec > 0 else None, "mfma_roof_tflops": roof_t,
+                 "alg_gbs_8d": by8 / sec / 1e9 if sec > 0 else None}
+            k["mfma_frac"] = k["alg_tflops"] / roof_t if k["alg_tflops"] else None
+            k["hbm_frac"] = k["alg_gbs_8d"] / PEAK_HBM_GBS if k["alg_gbs_8d"] else None
+            k["flop_per_byte"] = fl / by8 if by8 else None
+            ridge = roof_t * 1e12 / (PEAK_HBM_GBS * 1e9)
+            k["bound"] = "hbm" if (k["flop_per_byte"] is not None and k["flop_per_byte"] < ridge) else "mfma"
+            if f["bytes"] > 0:      # dense products: operand + RESULT stream of the kernel itself (counts the product buffer T)
+                k["kernel_stream_gbs"] = f["bytes"] / sec / 1e9
+                k["kernel_stream_frac"] = k["kernel_stream_gbs"] / PEAK_HBM_GBS
             kernels[nme] = k
         dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"]) if kernels else None
         d, df = (kernels[dom], forms[dom]) if dom else ({}, {})
@@ -539,23 +563,47 @@ def main():
         conv_ms = sum(k["ms_per_step"] for k in kernels.values())
         fam_ach = flops_step / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
         fam_peak = PEAK_BF16_MFMA_TFLOPS * flops_step / exec_flops_step if exec_flops_step else PEAK_FP32_MFMA_TFLOPS
+        lps = max(df.get("launches_per_step", 0), 1e-9)
+        bf = flops_by_form.get(dom, {}) if dom else {}
+        alg_b = bf.get("bytes_8d", 0.0) / lps if bf else None
+        alg_f = bf.get("flops", 0.0) / lps if bf else None
         if d.get("bound") == "hbm":
-            roof = {"bound": "hbm", "achieved": d["alg_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["hbm_frac"]}
+            roof = {"bound": "hbm", "achieved": d.get("alg_gbs_8d"), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d.get("hbm_frac")}
         else:
             roof = {"bound": "mfma", "achieved": d.get("alg_tflops"), "peak": d.get("mfma_roof_tflops"), "unit": "TFLOP/s",
                     "frac": d.get("mfma_frac")}
-        lps = max(df.get("launches_per_step", 0), 1e-9)
+        # the SURVEY 8d unit of the composite levels: dense products (k_gemm_h2) + ordered gather-sum (k_convt_gather_csr)
+        unit = None
+        gat = forms.get("k_convt_gather_csr")
+        if dom == "k_gemm_h2" and gat and gat["launches_per_step"] > 0:
+            u_ms = df["ms_per_step"] + gat["ms_per_step"]
+            # (the PMC run also holds the small gather-sums of the hyper-synthesis under the same kernel name: their traffic is
+            #  negligible, so ALL gather-sum bytes of the run are divided by the run's composite levels = its k_gemm_h2 launches)
+            g_bytes, _ = pmc_total("k_convt_gather_csr")
+            m_bytes, m_launches = pmc_total("k_gemm_h2")
+            u_note = "k_gemm_h2 + k_convt_gather_csr entries of " + PMC_FILE
+            ut = ((m_bytes + g_bytes) / m_launches) if (g_bytes and m_bytes and m_launches) else None
+            unit = {"name": "composite level = k_gemm_h2 + k_convt_gather_csr (pcc_convt_fwd_csr_grid)",
+                    "units_per_step": lps, "ms_per_unit": u_ms / lps, "alg_flops_per_unit": alg_f, "alg_bytes_per_unit": alg_b,
+                    "alg_tflops": bf["flops"] / (u_ms * 1e-3) / 1e12, "mfma_frac": bf["flops"] / (u_ms * 1e-3) / 1e12 / d["mfma_roof_tflops"],
+                    "alg_gbs": bf["bytes_8d"] / (u_ms * 1e-3) / 1e9, "hbm_frac": bf["bytes_8d"] / (u_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "traffic": ut, "traffic_over_alg_bytes": (ut / alg_b) if (ut and alg_b) else None,
+                    "traffic_source": u_note, "layers": bf.get("layers")}
         roof.update({
             "kernel": dom, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
-            "alg_bytes_per_launch": df.get("bytes", 0.0) / lps if df.get("bytes") else None,
-            "alg_flops_per_launch": (flops_by_form.get(dom, {}).get("flops", 0.0) / lps) if dom else None,
+            "alg_bytes_per_launch": alg_b, "alg_flops_per_launch": alg_f,
+            "traffic_over_alg_bytes": (traffic / alg_b) if (traffic and alg_b) else None,
             "avg_launch_ms": df.get("ms_per_step", 0.0) / lps, "launches_per_step": df.get("launches_per_step"),
             "mfma_frac": d.get("mfma_frac"), "hbm_frac": d.get("hbm_frac"), "flop_per_byte": d.get("flop_per_byte"),
-            "note": ("dominant kernel = the event-timed form with the most time per step. algorithmic bytes of a dense product = "
-                     "4 B x (rows x depth + rows x columns + depth x columns), algorithmic FLOPs = 2 x rows x depth x columns "
-                     "(DESIGN.md section 4); durations from HIP events on the launch stream, recorded inside the library in a "
-                     "separate pass (never inside the loop `value` is timed on); mfma roof = dense 16-bit MFMA peak 2500 TFLOP/s / "
-                     "MFMA terms per product of the form"),
+            "kernel_stream_frac": d.get("kernel_stream_frac"), "kernel_stream_gbs": d.get("kernel_stream_gbs"),
+            "unit": unit,
+            "note": ("dominant kernel = the event-timed form with the most time per step, priced by SURVEY 8d: algorithmic FLOPs = "
+                     "2 x pairs x Cin x Cout of the layers it ran, algorithmic bytes = 4 (N_in Cin + N_out Cout + K Cin Cout) + 8 pairs + "
+                     "16 (N_in + N_out) -- the per-pair product buffer T is NOT counted (it shows up in `traffic`); `kernel_stream_frac` "
+                     "is the kernel's own operand + result stream (T included) against the HBM peak, the figure rounds 2-3 printed as "
+                     "`frac`; `unit` = the composite level the kernel is half of.  Durations: HIP events on the launch stream, recorded "
+                     "inside the library in a separate pass (never inside the loop `value` is timed on); mfma roof = dense 16-bit MFMA "
+                     "peak 2500 TFLOP/s / MFMA terms per product of the form"),
             "kernels": kernels,
             # all event-timed MFMA launches together (round-2 style figure, kept for comparison across rounds)
             "mfma_family": {"achieved": fam_ach, "peak": fam_peak, "unit": "TFLOP/s", "frac": (fam_ach / fam_peak) if fam_ach else None,

@@ -540,7 +540,9 @@ int pcc_prof_collect(double* h_conv_ms, int64_t* h_conv_launches);
 #define PCC_FORM_CONV_BF 5    /* k_conv_mfma_bf: gathered output-stationary convolution, 6 terms */
 #define PCC_FORM_CONV_F32 6   /* k_conv_mfma: fp32-input MFMA */
 #define PCC_FORM_WAVE16 7     /* k_conv_wave16 / wave16z: narrow outputs, fp32-input 16x16x4 MFMA */
-#define PCC_FORM_COUNT 8
+#define PCC_FORM_GATHER_CSR 8 /* k_convt_gather_csr of a composite level (pcc_convt_fwd_csr_grid): not an MFMA launch; timed because
+                                 dense products + gather-sum are ONE unit of SURVEY 8d's accounting */
+#define PCC_FORM_COUNT 9
 int pcc_prof_collect_forms(double* h_ms, int64_t* h_launches, double* h_flops, double* h_bytes);
 /* forms of the timed launches recorded so far, in launch order (up to cap entries); returns their number; no reset */
 int64_t pcc_prof_sequence(int32_t* h_forms, int64_t cap);

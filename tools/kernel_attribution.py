@@ -20,7 +20,8 @@ calls = json.load(open(sys.argv[2]))
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
 # convolution launches of the family: MODE_CONV instantiations only (the GDN / IGDN modes of the same kernel are not calls of
 # the list), and only the calls that take the MFMA path (thin heads with <= 4 output channels run VALU kernels)
-fam = [r for r in rows if re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>|k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0>|k_conv_wave16|k_gemm_bf<\d+, \d+, \d+, \d+, 0>|k_gemm_bf2<\d+>|k_gemm_h2<\d+>|k_pair_h2<\d+>",
+fam = [r for r in rows if re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>|k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0, \d+>|k_conv_in4_bf<|"
+                                 r"k_conv_wave16|k_gemm_bf<\d+, \d+, \d+, \d+, 0>|k_gemm_bf2<\d+>|k_gemm_h2<\d+(, \d+)?>|k_pair_h2<\d+>",
                                  r["Kernel_Name"])]
 calls = [c for c in calls if c["cout"] > 4 and (c["cin"] in (4, 8, 16) or c["cin"] % 32 == 0)]
 assert len(fam) >= len(calls), (len(fam), len(calls))
@@ -38,6 +39,7 @@ for i, (c, r) in enumerate(zip(calls, fam)):
     name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
     peak = 833.3 if "_h2" in name else (416.7 if "_bf" in name else 157.3)
     tf = c["gflop"] / ms
+    assert tf / peak < 1.0, f"call {i} joined to the wrong launch ({name}: {tf:.0f} TFLOP/s): the family regex does not match the build's kernels"
     print(f"{i:2d} {c['K']:4d} {c['cin']:4d} {c['cout']:4d} {c['n_out']:9d} {c['pairs']:10d} {c['gflop']:8.1f} {ms:9.3f} {tf:8.1f} {tf / peak:7.2f}  {name}")
     tot_f += c["gflop"]
     tot_t += ms

@@ -3861,10 +3861,19 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
   const int64_t waves = pcc_cdiv(n_out, 64 >> l);
   const unsigned gg = (unsigned)pcc_cdiv(waves, 4);
   // pair slots per batch of independent loads: narrow outputs (the last level, ~4 pairs per row) take 4, the others 8
+  // (measurement: the gather-sum of a composite level is event-timed too -- with the dense products it is the SURVEY 8d unit)
+  const bool timed_gather = g_prof_on && ex_grid;
+  hipEvent_t g0, g1;
+  if (timed_gather) PCC_TRY(prof_event(&g0, s));
   if (vec == 4 && l <= 2) k_convt_gather_csr<4, 4><<<gg, 256, 0, s>>>(g);
   else if (vec == 4) k_convt_gather_csr<4, 8><<<gg, 256, 0, s>>>(g);
   else k_convt_gather_csr<1, 8><<<gg, 256, 0, s>>>(g);
   PCC_LAUNCH_CHECK();
+  if (timed_gather) {
+    PCC_TRY(prof_event(&g1, s));
+    prof_note(PCC_FORM_GATHER_CSR, 0.0, 0.0);
+    prof_push();
+  }
   return PCC_OK;
 }
 

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcc_hip.so")
 
 MAP_HDR_INTS = 512
-FORM_NAMES = ("other", "k_gemm_h2", "k_gemm_bf2", "k_pair_h2", "pair_bf", "k_conv_mfma_bf", "k_conv_mfma", "k_conv_wave16")
+FORM_NAMES = ("other", "k_gemm_h2", "k_gemm_bf2", "k_pair_h2", "pair_bf", "k_conv_mfma_bf", "k_conv_mfma", "k_conv_wave16",
+              "k_convt_gather_csr")
 MAP_MAX_SEG = 8
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 

@@ -21,11 +21,10 @@ struct SegPlan {           // host-built, passed by value to k_write_hdr
 };
 
 // class_begin: nullptr -> single segment covering [0, n_out)
-__global__ void k_write_hdr(SegPlan plan, const int* __restrict__ class_begin, int class_stride,
-                            int64_t n_out, int* __restrict__ hdr) {
-  // launched <<<1, 192>>>: thread i writes the i-th offset / order entry, thread 0 the segment table (one thread walking
-  // all of it took 10-14 us per map, ten maps per step)
-  if (blockIdx.x != 0) return;
+// threads 0..191 of ONE workgroup: thread i writes the i-th offset / order entry, thread 0 the segment table (one thread walking
+// all of it took 10-14 us per map, ten maps per step)
+__device__ __forceinline__ void write_hdr(const SegPlan& plan, const int* __restrict__ class_begin, int class_stride,
+                                          int64_t n_out, int* __restrict__ hdr) {
   {
     const int i = (int)threadIdx.x;
     if (i < plan.K && i < 192) {
@@ -54,6 +53,12 @@ __global__ void k_write_hdr(SegPlan plan, const int* __restrict__ class_begin, i
     seg[SEG_NBR_HI] = (int)(nbr_begin >> 32);
     nbr_begin += (int64_t)pc * plan.k_count[s];
   }
+}
+
+__global__ void k_write_hdr(SegPlan plan, const int* __restrict__ class_begin, int class_stride,
+                            int64_t n_out, int* __restrict__ hdr) {
+  if (blockIdx.x != 0) return;                              // launched <<<1, 192>>>
+  write_hdr(plan, class_begin, class_stride, n_out, hdr);
 }
 
 // Visiting order of a segment's offsets.  Tried on MI355X (round 1): "(dx,dy) major, dz minor" -- back-to-back
@@ -126,7 +131,9 @@ __global__ void __launch_bounds__(256) k_map_conv(PccGrid grid, const int64_t* _
 template <int KS>
 __global__ void __launch_bounds__(256) k_map_conv_z(PccGrid g, const int64_t* __restrict__ out_keys, int64_t n_out,
                                                     int step, const int* __restrict__ rows, int* __restrict__ nbr,
-                                                    int* __restrict__ d_pairs) {
+                                                    int* __restrict__ d_pairs, SegPlan plan, int* __restrict__ hdr) {
+  // (the map's header rides along: nothing in this kernel reads it, and a launch of its own cost ~5 us, nine times per step)
+  if (hdr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 192) write_hdr(plan, nullptr, 0, n_out, hdr);
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int kxy = blockIdx.y;                                      // kx + KS * ky
   constexpr int H = (KS & 1) ? (KS - 1) / 2 : 0;
@@ -320,8 +327,11 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
     plan.k_count[0] = K;
     plan.koff_begin[0] = 0;
     plan_order(plan, kernel_size);
-    k_write_hdr<<<1, 192, 0, s>>>(plan, nullptr, 0, n_out, hdr);
-    PCC_LAUNCH_CHECK();
+    const bool hdr_in_map = n_out > 0 && grid.bits && (kernel_size == 3 || kernel_size == 5);
+    if (!hdr_in_map) {
+      k_write_hdr<<<1, 192, 0, s>>>(plan, nullptr, 0, n_out, hdr);
+      PCC_LAUNCH_CHECK();
+    }
     if (n_out == 0) return PCC_OK;
     PCC_REQUIRE(in_keys && out_keys && nbr, "pcc_kernel_map_build: NULL array");
     dim3 gdim((unsigned)pcc_cdiv(n_out, 256), (unsigned)K);
@@ -339,8 +349,8 @@ extern "C" int pcc_kernel_map_build(const int64_t* in_keys, int64_t n_in, const 
     }
     if (grid.bits && (kernel_size == 3 || kernel_size == 5)) {
       gdim.y = (unsigned)(kernel_size * kernel_size);
-      if (kernel_size == 3) k_map_conv_z<3><<<gdim, 256, 0, s>>>(grid, out_keys, n_out, step, morton_rows, nbr, block_counts);
-      else k_map_conv_z<5><<<gdim, 256, 0, s>>>(grid, out_keys, n_out, step, morton_rows, nbr, block_counts);
+      if (kernel_size == 3) k_map_conv_z<3><<<gdim, 256, 0, s>>>(grid, out_keys, n_out, step, morton_rows, nbr, block_counts, plan, hdr);
+      else k_map_conv_z<5><<<gdim, 256, 0, s>>>(grid, out_keys, n_out, step, morton_rows, nbr, block_counts, plan, hdr);
     } else {
       k_map_conv<<<gdim, 256, 0, s>>>(grid, in_keys, (int)n_in, out_keys, n_out, kernel_size, step, morton_rows, nbr,
                                       block_counts);
@@ -438,7 +448,9 @@ __global__ void k_grid_popc(const unsigned long long* __restrict__ bits, int64_t
 
 extern "C" int64_t pcc_grid_words(const int32_t* h_grid) {
   const long long cells = (long long)h_grid[7] * h_grid[3] * h_grid[4] * h_grid[5];
-  return (cells + 63) / 64;
+  // an EVEN number of 64-bit words: hipMemsetAsync clears a size that is not a multiple of 16 bytes with two kernels (bulk + an
+  // 8-byte tail, each a launch: tools/probes/memset_probe.hip), and a step clears ~20 bitmaps
+  return ((cells + 63) / 64 + 1) / 2 * 2;
 }
 
 extern "C" size_t pcc_grid_ws_bytes(int64_t words) { return pcc_scan_ws_bytes(words) + 256; }

@@ -352,7 +352,7 @@ class CoordSet:
         dims = [(ob.hi[i] - ob.lo[i]) // ts_out + 1 for i in range(3)]
         cells = (ob.bmax + 1) * dims[0] * dims[1] * dims[2]
         h = (C.c_int32 * 8)(ob.lo[0], ob.lo[1], ob.lo[2], dims[0], dims[1], dims[2], ts_out, ob.bmax + 1)
-        return ob, cells, h, (cells + 63) // 64
+        return ob, cells, h, L.load().pcc_grid_words(h)
 
     def _expand_by_grid(self, ksize, ts_out):
         K = ksize ** 3

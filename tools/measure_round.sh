@@ -1,8 +1,9 @@
 #!/bin/bash
 # The round's measurement batch on the GPU box (run from the repo root): kernel stats, launch attribution, layer report,
-# PMC traffic, the bench line.  Outputs under gpurun_out/meas/; copy what is to be judged into profiles/.
+# PMC traffic, SQ counters, host reads / timeline, the train step, the frame sweep, the bench line.
+# Outputs under gpurun_out/meas/; tools/publish_profiles.sh copies what is to be judged into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/meas; mkdir -p $O
+O=gpurun_out/meas; rm -rf $O; mkdir -p $O
 echo "kernel stats" > $O/progress.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-aux > $O/ks_bench.json 2> $O/ks.err && python profiles/summarize.py $O/ks 18 > $O/kernel_stats.txt 2>&1 && python tools/gpu_idle.py $O/ks k_eb_encode 4 3 > $O/gpu_idle.txt 2>&1
 echo "attribution" >> $O/progress.txt
@@ -12,6 +13,11 @@ timeout -k 10 200 python tools/layer_report.py 10 > $O/layer_report.txt 2>&1
 echo "pmc" >> $O/progress.txt
 timeout -k 10 400 python tools/pmc_traffic.py collect $O/pmc > $O/pmc.log 2>&1 && python tools/pmc_traffic.py parse $O/pmc $O/pmc_traffic.json >> $O/pmc.log 2>&1 && python tools/pmc_by_kernel.py $O/pmc > $O/pmc_by_kernel.txt 2>&1
 cp $O/pmc_traffic.json profiles/pmc_traffic.json   # (so that the bench line below carries the traffic of THIS code: bench.py reads the stamped file)
+echo "sq" >> $O/progress.txt
+timeout -k 10 400 python tools/sq_by_kernel.py collect $O/sq > $O/sq.log 2>&1 && python tools/sq_by_kernel.py report $O/sq > $O/sq_by_kernel.txt 2>&1
+echo "host" >> $O/progress.txt
+timeout -k 10 200 python tools/sync_sites.py > $O/host_reads.txt 2>&1
+timeout -k 10 200 python tools/host_timeline.py $O/host_timeline.txt > $O/host_timeline.log 2>&1
 echo "train step" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 tools/train_profile.py 10 > $O/train_profile.txt 2>&1 && python profiles/summarize.py $O/train 16 > $O/train_kernel_stats.txt 2>&1
 echo "eval frames" >> $O/progress.txt

@@ -21,7 +21,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_sha  # noqa: E402
 
-KERNELS = ("k_conv_mfma", "k_conv_wave16", "k_gemm_bf2", "k_gemm_h2", "k_pair_h2")
+KERNELS = ("k_conv_mfma", "k_conv_wave16", "k_gemm_bf2", "k_gemm_h2", "k_pair_h2", "k_convt_gather_csr")
 BENCH = ["python3", "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-aux", "--coder", "symbols"]
 
 
@@ -50,7 +50,7 @@ def parse(out, dst):
                 e[0] += float(r["Counter_Value"])
                 e[1] += 1
             conv = ("k_conv_wave16" in name or re.search(r"k_conv_mfma<\d+, \d+, \d+, \d+, 0, (true|false)>", name)
-                    or re.search(r"k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0>", name) or re.search(r"k_gemm_(bf2|h2)<\d+>|k_pair_h2<\d+>", name))                                   # MODE_CONV only
+                    or re.search(r"k_conv_mfma_bf<\d+, \d+, \d+, \d+, 0, \d+>", name) or "k_conv_in4_bf<" in name or re.search(r"k_gemm_(bf2|h2)<\d+(, \d+)?>|k_pair_h2<\d+>", name))                                   # MODE_CONV only
             if r["Counter_Name"] == ctr and conv:
                 tot += float(r["Counter_Value"])
                 launches += 1

@@ -66,8 +66,8 @@ class MeanScaleHyperprior(CompressionModel):
             raise L.PccError(f"unknown entropy_coder {self.entropy_coder!r}")
         coder = None if self.entropy_coder == "symbols" else self.entropy_coder
         if self.entropy_bottleneck_vbr:
-            raise L.PccError("entropy_bottleneck_vbr is training-only in the reference (`model/entropy_models.py:275`) "
-                             "and not built")
+            raise L.PccError("entropy_bottleneck_vbr: CompressAI's EntropyBottleneckVbr (reference `model/entropy_models.py:163-173`, "
+                             "used by its training forward only, `:253,275-279`; false in every shipped configuration) is not built")
         self.gaussian_conditional = GaussianConditional(None, entropy_coder=coder)
         self.entropy_bottleneck = EntropyBottleneck(Ch, entropy_coder=coder)
         conv, gen = ME.MinkowskiConvolution, SortedMinkowskiGenerativeConvolutionTranspose

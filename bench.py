@@ -151,7 +151,7 @@ def account_flops(model, pc, q):
     orig_g = S.convt_forward_csr_grid
 
     def spy_g(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope=0.01):
-        calls.append((int(csr[0][out_set.n].item()), -K, cin, cout, out_set.n, feats.shape[0]))
+        calls.append((S.csr_pair_total(csr, out_set.n), -K, cin, cout, out_set.n, feats.shape[0]))
         return orig_g(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope)
 
     names = ("conv_forward", "convt_forward", "convt_forward_csr", "convt_forward_rows", "conv_head_forward",

@@ -191,6 +191,17 @@ int pcc_coords_expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t k
                                int32_t* first, int32_t* pair_ids, int64_t* d_total, void* ws, size_t ws_bytes, void* stream);
 /* the same lists, kernel offsets of the pair ids numbered z fastest (iz + KS*iy + KS*KS*ix) -- for product buffers laid out
  * [input row][kx][ky][kz][c]: the composite levels gather z-runs of output rows from adjacent memory */
+/* The same pair lists in ONE pass (round 4): the 256 rows of a workgroup write into a slot of their own, pair_ids[w * SLOT ...) with
+ * SLOT = 256 x the most pairs a row can have ((k+1)/2)^3, so no prefix sum over all rows (and no second probing pass) is needed.
+ * first[o] (n_out entries) = absolute start of row o's list; the list ends at first[o + 1], except for the last row of a workgroup
+ * (o % 256 == 255, or the last row): wg_end[o / 256].  Same pairs, same order inside a row as pcc_coords_expand_grid_csr[_zk].
+ * kernel_size 5 or 7, input pitch >= 2 x output pitch.  pair_ids: pcc_expand_grid_csr_slot_elems(n_out, kernel_size) ints (sized for
+ * the worst case; only the written part is touched); wg_end: ceil(n_out / 256) ints; d_total (nullable): receives the pair total. */
+int64_t pcc_expand_grid_csr_slot_elems(int64_t n_out, int32_t kernel_size);
+int pcc_coords_expand_grid_csr_slots(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
+                                     const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in, int64_t n_in,
+                                     int32_t* first, int32_t* pair_ids, int32_t* wg_end, int64_t* d_total /*nullable*/, int32_t zk,
+                                     void* stream);
 int pcc_coords_expand_grid_csr_zk(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
                                const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in, int64_t n_in,
                                int32_t* first, int32_t* pair_ids, int64_t* d_total, void* ws, size_t ws_bytes, void* stream);
@@ -309,8 +320,9 @@ int pcc_convt_fwd_csr(const float* feat_in, int64_t n_in, int32_t cin, const flo
 int pcc_convt_fwd_csr_grid(const float* feat_in, int64_t n_in, int32_t cin, const float* packed_w, const float* bias /*nullable*/,
                            int32_t K, int32_t cout, const int32_t* first, const int32_t* pair_ids, int64_t n_out, float* T,
                            float* out, int32_t act, float slope, const int64_t* out_keys, const uint64_t* out_bits,
-                           const int32_t* out_rank, const int32_t* h_out, const float* ex_bias, int32_t arith,
-                           int32_t* d_guard /*nullable*/, void* stream);
+                           const int32_t* out_rank, const int32_t* h_out, const float* ex_bias,
+                           const int32_t* wg_end /*nullable: first / pair_ids are the slotted lists of pcc_coords_expand_grid_csr_slots*/,
+                           int32_t arith, int32_t* d_guard /*nullable*/, void* stream);
 /* Chunked form of pcc_convt_fwd_csr for 7x7x7 composite levels: the per-pair products never exist as a whole.  Parent rows
  * are processed in chunks whose products fit the Infinity Cache (pcc_set_t_chunk_bytes, default 96 MiB; env PCC_T_CHUNK_MIB):
  * GEMM chunk -> staging buffer T (pcc_convt_chunk_t_bytes) -> ordered gather-sum of the children that chunk reaches, partial

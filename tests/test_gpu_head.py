@@ -235,3 +235,53 @@ def test_pair_lists_with_z_fastest_offset_numbering():
     ix, iy, iz = k_a % 7, (k_a // 7) % 7, k_a // 49
     assert np.array_equal(pb // 343, row_a) and np.array_equal(pb % 343, iz + 7 * iy + 49 * ix)
     assert P > out_set.n                                   # several parents per child on average
+
+
+@pytest.mark.parametrize("ks,ts_in,shift,zk,dense", [(7, 2, -3, True, False), (7, 4, 0, False, False), (5, 2, -3, False, False), (7, 2, 0, True, True)])
+def test_one_pass_slotted_pair_lists_equal_the_three_launch_form(ks, ts_in, shift, zk, dense):
+    """Round 4: `pcc_coords_expand_grid_csr_slots` (probe once, positions from a scan INSIDE the workgroup, lists in
+    per-workgroup slots) holds exactly the lists of the count / scan / fill form -- same pairs, same order inside a row -- and the
+    composite gather-sum over them gives the same bits.  Two batch entries, negative coordinates, a row count that is not a
+    multiple of 256, and a DENSE block whose rows carry up to 64 pairs (more than the 16 parked in LDS: the re-probe path, and
+    workgroup totals beyond the LDS stage: the write-through path)."""
+    from unified_point_cloud_compression_amd import sparse as S, lib as L
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    if dense:
+        g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(12), indexing="ij"), -1).reshape(-1, 3) * ts_in
+        keys = np.unique(co.pack_keys(np.concatenate([np.zeros((len(g), 1), np.int64), g], 1)))
+    else:
+        keys = _two_batch_keys(9, ts_in, shift)
+    C = co.unpack_keys(keys)
+    cs = S.CoordSet(t(keys), len(keys), ts_in, S.Bounds(int(C[:, 0].max()), C[:, 1:].min(0), C[:, 1:].max(0)))
+    ts_out = ts_in // 2
+    out_set = cs.expand(5, ts_out, want_csr=False)
+    n_out = out_set.n
+    first, pids = cs.csr_for(out_set.keys, n_out, ks, ts_out, zk=zk)
+    total = L.counter()
+    sl = cs.csr_for(out_set.keys, n_out, ks, ts_out, zk=zk, slots=True, total=total)
+    assert len(sl) == 3
+    f, p = n(first).astype(np.int64), n(pids)
+    sf, sp, we = n(sl[0]).astype(np.int64), n(sl[1]), n(sl[2]).astype(np.int64)
+    assert S.csr_pair_total(sl, n_out) == int(f[n_out]) == int(L.read(total)[0])
+    ends = np.empty(n_out, np.int64)
+    ends[:-1] = sf[1:]
+    last = np.arange(n_out) % 256 == 255
+    last[-1] = True
+    ends[last] = we[np.arange(n_out)[last] // 256]
+    assert np.array_equal(ends - sf, np.diff(f[:n_out + 1]))                  # same list lengths, row by row
+    if dense:
+        assert (ends - sf).max() > 16
+    rows = np.random.default_rng(0).permutation(n_out)[:4000]
+    for o in rows:
+        assert np.array_equal(sp[sf[o]:ends[o]], p[f[o]:f[o + 1]]), o
+    if ks == 7:                                                                # ... and the composite level over them: same bits
+        rng = np.random.default_rng(ks + ts_in)
+        cin, cout = 32, 16
+        x = t(rng.standard_normal((len(keys), cin)).astype(np.float32))
+        gen = ME.MinkowskiGenerativeConvolutionTranspose(cin, cout, kernel_size=7, stride=2, bias=True, dimension=3).to(dev())
+        ex_bias = t(rng.standard_normal((27, cout)).astype(np.float32))
+        with torch.no_grad():
+            w = gen._packed.get(gen.kernel)
+            a = S.convt_forward_csr_grid(x, w, gen.bias, 343, cin, cout, (first, pids), out_set, L.ACT_RELU, ex_bias)
+            b = S.convt_forward_csr_grid(x, w, gen.bias, 343, cin, cout, sl, out_set, L.ACT_RELU, ex_bias)
+        assert torch.equal(a, b) and float(a.abs().max().item()) > 0

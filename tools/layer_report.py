@@ -84,7 +84,7 @@ def spy_g(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope
     e0.record()
     out = orig_g(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope)
     e1.record()
-    calls.append((int(csr[0][out_set.n].item()), -K, cin, cout, feats.shape[0], out_set.n, e0, e1))
+    calls.append((S.csr_pair_total(csr, out_set.n), -K, cin, cout, feats.shape[0], out_set.n, e0, e1))
     return out
 
 

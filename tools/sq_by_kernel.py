@@ -6,10 +6,13 @@ short bench run (`profiles/r04_sq_mfma_busy_by_kernel.txt`).
   python tools/sq_by_kernel.py report  gpurun_out/sq > profiles/r04_sq_mfma_busy_by_kernel.txt
 
 Derived per kernel instantiation (averages per dispatch over the run's launches of the timed steps):
-  clock        = GRBM_GUI_ACTIVE / 8 / duration     (the counter sums the 8 XCDs: MI355X_MICROARCH.md 'DVFS give-back')
-  MFMA busy    = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CYCLES)   share of the busy SIMD-cycles the matrix pipe was occupied
-                 (SQ_BUSY_CYCLES counts per CU-level SQ; the MFMA counter per SIMD)
-  MFMA busy vs peak clock = MFMA busy x clock / 2.4 GHz
+  cycles       = GRBM_GUI_ACTIVE / 8                (the counter sums the 8 XCDs: MI355X_MICROARCH.md 'DVFS give-back')
+  clock        = cycles / duration
+  MFMA busy    = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)   share of the chip's SIMD-cycles with the matrix pipe occupied
+                 (the counter adds, per SIMD, the pipe cycles of every MFMA issued: 32 for a 32x32x16 16-bit MFMA; checked against
+                 SQ_INSTS_MFMA)
+  x clk/2.4    = MFMA busy x clock / 2.4 GHz        the same share of what the pipe could do at the peak clock
+  waves/SIMD   = 4 x SQ_WAVE_CYCLES / (1024 x cycles)               (SQ_WAVE_CYCLES counts in quad-cycle units)
   LDS conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
 import collections
@@ -57,7 +60,7 @@ def report(out):
                 dur[key] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     print("# rocprofv3 --kernel-trace --pmc passes of `" + " ".join(BENCH) + "` (counter collection serialises kernels: durations are a")
     print("# little longer than in an untraced run).  One row per (kernel instantiation, grid size); averages per dispatch.")
-    print(f"{'kernel':44s} {'grid':>10s} {'n':>3s} {'us':>8s} {'clock GHz':>9s} {'MFMA busy':>9s} {'x clk/2.4':>9s} {'MFMA/wave':>9s} {'LDS confl':>9s}")
+    print(f"{'kernel':44s} {'grid':>10s} {'n':>3s} {'us':>8s} {'clock GHz':>9s} {'MFMA busy':>9s} {'x clk/2.4':>9s} {'waves/SIMD':>10s} {'MFMA insts':>10s} {'LDS confl':>9s}")
     rows = sorted(agg.items(), key=lambda kv: -dur[kv[0]])
     for key, c in rows:
         if n[key] == 0:
@@ -65,13 +68,14 @@ def report(out):
         us = dur[key] / n[key]
         if us < 20:
             continue
-        clock = c.get("GRBM_GUI_ACTIVE", 0.0) / n[key] / 8 / (us * 1e-6) / 1e9 if us > 0 else 0.0
-        busy = c.get("SQ_BUSY_CYCLES", 0.0)
-        mfma = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * busy) if busy else 0.0
-        waves = c.get("SQ_WAVE_CYCLES", 0.0)
+        cycles = c.get("GRBM_GUI_ACTIVE", 0.0) / n[key] / 8          # per dispatch
+        clock = cycles / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        # p1 counters are sums over the same number of dispatches (same run shape): per-dispatch averages via n[key]
+        mfma = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / n[key] / (1024.0 * cycles) if cycles else 0.0
+        waves = 4.0 * c.get("SQ_WAVE_CYCLES", 0.0) / n[key] / (1024.0 * cycles) if cycles else 0.0
         lds = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else 0.0
-        print(f"{key[0][:44]:44s} {key[1]:>10s} {n[key]:3d} {us:8.1f} {clock:9.2f} {mfma:9.2f} {mfma * clock / 2.4:9.2f} "
-              f"{c.get('SQ_INSTS_MFMA', 0.0) / max(n[key], 1):9.3g} {lds:9.3f}")
+        print(f"{key[0][:44]:44s} {key[1]:>10s} {n[key]:3d} {us:8.1f} {clock:9.2f} {mfma:9.2f} {mfma * clock / 2.4:9.2f} {waves:10.2f} "
+              f"{c.get('SQ_INSTS_MFMA', 0.0) / max(n[key], 1):10.3g} {lds:9.3f}")
 
 
 if __name__ == "__main__":

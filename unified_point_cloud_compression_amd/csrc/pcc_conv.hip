@@ -3682,6 +3682,7 @@ __device__ __forceinline__ void nt_store(float v, float* p) { __builtin_nontempo
 
 struct GatherCsrArgs {
   const float* T; const float* bias; const int* first; const int* pair_ids;
+  const int* wg_end = nullptr;                            // slotted lists (pcc_coords_expand_grid_csr_slots): end of the last row of every 256 rows
   float* out; long long n_out; int cout, act; float slope; int lpr_log2;
   const int* ex_nbr; const float* ex_bias; int ex_K;      // optional: + sum over the existing neighbours k of ex_bias[k]
   const float* ex_tab;                                    //   as subset-sum tables [4][128][cout] over 7+7+7+6 neighbour bits (k_presence_tables)
@@ -3699,7 +3700,8 @@ __global__ void __launch_bounds__(256) k_convt_gather_csr(GatherCsrArgs a) {
   const int cl = lane & (lpr - 1);
   if (o >= a.n_out) return;
   const int cvec = a.cout / VEC;
-  const int t0 = a.first[o], t1 = a.first[o + 1];
+  const int t0 = a.first[o];
+  const int t1 = (a.wg_end && ((o & 255) == 255 || o + 1 == a.n_out)) ? a.wg_end[o >> 8] : a.first[o + 1];
   // optional constant per existing neighbour (two fused affine layers): the lanes of the row's group fetch the ex_K presence
   // flags side by side and share them by ballot (one load per lane instead of ex_K dependent loads: the serial loop cost
   // 2.1 ms on the level-2 head in round 2)
@@ -3822,7 +3824,7 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
                               const float* bias, int32_t K, int32_t cout, const int32_t* first,
                               const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
                               const int32_t* ex_nbr, int32_t ex_K, const float* ex_bias, const PccGrid* ex_grid,
-                              const long long* ex_keys, int32_t arith, int32_t* d_guard, void* stream) {
+                              const long long* ex_keys, int32_t arith, int32_t* d_guard, void* stream, const int32_t* wg_end = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out <= 0 || n_in <= 0) return PCC_OK;
   PCC_REQUIRE(feat_in && packed_w && first && pair_ids && T && out, "pcc_convt_fwd_csr: NULL array");
@@ -3847,6 +3849,7 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
   GatherCsrArgs g;
   g.T = T; g.bias = bias; g.first = first; g.pair_ids = pair_ids; g.out = out; g.n_out = n_out; g.cout = cout;
   g.act = act; g.slope = slope; g.ex_nbr = ex_nbr; g.ex_bias = ex_bias; g.ex_K = ex_K; g.nt = g_nt;
+  g.wg_end = wg_end;
   g.ex_grid.bits = nullptr; g.out_keys = nullptr;
   if (ex_grid) { g.ex_grid = *ex_grid; g.out_keys = ex_keys; g.ex_nbr = nullptr; }
   g.ex_tab = nullptr;
@@ -3902,11 +3905,12 @@ extern "C" int pcc_convt_fwd_csr_grid(const float* feat_in, int64_t n_in, int32_
                                       const float* bias, int32_t K, int32_t cout, const int32_t* first,
                                       const int32_t* pair_ids, int64_t n_out, float* T, float* out, int32_t act, float slope,
                                       const int64_t* out_keys, const uint64_t* out_bits, const int32_t* out_rank,
-                                      const int32_t* h_out, const float* ex_bias, int32_t arith, int32_t* d_guard, void* stream) {
+                                      const int32_t* h_out, const float* ex_bias, const int32_t* wg_end, int32_t arith,
+                                      int32_t* d_guard, void* stream) {
   PCC_REQUIRE(out_keys && out_bits && out_rank && h_out && ex_bias, "pcc_convt_fwd_csr_grid: NULL array");
   const PccGrid ex = grid_from_host(out_bits, out_rank, h_out);
   return convt_fwd_csr_impl(feat_in, n_in, cin, packed_w, bias, K, cout, first, pair_ids, n_out, T, out, act, slope,
-                            nullptr, 27, ex_bias, &ex, (const long long*)out_keys, arith, d_guard, stream);
+                            nullptr, 27, ex_bias, &ex, (const long long*)out_keys, arith, d_guard, stream, wg_end);
 }
 
 // ---- chunked form of the CSR generative transposed convolution --------------------------------------------------------

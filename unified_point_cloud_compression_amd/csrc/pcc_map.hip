@@ -991,6 +991,48 @@ __global__ void __launch_bounds__(256) k_expand_csr_fill(ExpandCsrArgs a) {
   for (int t = threadIdx.x; t < total; t += 256) a.pair_ids[base + t] = stage[t];
 }
 
+// ---- one-pass pair lists in per-workgroup SLOTS (round 4) -------------------------------------------------------------------
+// The count / scan / fill form probes every row twice (the probes are the cost: dependent bitmap + rank reads) because a row's
+// position in pair_ids is a prefix sum over ALL rows before it.  Here a workgroup's 256 rows write into a slot of their own --
+// pair_ids[w * SLOT ...), SLOT = 256 rows x the most pairs a row can have -- so positions need only a scan INSIDE the workgroup:
+// probe once (hits parked in LDS), block scan of the counts, compact, write.  first[o] = absolute start of row o; a row's list
+// ends where the next row's begins, except for the last row of a workgroup: wg_end[w].  Same lists, same order inside a row as
+// the three-launch form (tests compare them row by row), so the gather-sum's results are bit-identical.  The buffer is sized for
+// the worst case (no overflow path, nothing to re-run); only the written part costs bandwidth.
+template <int KS>
+__global__ void __launch_bounds__(256) k_expand_csr_slot(ExpandCsrArgs a, int slot, int* __restrict__ wg_end) {
+  // (LDS budget = occupancy: the pass is latency-bound.  With a second 20 KB buffer to compact the workgroup's hits before the
+  //  write it held 37 KB, four workgroups per CU, and took 560 us on the benchmark's last level -- as long as count + scan + fill.)
+  constexpr int R = 12;                       // hits per row parked in LDS (rows with more re-probe: rare on surfaces)
+  __shared__ int region[256 * R];
+  __shared__ int wsum[4];
+  const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+  int cnt = 0;
+  int* const mine = region + threadIdx.x;     // hit j of this thread at region[j * 256 + thread]: the lanes of a wave hit 64 different banks
+  if (o < a.n_out) csr_probe<KS>(a, o, [&](int i, int kidx) { if (cnt < R) mine[cnt * 256] = i * a.K + kidx; ++cnt; });
+  // exclusive scan of the counts over the workgroup
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int off = inc - cnt, total = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int sv = wsum[q]; if (q < w) off += sv; total += sv; }
+  const int base = (int)blockIdx.x * slot;
+  if (threadIdx.x == 0) {
+    wg_end[blockIdx.x] = base + total;
+    if (a.d_total) atomicAdd((unsigned long long*)a.d_total, (unsigned long long)total);   // (integer: order-independent)
+  }
+  if (o >= a.n_out) return;
+  a.first[o] = base + off;
+  // adjacent rows write adjacent runs: the wave's stores of one j cover ~64 * 4 consecutive positions, whole lines after a few j
+  int* const dst = a.pair_ids + base + off;
+  if (cnt <= R) { for (int j = 0; j < cnt; ++j) dst[j] = mine[j * 256]; }
+  else { int wpos = 0; csr_probe<KS>(a, o, [&](int i, int kidx) { dst[wpos++] = i * a.K + kidx; }); }
+}
+
 __global__ void k_set_int(int* p, int v) { *p = v; }
 
 // phase 1: output set + its grid index.  h_out: output lattice (pitch ts_out).  out_keys capacity >= min(n*K, cells).
@@ -1077,6 +1119,39 @@ static int expand_grid_csr(const int64_t* out_keys, int64_t n_out, int32_t kerne
   PCC_TRY(pcc_scan_exclusive_i32(first, first, n_out + 1, ws, ws_bytes, s));
   PCC_EXPAND_CSR(k_expand_csr_fill);
 #undef PCC_EXPAND_CSR
+  return PCC_OK;
+}
+
+// one-pass slotted lists (k_expand_csr_slot): kernel sizes 5 and 7 at a pitch ratio >= 2 (the generative convolutions of the codec)
+static int csr_slot_rows(int kernel_size) { const int m = (kernel_size + 1) / 2; return m * m * m; }
+extern "C" int64_t pcc_expand_grid_csr_slot_elems(int64_t n_out, int32_t kernel_size) {
+  if (kernel_size != 5 && kernel_size != 7) return -1;
+  return pcc_cdiv(n_out > 0 ? n_out : 1, 256) * 256 * csr_slot_rows(kernel_size);
+}
+extern "C" int pcc_coords_expand_grid_csr_slots(const int64_t* out_keys, int64_t n_out, int32_t kernel_size, int32_t ts_out,
+                                                const uint64_t* in_bits, const int32_t* in_rank, const int32_t* h_in, int64_t n_in,
+                                                int32_t* first, int32_t* pair_ids, int32_t* wg_end, int64_t* d_total, int32_t zk,
+                                                void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(out_keys && in_bits && in_rank && h_in && first && pair_ids && wg_end && n_out > 0, "pcc_coords_expand_grid_csr_slots: bad arguments");
+  PCC_REQUIRE(kernel_size == 5 || kernel_size == 7, "pcc_coords_expand_grid_csr_slots: kernel_size %d unsupported", kernel_size);
+  const int K = kernel_size * kernel_size * kernel_size;
+  PCC_REQUIRE(n_in * K < (1ll << 31), "pcc_coords_expand_grid_csr_slots: too many pairs");
+  PCC_REQUIRE(pcc_expand_grid_csr_slot_elems(n_out, kernel_size) < (1ll << 31), "pcc_coords_expand_grid_csr_slots: too many rows for 32-bit list positions");
+  PCC_REQUIRE(ts_out >= 1 && h_in[6] >= 2 * ts_out && h_in[6] % ts_out == 0,
+              "pcc_coords_expand_grid_csr_slots: the input pitch %d must be at least twice the output pitch %d", h_in[6], ts_out);
+  ExpandCsrArgs a;
+  a.out_keys = out_keys; a.n_out = n_out; a.ts_out = ts_out; a.K = K; a.first = first; a.pair_ids = pair_ids; a.zk = zk;
+  a.d_total = (long long*)d_total;
+  a.in.bits = (const unsigned long long*)in_bits; a.in.rank = in_rank;
+  for (int i = 0; i < 3; ++i) { a.in.lo[i] = h_in[i]; a.in.dims[i] = h_in[3 + i]; }
+  a.in.ts_log2 = ilog2(h_in[6]); a.in.nbatch = h_in[7];
+  const unsigned g = (unsigned)pcc_cdiv(n_out, 256);
+  const int slot = 256 * csr_slot_rows(kernel_size);
+  if (d_total) PCC_CHECK_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), s));
+  if (kernel_size == 5) k_expand_csr_slot<5><<<g, 256, 0, s>>>(a, slot, wg_end);
+  else k_expand_csr_slot<7><<<g, 256, 0, s>>>(a, slot, wg_end);
+  PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
 

@@ -56,6 +56,8 @@ SIGNATURES = {
     "pcc_expand_grid_csr_ws_bytes": (_sz, [_i64]),
     "pcc_coords_expand_grid_csr": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "pcc_coords_expand_grid_csr_zk": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _sz, _p]),
+    "pcc_expand_grid_csr_slot_elems": (_i64, [_i64, _i32]),
+    "pcc_coords_expand_grid_csr_slots": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _i32, _p]),
     "pcc_map_to_dense": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_set_in4_min_rows": (C.c_int, [_i64]),
     "pcc_set_thin_z_min_rows": (C.c_int, [_i64]),
@@ -82,7 +84,7 @@ SIGNATURES = {
     "pcc_conv_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "pcc_conv_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_convt_scatter_rows": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
-    "pcc_convt_fwd_csr_grid": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p, _p, _p, C.POINTER(_i32), _p, _i32, _p, _p]),
+    "pcc_convt_fwd_csr_grid": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p, _p, _p, C.POINTER(_i32), _p, _p, _i32, _p, _p]),
     "pcc_set_t_chunk_bytes": (C.c_int, [_i64]),
     "pcc_convt_chunk_t_bytes": (_sz, [_i64, _i32, _i32]),
     "pcc_convt_chunk_ws_bytes": (_sz, [_i64, _i32, _i32]),

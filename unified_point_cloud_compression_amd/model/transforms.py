@@ -249,14 +249,16 @@ class SparseSynthesisTransform(nn.Module):
         feats = x._canonical_features()
         out_set = cs_in.expand(5, ts_out, want_csr=False)
         packedM, cb = self._fused_weights(gen, c0)
-        csr7 = cs_in.csr_for(out_set.keys, out_set.n, 7, ts_out, zk=S.T_Z_FASTEST)
         from_grid = (S.STENCIL_FROM_GRID and out_set.grid() is not None and c2.kernel_size == 3 and c2.stride == 1
                      and c2.out_channels <= 4 and c0.out_channels in (4, 8, 16, 32, 64)
                      and 27 * c2.out_channels * c0.out_channels * 4 <= 48 * 1024)
+        chunked = S.T_CHUNKED and cs_in.n * 343 * c0.out_channels * 4 >= S.T_CHUNKED_MIN_BYTES
+        # (the one-pass slotted lists are consumed by the grid form of the gather-sum only)
+        csr7 = cs_in.csr_for(out_set.keys, out_set.n, 7, ts_out, zk=S.T_Z_FASTEST, slots=S.CSR_SLOTS and from_grid and not chunked)
         if from_grid:
             # the candidate set's own bitmap + rank give the 27 neighbours of a row directly: no 3x3x3 kernel map of the
             # (large) candidate set is built, written and re-read for the presence flags and for the 1-channel convolution
-            if S.T_CHUNKED and cs_in.n * 343 * c0.out_channels * 4 >= S.T_CHUNKED_MIN_BYTES:
+            if chunked:
                 h = S.convt_forward_csr_chunked(feats, packedM, c0.bias, 343, gen.in_channels, c0.out_channels, csr7, cs_in,
                                                 out_set, L.ACT_RELU, cb)
             else:

@@ -124,6 +124,7 @@ T_CHUNKED = os.environ.get("PCC_T_CHUNKED", "0") != "0"            # composite l
 #   (measured round 2: bit-identical, 10 GB less memory, but +3.5 ms per step -- 125 chunk pairs of launches, children near
 #   chunk borders visited twice, and the Infinity Cache does not speed the gather up enough to pay for it: off)
 T_CHUNKED_MIN_BYTES = 256 << 20
+CSR_SLOTS = os.environ.get("PCC_CSR_SLOTS", "1") != "0"      # composite levels: 7-wide pair lists in one pass (per-workgroup slots)
 STENCIL_FROM_GRID = os.environ.get("PCC_STENCIL_FROM_GRID", "1") != "0"   # composite levels: 3x3x3 neighbours from the bitmap, no nbr table
 HEAD_FUSED = os.environ.get("PCC_HEAD_FUSED", "1") != "0"      # occupancy heads with <= 16 hidden channels: conv + ReLU + projection in one kernel
 
@@ -327,10 +328,13 @@ class CoordSet:
             return parent
         return Pending([p.counter for _, p in parts], finish)
 
-    def csr_for(self, out_keys, n_out, ksize, ts_out, zk=False, total=None):
+    def csr_for(self, out_keys, n_out, ksize, ts_out, zk=False, total=None, slots=False):
         """CSR pair lists (first[n_out+1], pair_ids) of the transposed conv from this set onto the GIVEN output rows
         (any canonical subset of the lattice at pitch ts_out), built by probing this set's grid index.
-        total: a counter() that receives the number of pairs (to be read together with other sizes, `resolve`)."""
+        total: a counter() that receives the number of pairs (to be read together with other sizes, `resolve`).
+        slots: the one-pass form (`pcc_coords_expand_grid_csr_slots`): returns (first, pair_ids, wg_end) -- row o's list is
+        pair_ids[first[o] : first[o + 1]], or up to wg_end[o // 256] for the last row of every 256; consumed by
+        `convt_forward_csr_grid`."""
         g = self.grid()
         if not g:
             raise L.PccError("csr_for needs the grid index of the input set")
@@ -338,6 +342,16 @@ class CoordSet:
         K = ksize ** 3
         if n_out == 0:
             return torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev)
+        if slots:
+            elems = L.load().pcc_expand_grid_csr_slot_elems(n_out, ksize)
+            if ksize in (5, 7) and self.ts >= 2 * ts_out and 0 < elems < (1 << 31):
+                first = torch.empty(n_out, dtype=torch.int32, device=dev)
+                pair_ids = torch.empty(elems, dtype=torch.int32, device=dev)         # worst-case capacity; only the written part is touched
+                wg_end = torch.empty((n_out + 255) // 256, dtype=torch.int32, device=dev)
+                L.call("pcc_coords_expand_grid_csr_slots", L.ptr(out_keys), n_out, ksize, ts_out, L.ptr(g[0]), L.ptr(g[1]), g[2], self.n,
+                       L.ptr(first), L.ptr(pair_ids), L.ptr(wg_end), L.cptr(total) if total is not None else None, 1 if zk else 0,
+                       L.stream())
+                return first, pair_ids, wg_end
         first = torch.empty(n_out + 1, dtype=torch.int32, device=dev)
         pair_ids = torch.empty(max(self.n * K, 1), dtype=torch.int32, device=dev)
         ws = L.workspace(L.load().pcc_expand_grid_csr_ws_bytes(n_out), dev)
@@ -771,6 +785,16 @@ def convt_forward_csr(feats, packed_w, bias, K, cin, cout, csr, n_out, act=L.ACT
     return out
 
 
+def csr_pair_total(csr, n_out):
+    """Number of pairs of CSR lists (host read; accounting / tests only): first[n_out] of the prefix form, the slots' fill of the
+    slotted form (`csr_for(slots=True)`)."""
+    if len(csr) > 2:
+        wg_end = csr[2]
+        slot = csr[1].numel() // wg_end.numel()
+        return int((wg_end.long() - torch.arange(wg_end.numel(), device=wg_end.device) * slot).sum().item())
+    return int(csr[0][n_out].item())
+
+
 def convt_forward_csr_grid(feats, packed_w, bias, K, cin, cout, csr, out_set, act, ex_bias, slope=0.01):
     """`convt_forward_csr` with the constant-per-existing-neighbour term keyed on the output set's own grid index
     (no 3x3x3 kernel map of the candidate set)."""
@@ -779,13 +803,14 @@ def convt_forward_csr_grid(feats, packed_w, bias, K, cin, cout, csr, out_set, ac
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
     if n_out == 0 or n_in == 0:
         return out
-    first, pair_ids = csr
+    first, pair_ids = csr[0], csr[1]
+    wg_end = csr[2] if len(csr) > 2 else None                  # slotted lists (`csr_for(slots=True)`)
     g = out_set.grid()
     T = torch.empty(n_in * K * cout, dtype=torch.float32, device=feats.device)
     b = bias.detach().reshape(-1).contiguous() if bias is not None else None
     L.call("pcc_convt_fwd_csr_grid", L.ptr(feats), n_in, cin, L.ptr(packed_w), L.ptr(b), K, cout, L.ptr(first), L.ptr(pair_ids),
            n_out, L.ptr(T), L.ptr(out), act, float(slope), L.ptr(out_set.keys), L.ptr(g[0]), L.ptr(g[1]), g[2],
-           L.ptr(ex_bias.detach().to(torch.float32).contiguous()), *L.arith_args(feats.device), L.stream())
+           L.ptr(ex_bias.detach().to(torch.float32).contiguous()), L.ptr(wg_end), *L.arith_args(feats.device), L.stream())
     return out
 
 

@@ -114,6 +114,26 @@ class MeanScaleHyperprior(CompressionModel):
         x = self._conv_act(self.h_s[2], x, L.ACT_LEAKY)
         return self._conv_act(self.h_s[4], x, L.ACT_NONE)
 
+    def plan_synthesis(self, z_cset, y_cset):
+        """Coordinate-only pre-pass of the hyper-synthesis (inference): its two generative expansions, their pair lists and the
+        map of the last convolution onto y's rows depend on the COORDINATES of z and y alone, so the decoder queues them while
+        the hyper-latent's rANS decode runs on the side stream instead of in front of the features that wait for them (~25
+        small launches, no host read: a k2-s2 expansion makes exactly 8 children per row).  Everything is cached on the sets;
+        `_gaussian_params` finds it.  (The encoder's opening is host-bound: queued there the same launches cost 0.15 ms.)"""
+        if torch.is_grad_enabled() or not S.USE_GRID or z_cset.n == 0 or y_cset.n == 0:
+            return
+        cs = z_cset
+        for layer in (self.h_s[0], self.h_s[2]):
+            if not isinstance(layer, ME.MinkowskiGenerativeConvolutionTranspose) or cs.ts % layer.stride:
+                return
+            out_set = cs.expand(layer.kernel_size, cs.ts // layer.stride)
+            if cs.csr_map(layer.kernel_size, cs.ts // layer.stride) is None:
+                cs.kernel_map(out_set, layer.kernel_size, transposed=True, up_stride=layer.stride)
+            cs = out_set
+        last = self.h_s[4]
+        if last.kernel_size == 3 and last.stride == 1 and cs.ts == y_cset.ts:
+            cs.kernel_map(y_cset, 3)
+
     def gaussian_conditional_channels(self):
         return self.h_s[4].out_channels // 2
 

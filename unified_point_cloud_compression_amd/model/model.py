@@ -25,6 +25,8 @@ class UnifiedModel(CompressionModel):
         self.g_s = SparseSynthesisTransform(config["g_s"])
         self.entropy_model = MeanScaleHyperprior(config["entropy_model"])
 
+    PLAN_SYNTHESIS_EARLY = __import__("os").environ.get("PCC_PLAN_HS", "1") != "0"
+
     def update(self):
         self.entropy_model.update(force=True)
 
@@ -213,6 +215,8 @@ class UnifiedModel(CompressionModel):
                 z_cset = S.resolve(y_cset.stride_begin(ts_z), *self.g_s.plan(y_cset))[0]
             if z_cset.n != int(block_shape[0]):
                 raise L.PccError(f"bitstream says {int(block_shape[0])} hyper-latent rows, the coordinates give {z_cset.n}")
+            if self.PLAN_SYNTHESIS_EARLY:
+                self.entropy_model.plan_synthesis(z_cset, y_cset)   # (beside the hyper-latent's decode on the side stream)
             pre = self.entropy_model.predecode_upload(pre, block_symbols, device)
             y_hat = self.entropy_model.decompress([y_cset, z_cset], block_symbols, block_shape, q_vals[i], check=status, pre=pre)
             x_hat = self.g_s(y_hat, k=block_k, trace=trace, probe=probe)

@@ -532,6 +532,7 @@ __global__ void k_grid_enumerate(const unsigned long long* __restrict__ bits, co
 // the set bits back out of the words it already holds.  2048 words per workgroup (256 threads x 8 consecutive words).
 static constexpr int GR_B = 2048;
 static constexpr int64_t GR_DIRECT_NB = 16384;          // workgroup totals the apply pass sums up itself (as the scan does)
+static constexpr int64_t GR_SELF_NB = 8;                // lattices of <= 8 x 2048 words (1 M cells): rank + read-out in ONE launch
 
 __global__ void __launch_bounds__(256) k_grid_rank_reduce(const unsigned long long* __restrict__ bits, int64_t words,
                                                           int* __restrict__ sums) {
@@ -552,7 +553,10 @@ __global__ void __launch_bounds__(256) k_grid_rank_reduce(const unsigned long lo
   if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-template <bool ENUM>
+// SELF: no reduce pass ran -- the workgroup popcounts the words of the (few) workgroups before it itself.  Small lattices only
+// (<= GR_SELF_NB workgroups): there the three launches reduce / apply / read-out are pure launch latency, ~5 us each, and a step
+// builds about ten such grids (the hyper-prior's sets, the coarse end of the stride chain); ONE launch does all three.
+template <bool ENUM, bool SELF = false>
 __global__ void __launch_bounds__(256) k_grid_rank_apply(const unsigned long long* __restrict__ bits, int64_t words,
                                                          const int* __restrict__ sums, int* __restrict__ rank, int lo0, int lo1,
                                                          int lo2, int d0, int d1, int d2, int tsl, int64_t* __restrict__ keys,
@@ -563,6 +567,8 @@ __global__ void __launch_bounds__(256) k_grid_rank_apply(const unsigned long lon
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // offset of this workgroup: totals of the workgroups before it
   int part = 0;
+  if (SELF) { for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x * GR_B; i += 256) part += __popcll(bits[i]); }
+  else
   for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += sums[i];
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
@@ -643,6 +649,12 @@ static int g_grid_rank_fused = getenv("PCC_GRID_RANK_FUSED") ? atoi(getenv("PCC_
 static int grid_rank(const unsigned long long* b, int64_t words, int32_t* rank, const int32_t* h, int tsl, int64_t* out_keys,
                      int64_t* d_count, void* ws, size_t ws_bytes, hipStream_t s) {
   const int64_t nb = pcc_cdiv(words, GR_B);
+  if (g_grid_rank_fused && nb <= GR_SELF_NB && (((uintptr_t)b | (uintptr_t)rank) & 15) == 0) {      // small lattice: one launch
+    if (out_keys) k_grid_rank_apply<true, true><<<(unsigned)nb, 256, 0, s>>>(b, words, nullptr, rank, h[0], h[1], h[2], h[3], h[4], h[5], tsl, out_keys, d_count);
+    else k_grid_rank_apply<false, true><<<(unsigned)nb, 256, 0, s>>>(b, words, nullptr, rank, 0, 0, 0, 1, 1, 1, 0, nullptr, nullptr);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+  }
   if (g_grid_rank_fused && nb <= GR_DIRECT_NB && ws_bytes >= (size_t)nb * 4 + 256 && (((uintptr_t)b | (uintptr_t)rank) & 15) == 0) {
     int* sums = (int*)ws;
     k_grid_rank_reduce<<<(unsigned)nb, 256, 0, s>>>(b, words, sums);

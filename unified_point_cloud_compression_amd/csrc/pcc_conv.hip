@@ -3868,6 +3868,8 @@ static int convt_fwd_csr_impl(const float* feat_in, int64_t n_in, int32_t cin, c
   const bool timed_gather = g_prof_on && ex_grid;
   hipEvent_t g0, g1;
   if (timed_gather) PCC_TRY(prof_event(&g0, s));
+  // (round 4 probe: 8 slots on the last level as well -- 1.698 vs 1.703 ms per composite level: the gather-sum is bound by the
+  //  memory system's rate on 64-byte pieces, not by loads in flight)
   if (vec == 4 && l <= 2) k_convt_gather_csr<4, 4><<<gg, 256, 0, s>>>(g);
   else if (vec == 4) k_convt_gather_csr<4, 8><<<gg, 256, 0, s>>>(g);
   else k_convt_gather_csr<1, 8><<<gg, 256, 0, s>>>(g);

@@ -6,6 +6,8 @@
 // output-gradient row of each pair) into LDS and feeds v_mfma_f32_32x32x2_f32 with transposed operand reads.
 // Slices write partial tiles that a second kernel sums in slice order: deterministic, no atomics.
 // The data gradient needs no kernel of its own: it is the forward kernel on the inverse map with W^T (sparse.py).
+#include <stdlib.h>
+
 #include "pcc_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -225,6 +227,205 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same weight gradient on the 16-bit matrix pipe at fp32 accuracy (round 4): both operands split exactly into three bf16
+// planes (x = h + m + l, the split of k_conv_mfma_bf), six cross terms per product on v_mfma_f32_32x32x16_bf16 -- 2.67x the
+// rate of the fp32-input MFMA the kernel above runs on.  The reduction index of this GEMM is the PAIR, so an MFMA operand needs,
+// per channel, 8 consecutive pairs: the staging pass writes the LDS images TRANSPOSED, [plane][channel][pair], a thread packing
+// two pairs of one channel into one 32-bit store.  Channel rows are 88 bytes (32 pairs x 2 B + pad): the 32 lanes of a half wave
+// (16 pair-pairs x 2 channel groups 8 channels = 176 dwords apart) store to 32 different banks, and the fragment reads -- two
+// 8-byte reads per operand, rows 22 dwords apart -- are conflict-free as well.  Tile, slices, compaction of the pair list and the
+// fixed summation order are those of k_wgrad<false>.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wg_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const wg_f32x2 v = {x0, x1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg_bf16x2));
+  const wg_f32x2 r1 = {x0 - __builtin_bit_cast(float, h << 16), x1 - __builtin_bit_cast(float, h & 0xFFFF0000u)};
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, wg_bf16x2));
+  const wg_f32x2 r2 = {r1.x - __builtin_bit_cast(float, m << 16), r1.y - __builtin_bit_cast(float, m & 0xFFFF0000u)};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, wg_bf16x2));
+}
+
+static constexpr int WB_ROW = 88;                    // bytes per channel row of a transposed image
+static constexpr int WB_PLANE = 128 * WB_ROW;        // one plane: 128 channels
+
+__global__ void __launch_bounds__(256, 2) k_wgrad_bf(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char Xt[3 * WB_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Gt[3 * WB_PLANE];
+  __shared__ int c_in[WG_SUB + WG_PAIRS], c_out[WG_SUB + WG_PAIRS];
+  __shared__ int s_wtot[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kid = blockIdx.y;
+  const int slice = blockIdx.x;
+  const int mt = blockIdx.z / ((a.cout + 127) / 128), nt = blockIdx.z % ((a.cout + 127) / 128);
+  const int m0 = mt * 128, n0 = nt * 128;
+
+  long long pos_begin = 0, pos_count = a.n_out;
+  const int* seg_nbr = nullptr;
+  const bool identity = (a.hdr == nullptr);
+  if (!identity) {
+    const int nseg = a.hdr[HDR_NSEG];
+    bool found = false;
+    for (int s = 0; s < nseg && !found; ++s) {
+      const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+      for (int j = 0; j < sg[SEG_K_COUNT]; ++j)
+        if (a.hdr[HDR_KOFFS + sg[SEG_KOFF_BEGIN] + j] == kid) {
+          pos_begin = sg[SEG_POS_BEGIN]; pos_count = sg[SEG_POS_COUNT];
+          seg_nbr = a.nbr + (((long long)(unsigned)sg[SEG_NBR_LO]) | ((long long)sg[SEG_NBR_HI] << 32)) + (long long)j * pos_count;
+          found = true;
+          break;
+        }
+    }
+    if (!found) pos_count = 0;
+  }
+  const long long per = (pos_count + a.nslices - 1) / a.nslices;
+  const long long p_lo = (long long)slice * per;
+  const long long p_hi = min(pos_count, p_lo + per);
+
+  const int wm = w >> 1, wn = w & 1;
+  const int half = lane >> 5, r31 = lane & 31;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  bool sub_on[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sub_on[i][j] = m0 + (wm * 2 + i) * 32 < a.cin && n0 + (wn * 2 + j) * 32 < a.cout;
+
+  auto step = [&](const int* l_in, const int* l_out, int cnt) {
+    __syncthreads();                                 // previous step's fragment reads are done; the list is complete
+    {
+      const int pp = tid & 15, cg = tid >> 4;        // pairs 2 pp, 2 pp + 1 of the staged 32; channels cg * 8 .. + 7
+      const int r0 = 2 * pp, r1 = r0 + 1;
+      const int i0 = r0 < cnt ? l_in[r0] : -1, i1 = r1 < cnt ? l_in[r1] : -1;
+      const int o0 = r0 < cnt ? l_out[r0] : -1, o1 = r1 < cnt ? l_out[r1] : -1;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = cg * 8 + 4 * q;
+        const float4 x0 = i0 >= 0 ? load4(a.x + (long long)i0 * a.cin, a.cin, m0 + c) : z4;
+        const float4 x1 = i1 >= 0 ? load4(a.x + (long long)i1 * a.cin, a.cin, m0 + c) : z4;
+        const float4 g0 = i0 >= 0 ? load4(a.g + (long long)o0 * a.cout, a.cout, n0 + c) : z4;
+        const float4 g1 = i1 >= 0 ? load4(a.g + (long long)o1 * a.cout, a.cout, n0 + c) : z4;
+        const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, xb[4] = {x1.x, x1.y, x1.z, x1.w};
+        const float ga[4] = {g0.x, g0.y, g0.z, g0.w}, gb[4] = {g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned h, m, l;
+          const int off = (c + j) * WB_ROW + pp * 4;
+          wg_split2(xa[j], xb[j], h, m, l);
+          *reinterpret_cast<unsigned*>(Xt + off) = h;
+          *reinterpret_cast<unsigned*>(Xt + WB_PLANE + off) = m;
+          *reinterpret_cast<unsigned*>(Xt + 2 * WB_PLANE + off) = l;
+          wg_split2(ga[j], gb[j], h, m, l);
+          *reinterpret_cast<unsigned*>(Gt + off) = h;
+          *reinterpret_cast<unsigned*>(Gt + WB_PLANE + off) = m;
+          *reinterpret_cast<unsigned*>(Gt + 2 * WB_PLANE + off) = l;
+        }
+      }
+    }
+    __syncthreads();
+    // D[ci][co] += sum_pairs X[pair][ci] * G[pair][co]:  A[i = ci][k = pair], B[k = pair][j = co]; 16 pairs per MFMA
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      wg_bf16x8 af[3][2], bf[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned char* src = Xt + p * WB_PLANE + ((wm * 2 + i) * 32 + r31) * WB_ROW + kb * 32 + half * 16;
+          const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+          af[p][i] = __builtin_bit_cast(wg_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned char* src = Gt + p * WB_PLANE + ((wn * 2 + j) * 32 + r31) * WB_ROW + kb * 32 + half * 16;
+          const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+          bf[p][j] = __builtin_bit_cast(wg_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (sub_on[i][j]) {                          // smallest terms first (planes: 0 = h, 1 = m, 2 = l)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+          }
+    }
+  };
+
+  int pending = 0;
+  for (long long pb = p_lo; pb < p_hi; pb += WG_SUB) {
+    int ir[4], cnt = 0;
+    const long long q0 = pb + 4 * tid;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long p = q0 + j;
+      ir[j] = -1;
+      if (p < p_hi) ir[j] = identity ? (int)p : seg_nbr[p];
+      cnt += ir[j] >= 0;
+    }
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) s_wtot[w] = inc;
+    __syncthreads();
+    int off = pending + inc - cnt;
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (i < w) off += s_wtot[i]; total += s_wtot[i]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ir[j] >= 0) {
+        const long long p = q0 + j;
+        c_in[off] = ir[j];
+        c_out[off] = a.rows ? a.rows[pos_begin + p] : (int)(pos_begin + p);
+        ++off;
+      }
+    pending += total;
+    int g = 0;
+    for (; pending - g >= WG_PAIRS; g += WG_PAIRS) step(c_in + g, c_out + g, WG_PAIRS);
+    const int rem = pending - g;
+    __syncthreads();
+    int ti = 0, to = 0;
+    if (tid < rem) { ti = c_in[g + tid]; to = c_out[g + tid]; }
+    __syncthreads();
+    if (tid < rem) { c_in[tid] = ti; c_out[tid] = to; }
+    pending = rem;
+  }
+  if (pending > 0) step(c_in, c_out, pending);
+
+  float* dst = a.partial + ((long long)slice * a.K + kid) * a.cin * a.cout;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = n0 + (wn * 2 + j) * 32 + r31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (ci < a.cin && co < a.cout) dst[(long long)ci * a.cout + co] = acc[i][j][e];
+      }
+    }
+}
+
 __global__ void k_wgrad_reduce(const float* __restrict__ partial, long long elems, int nslices, float* __restrict__ dW) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= elems) return;
@@ -272,7 +473,10 @@ extern "C" int pcc_conv_wgrad(const float* feat_in, int64_t n_in, int32_t cin, c
   a.x = feat_in; a.g = grad_out; a.hdr = hdr; a.nbr = nbr; a.rows = rows; a.partial = (float*)ws; a.n_out = n_out;
   a.cin = cin; a.cout = cout; a.K = K; a.nslices = wgrad_slices(n_out, K, cin, cout);
   const unsigned tiles = (unsigned)(((cin + 127) / 128) * ((cout + 127) / 128));
+  // wide layers: six bf16 terms on the 16-bit pipe (k_wgrad_bf); env PCC_WGRAD_BF=0 keeps the fp32-input MFMA kernel
+  static const bool bf_on = getenv("PCC_WGRAD_BF") ? atoi(getenv("PCC_WGRAD_BF")) != 0 : true;
   if (cin <= 32 && cout <= 32) k_wgrad<true><<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
+  else if (bf_on) k_wgrad_bf<<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
   else k_wgrad<false><<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
   PCC_LAUNCH_CHECK();
   k_wgrad_reduce<<<(unsigned)pcc_cdiv(elems, 256), 256, 0, s>>>(a.partial, elems, a.nslices, dW);

@@ -457,6 +457,13 @@ int pcc_conv_wgrad(const float* feat_in, int64_t n_in, int32_t cin, const float*
                    void* ws, size_t ws_bytes, void* stream);
 int pcc_convt_scatter_rows(const float* grad_out, const int32_t* first, const int32_t* pair_ids, int64_t n_out,
                            int32_t cout, float* dT /*[n_in*K, cout]*/, void* stream);
+/* One-logit convolution over a set mapped onto itself (reference model/transforms.py:146-161, predict_*[2]; odd K <= 27,
+ * cin in {16,32,64}, cout = 1, stride 1): dW[k][ci] = sum_i feat[i][ci] * grad_out[nbr_{K-1-k}(i)] -- input-stationary, the feature
+ * rows are streamed once.  hdr/nbr: the map of the set onto ITSELF (the caller guarantees in_set == out_set). */
+int pcc_conv_wgrad_self_supported(int32_t K, int32_t cin, int32_t cout);
+size_t pcc_conv_wgrad_self_ws_bytes(int64_t n, int32_t K, int32_t cin);
+int pcc_conv_wgrad_self(const float* feat, int64_t n, int32_t cin, const float* grad_out /*[n]*/, int32_t K, const int32_t* hdr,
+                        const int32_t* nbr, float* dW /*[K,cin]*/, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 8f-1  rANS entropy coder + CDF tables  (CompressAI `_CXX`: `pmf_to_quantized_cdf`, `BufferedRansEncoder`,

@@ -49,7 +49,8 @@ def _check(mod, x, out_fn, pairs, n_out, act, W, b, f):
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride,act", [(16, 32, 3, 1, "relu"), (32, 16, 3, 1, "leaky"), (128, 128, 5, 2, None),
-                                                    (32, 1, 3, 1, None), (8, 3, 1, 1, None), (4, 16, 5, 2, None),
+                                                    (32, 1, 3, 1, None), (16, 1, 3, 1, None), (64, 1, 3, 1, "relu"),
+                                                    (8, 3, 1, 1, None), (4, 16, 5, 2, None),
                                                     (192, 192, 3, 2, "leaky")])
 def test_conv_gradients(cin, cout, ks, stride, act):
     import unified_point_cloud_compression_amd.MinkowskiEngine as ME
@@ -73,6 +74,31 @@ def test_conv_gradients(cin, cout, ks, stride, act):
         kmap = None if ks == 1 else cs.kernel_map(out_set, ks)
         return mod._apply_conv(x, out_set, kmap, act=code)
     _check(mod, x, run, pairs, len(out_keys), act, W, b, f)
+
+
+@pytest.mark.parametrize("cin", [16, 32, 64])
+def test_one_logit_self_map_weight_gradient_equals_the_pair_list_form(cin):
+    """`pcc_conv_wgrad_self` (input-stationary, inverse offsets of the set's own map) against `pcc_conv_wgrad` on the same map
+    and against the float64 sum over the oracle's pairs; a set large enough for several workgroup chunks and ragged tails."""
+    from unified_point_cloud_compression_amd import lib as L
+    from unified_point_cloud_compression_amd import sparse as S
+    keys = cloud_keys(cin, 40, 0.12, 1, batch=3)
+    rng = np.random.default_rng(cin)
+    f = rng.standard_normal((len(keys), cin)).astype(np.float32)
+    g = rng.standard_normal((len(keys), 1)).astype(np.float32)
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    cs = ME.SparseTensor(coordinates=t(co.unpack_keys(keys)), features=t(f))._cset      # rows in key order (keys are canonical)
+    kmap = cs.kernel_map(cs, 3)
+    assert L.load().pcc_conv_wgrad_self_supported(27, cin, 1)
+    a = n(S.conv_wgrad_self(t(f), t(g), 27, cin, kmap))
+    b = n(S.conv_wgrad(t(f), t(g), 27, cin, 1, kmap))
+    ref = np.zeros((27, cin, 1))
+    for k, (i, o) in enumerate(codec.kernel_map_pairs(keys, keys, 3, 1)):
+        if len(i):
+            ref[k, :, 0] = f[i].astype(np.float64).T @ g[o, 0].astype(np.float64)
+    assert_close(a, b, atol=2e-4, rtol=2e-4, what="self form vs pair-list form")
+    assert_close(a, ref.astype(np.float32), atol=2e-4, rtol=2e-4, what="self form vs float64 pairs")
+    assert not L.load().pcc_conv_wgrad_self_supported(27, cin, 2) and not L.load().pcc_conv_wgrad_self_supported(8, cin, 1)
 
 
 @pytest.mark.parametrize("cin,cout,ks", [(16, 16, 5), (128, 32, 5), (32, 32, 2), (192, 192, 2)])

@@ -9,10 +9,15 @@ The reference back-propagates through every `ME.MinkowskiConvolution` / `Minkows
   * the bias gradient is a column sum.
 Fused activations are differentiated from the saved output.
 """
+import os
+
 import torch
 
 from . import lib as L
 from . import sparse as S
+
+
+WGRAD_SELF = os.environ.get("PCC_WGRAD_SELF", "1") != "0"     # one-logit heads: input-stationary weight gradient
 
 
 def _pack(w3):
@@ -93,7 +98,11 @@ class SparseConvFn(torch.autograd.Function):
                 g_feats = _conv_any(dT, wt, None, feats.shape[0])
         else:
             if ctx.needs_input_grad[1]:
-                g_kernel = S.conv_wgrad(feats, g, K, cin, cout, kmap)
+                if (WGRAD_SELF and in_set is out_set and kmap is not None and kmap.rows is None and module.stride == 1
+                        and g.shape[0] == feats.shape[0] and L.load().pcc_conv_wgrad_self_supported(K, cin, cout)):
+                    g_kernel = S.conv_wgrad_self(feats, g, K, cin, kmap)
+                else:
+                    g_kernel = S.conv_wgrad(feats, g, K, cin, cout, kmap)
             if ctx.needs_input_grad[0]:
                 if K == 1:
                     g_feats = _conv_any(g, w3.permute(0, 2, 1), None, feats.shape[0])

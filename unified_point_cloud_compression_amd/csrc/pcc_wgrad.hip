@@ -509,6 +509,146 @@ extern "C" int pcc_conv_wgrad(const float* feat_in, int64_t n_in, int32_t cin, c
   return PCC_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of a ONE-logit convolution over a set mapped onto ITSELF (the occupancy heads' second convolution,
+// reference `model/transforms.py:146-161` predict_*[2]: cin -> 1, 3x3x3, stride 1 -- in the training step of configs[3] these run over the
+// largest candidate sets: 0.98 + 0.91 ms of the step through the pair-list GEMM, whose 128 x 128 / 32 x 32 tiles hold one
+// useful column).  For an odd kernel on one set the pair (i, o) of offset k is the pair (o, i) of offset K-1-k, so
+//     dW[k][ci] = sum_i  x[i][ci] * g[ nbr_{K-1-k}(i) ]
+// is INPUT-stationary: the feature rows stream through once, coalesced, the map is read once, and what is gathered is one
+// float per pair from an array that fits the L2.  A thread owns 4 channels of every (256 / LPR)-th row of its block's chunk
+// and keeps the K partial sums in registers; lanes are summed by an xor butterfly, waves in wave order, blocks by
+// k_wgrad_reduce in block order: deterministic.
+// ------------------------------------------------------------------------------------------
+static constexpr int WT_KMAX = 27;
+static constexpr int WT_MAX_BLOCKS = 1024;
+struct WgradThinArgs {
+  const float* x;        // [n, cin]
+  const float* g;        // [n]
+  const int* hdr;
+  const int* nbr;
+  float* partial;        // [nblocks][K][cin]
+  long long n;
+  int cin, K, nblocks;
+};
+
+template <int LPR>       // lanes per row = cin / 4
+__global__ void __launch_bounds__(256, 2) k_wgrad_thin(WgradThinArgs a) {
+  constexpr int RPI = 256 / LPR;                    // rows per iteration of a workgroup
+  constexpr int CIN = LPR * 4;
+  __shared__ __attribute__((aligned(16))) int4 s_seg[WT_KMAX];     // {lo, hi of (nbr offset - pos_begin), pos_begin, pos_count}
+  __shared__ __attribute__((aligned(16))) float red[4 * WT_KMAX * CIN];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < WT_KMAX) {                               // segment that lists the INVERSE offset of k
+    long long base = 0; int pb = 0, pc = 0;
+    const int kk = a.K - 1 - tid;
+    if (tid < a.K) {
+      const int nseg = a.hdr[HDR_NSEG];
+      bool found = false;
+      for (int s = 0; s < nseg && !found; ++s) {
+        const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+        for (int j = 0; j < sg[SEG_K_COUNT]; ++j)
+          if (a.hdr[HDR_KOFFS + sg[SEG_KOFF_BEGIN] + j] == kk) {
+            pb = sg[SEG_POS_BEGIN]; pc = sg[SEG_POS_COUNT];
+            base = (((long long)(unsigned)sg[SEG_NBR_LO]) | ((long long)sg[SEG_NBR_HI] << 32)) + (long long)j * pc - pb;
+            found = true;
+            break;
+          }
+      }
+    }
+    s_seg[tid] = make_int4((int)(unsigned)(base & 0xFFFFFFFFll), (int)(base >> 32), pb, pc);
+  }
+  __syncthreads();
+  const int rg = tid / LPR, l = tid % LPR;
+  long long per = (a.n + a.nblocks - 1) / a.nblocks;
+  per = (per + RPI - 1) / RPI * RPI;
+  const long long lo = (long long)blockIdx.x * per;
+  const long long hi = min(a.n, lo + per);
+  float4 acc[WT_KMAX];
+#pragma unroll
+  for (int k = 0; k < WT_KMAX; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long i = lo + rg; i < hi; i += RPI) {
+    const int4* seg = s_seg;
+    asm volatile("" : "+v"(seg));                   // the 27 segment records stay in LDS (hoisted they cost 108 SGPRs and spill)
+    const float4 xv = *reinterpret_cast<const float4*>(a.x + i * CIN + 4 * l);
+    int j[WT_KMAX];
+#pragma unroll
+    for (int k = 0; k < WT_KMAX; ++k) {
+      const int4 sg = seg[k];
+      const long long off = (((long long)(unsigned)sg.x) | ((long long)sg.y << 32)) + i;
+      const unsigned q = (unsigned)(i - sg.z);
+      j[k] = (k < a.K && q < (unsigned)sg.w) ? a.nbr[off] : -1;
+    }
+    float gv[WT_KMAX];
+#pragma unroll
+    for (int k = 0; k < WT_KMAX; ++k) gv[k] = j[k] >= 0 ? a.g[j[k]] : 0.f;
+#pragma unroll
+    for (int k = 0; k < WT_KMAX; ++k) {
+      acc[k].x = fmaf(xv.x, gv[k], acc[k].x); acc[k].y = fmaf(xv.y, gv[k], acc[k].y);
+      acc[k].z = fmaf(xv.z, gv[k], acc[k].z); acc[k].w = fmaf(xv.w, gv[k], acc[k].w);
+    }
+  }
+  // lanes holding the same channels: xor butterfly over the row index inside the wave (fixed tree)
+#pragma unroll
+  for (int k = 0; k < WT_KMAX; ++k) {
+#pragma unroll
+    for (int d = LPR; d < 64; d <<= 1) {
+      acc[k].x += __shfl_xor(acc[k].x, d, 64); acc[k].y += __shfl_xor(acc[k].y, d, 64);
+      acc[k].z += __shfl_xor(acc[k].z, d, 64); acc[k].w += __shfl_xor(acc[k].w, d, 64);
+    }
+    if (lane < LPR) *reinterpret_cast<float4*>(&red[(w * WT_KMAX + k) * CIN + 4 * lane]) = acc[k];
+  }
+  __syncthreads();
+  float* dst = a.partial + (long long)blockIdx.x * a.K * CIN;
+  for (int e = tid; e < a.K * CIN; e += 256) {
+    const int k = e / CIN, c = e - k * CIN;
+    dst[e] = ((red[(0 * WT_KMAX + k) * CIN + c] + red[(1 * WT_KMAX + k) * CIN + c]) + red[(2 * WT_KMAX + k) * CIN + c]) +
+             red[(3 * WT_KMAX + k) * CIN + c];
+  }
+}
+
+static bool wgrad_thin_ok(int K, int cin) { return K >= 1 && K <= WT_KMAX && (K & 1) && (cin == 16 || cin == 32 || cin == 64); }
+static int wgrad_thin_blocks(int64_t n, int cin) {
+  const int rpi = 256 / (cin / 4);
+  int64_t b = pcc_cdiv(n, (int64_t)rpi * 4);
+  if (b < 1) b = 1;
+  if (b > WT_MAX_BLOCKS) b = WT_MAX_BLOCKS;
+  return (int)b;
+}
+
+extern "C" int pcc_conv_wgrad_self_supported(int32_t K, int32_t cin, int32_t cout) { return cout == 1 && wgrad_thin_ok(K, cin); }
+
+extern "C" size_t pcc_conv_wgrad_self_ws_bytes(int64_t n, int32_t K, int32_t cin) {
+  return (size_t)wgrad_thin_blocks(n, cin) * (size_t)K * cin * sizeof(float) + 256;
+}
+
+extern "C" int pcc_conv_wgrad_self(const float* feat, int64_t n, int32_t cin, const float* grad_out, int32_t K,
+                                   const int32_t* hdr, const int32_t* nbr, float* dW, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCC_REQUIRE(dW && wgrad_thin_ok(K, cin), "pcc_conv_wgrad_self: odd K <= 27 and cin in {16, 32, 64} (see pcc_conv_wgrad_self_supported)");
+  const long long elems = (long long)K * cin;
+  if (n <= 0) {
+    PCC_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)elems * sizeof(float), s));
+    return PCC_OK;
+  }
+  PCC_REQUIRE(feat && grad_out && hdr && nbr && ws, "pcc_conv_wgrad_self: NULL array");
+  PCC_REQUIRE(n < (1ll << 31), "pcc_conv_wgrad_self: too many rows");
+  if (ws_bytes < pcc_conv_wgrad_self_ws_bytes(n, K, cin)) {
+    pcc_set_error("pcc_conv_wgrad_self: workspace too small");
+    return PCC_EWS;
+  }
+  WgradThinArgs a;
+  a.x = feat; a.g = grad_out; a.hdr = hdr; a.nbr = nbr; a.partial = (float*)ws; a.n = n; a.cin = cin; a.K = K;
+  a.nblocks = wgrad_thin_blocks(n, cin);
+  if (cin == 16) k_wgrad_thin<4><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
+  else if (cin == 32) k_wgrad_thin<8><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
+  else k_wgrad_thin<16><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
+  PCC_LAUNCH_CHECK();
+  k_wgrad_reduce<<<(unsigned)pcc_cdiv(elems, 256), 256, 0, s>>>(a.partial, elems, a.nblocks, dW);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
 // generative transposed conv backward: dT[pair] = grad_out[output row of the pair]   (every pair written once)
 template <typename VT>
 __global__ void k_convt_scatter(const VT* __restrict__ g, const int* __restrict__ first, const int* __restrict__ pair_ids,

@@ -37,12 +37,15 @@ class ColorLoss:
         prediction, q_map = pred["prediction"], pred["q_map"]
         gcs, pcs = gt._cset, prediction._cset
         rows = _lookup_rows(pcs, gcs.keys, gcs.n)                  # prediction row of every GT voxel (-1: not decoded)
-        ov = rows >= 0
-        pred_colors = prediction._canonical_features()[rows[ov]]
-        gt_colors = gt._canonical_features()[ov]
-        batch = (gcs.keys[:gcs.n] >> 48)[ov]
-        e = (gt_colors - pred_colors) ** 2 if self.l2 else (gt_colors - pred_colors).abs()
-        return (e * q_map[batch, 1].unsqueeze(1)).mean()
+        # mean over the overlapping voxels x channels, written with a 0/1 weight instead of boolean-mask indexing: a mask index
+        # makes torch count its rows on the host (a device->host wait here and again in the backward pass)
+        ov = (rows >= 0).to(torch.float32).unsqueeze(1)
+        pred_colors = prediction._canonical_features().index_select(0, rows.clamp(min=0))
+        gt_colors = gt._canonical_features()
+        batch = gcs.keys[:gcs.n] >> 48
+        d = (gt_colors - pred_colors) * ov
+        e = d * d if self.l2 else d.abs()
+        return (e * q_map[batch, 1].unsqueeze(1)).sum() / (ov.sum() * gt_colors.shape[1])
 
 
 class Multiscale_FocalLoss:

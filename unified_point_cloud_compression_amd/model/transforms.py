@@ -164,8 +164,11 @@ class SparseSynthesisTransform(nn.Module):
         cs = x._cset
         f = x._canonical_features()
         if torch.is_grad_enabled() and f.requires_grad:      # training: row selection through autograd
-            keys, _, n = S.prune(cs.keys, cs.n, None, mask, n_keep)
-            return SparseTensor._from_canonical(S.CoordSet(keys, n, cs.ts, cs.bounds), f[mask])
+            # the kept row numbers come from the same stable compaction as the keys (payload = 0..n-1): `f[mask]` would make
+            # torch count the mask on the host in the forward AND in the backward pass (two device->host waits per level)
+            idx, _, n = S.prune(torch.arange(cs.n, dtype=torch.int64, device=f.device), cs.n, None, mask, n_keep)
+            keys = cs.keys.index_select(0, idx)
+            return SparseTensor._from_canonical(S.CoordSet(keys, n, cs.ts, cs.bounds), f.index_select(0, idx))
         keys, feats, n = S.prune(cs.keys, cs.n, f, mask, n_keep)
         return SparseTensor._from_canonical(S.CoordSet(keys, n, cs.ts, cs.bounds), feats)
 

@@ -415,12 +415,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     from unified_point_cloud_compression_amd import frames as _frames
     cores = _frames.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else []
+    # PCC_BENCH_REHEARSE=1: the N-rank control flow on ONE GPU -- every rank on device 0, collectives over gloo on host tensors.
+    # A check that the ranks meet at the same collectives and that rank 0 prints its line; never a measurement (the line says so).
+    rehearse = world > 1 and os.environ.get("PCC_BENCH_REHEARSE", "0") == "1"
+    gpu_index = 0 if rehearse else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu_index))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(gpu_index)
+    device = torch.device("cuda", gpu_index)
+    coll_device = torch.device("cpu") if rehearse else device      # where the collectives' tensors live
 
     from unified_point_cloud_compression_amd import lib, synth, frames
     lib.load()
@@ -433,7 +441,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if rehearse else dist.barrier(device_ids=[gpu_index])
 
     for _ in range(args.warmup):
         step(model, pc, q)
@@ -441,10 +449,12 @@ def main():
     (flops_step, launches_step, pairs_step, alg_bytes_step, exec_flops_step, flops_by_form) = (
         account_flops(model, pc, q) if rank == 0 else (0.0, 0, 0, 0.0, 0.0, {}))
 
-    def timed_loop(steps, reuse_encoder_sets=False):
+    def timed_loop(steps, reuse_encoder_sets=False, all_ranks=True):
         """EXACTLY `steps` steps between barrier + synchronize on both sides.  The decoder gets PLAIN coordinate tensors
-        (`plain`): it rebuilds every coordinate set, map and pair list from them, as a decoder reading a bitstream must."""
-        barrier()
+        (`plain`): it rebuilds every coordinate set, map and pair list from them, as a decoder reading a bitstream must.
+        all_ranks=False: a rank-0-only diagnostic pass -- no collective inside (the other ranks are not in this loop)."""
+        if all_ranks:
+            barrier()
         torch.cuda.synchronize()
         t0 = time.time()
         t_enc, marks = 0.0, []
@@ -457,12 +467,27 @@ def main():
             rec = model.decompress(coordinates=coords, strings=out[0], shape=out[1], k=out[2], q_vals=out[4])
             marks.append(time.time())           # host time only (no sync): the next compress starts with a size read
         torch.cuda.synchronize()
-        barrier()
+        if all_ranks:
+            barrier()
         return time.time() - t0, t_enc, [t0] + marks, out, rec
 
     # pass 1 -- the one `value` comes from: no event records, no profiler hooks inside
     lib.call("pcc_prof_enable", 0)
     dt, t_enc, step_marks, out, rec = timed_loop(args.steps)
+
+    # every collective of the run happens HERE, right behind the timed pass: what follows is rank 0 alone (event pass, strict /
+    # fp32 / cached passes, auxiliary figures, CPU baseline) and must not contain one -- the other ranks are already past them
+    tt = torch.tensor([dt], dtype=torch.float64, device=coll_device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt_max = float(tt.item())
+    recs = frames.gather_records([(rank, n_points, t_enc / args.steps, (dt - t_enc) / args.steps, 0.0, rec.shape[0])],
+                                 coll_device)
+    # per-rank diagnostics for the first real multi-GPU run: where each rank's step went, on which cores it ran
+    steps_ms = [(b - a) * 1e3 for a, b in zip(step_marks[:-1], step_marks[1:])]
+    diag = frames.gather_records([(rank, t_enc / args.steps * 1e3, (dt - t_enc) / args.steps * 1e3, dt / args.steps * 1e3, min(steps_ms),
+                                   max(steps_ms), len(cores), cores[0] if cores else -1)], coll_device, n_fields=8)
+    total_points = sum(r[1] for r in recs)
 
     # pass 2 (rank 0, un-timed for `value`): the same steps with a HIP-event pair around every MFMA launch, recorded on the
     # launch stream inside the library -> launch durations by kernel form (roofline)
@@ -489,7 +514,7 @@ def main():
         def quick(n=5, **kw):
             for _ in range(2):
                 step(model, pc, q, **kw)
-            d, te, _, _, _ = timed_loop(n, **kw)
+            d, te, _, _, _ = timed_loop(n, all_ranks=False, **kw)
             return d / n * 1e3, (d - te) / n * 1e3
         try:
             lib.ARITH_FORCE = lib.ARITH_BF6               # (process-wide diagnostic override: encoder and decoder alike)
@@ -516,17 +541,6 @@ def main():
         hot_ms = (time.time() - t1) / 3 * 1e3
         del m2
 
-    tt = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt_max = float(tt.item())
-    recs = frames.gather_records([(rank, n_points, t_enc / args.steps, (dt - t_enc) / args.steps, 0.0, rec.shape[0])],
-                                 device)
-    # per-rank diagnostics for the first real multi-GPU run: where each rank's step went, on which cores it ran
-    steps_ms = [(b - a) * 1e3 for a, b in zip(step_marks[:-1], step_marks[1:])]
-    diag = frames.gather_records([(rank, t_enc / args.steps * 1e3, (dt - t_enc) / args.steps * 1e3, dt / args.steps * 1e3, min(steps_ms),
-                                   max(steps_ms), len(cores), cores[0] if cores else -1)], device, n_fields=8)
-    total_points = sum(r[1] for r in recs)
 
     def count_bits(strings):   # `utils.count_bits` (utils.py:30-48)
         return sum(count_bits(x) if isinstance(x, list) else len(x) * 8 for x in strings)
@@ -659,6 +673,8 @@ def main():
                        "device": arch, "cus": cu},
             "roofline": roof,
         }
+        if rehearse:
+            line["rehearsal"] = f"{world} ranks sharing ONE GPU, collectives over gloo: a control-flow check, not a measurement"
         if world == 1 and not args.no_aux:
             line["config"]["aux_true_geometry"] = true_geometry_ms(model, pc, q)
             line["config"]["aux_train_step"] = train_step_ms(device)

@@ -22,12 +22,26 @@ ap.add_argument("--bits", type=int, nargs="+", default=[10, 10, 11, 10], help="g
 ap.add_argument("--block-size", type=int, default=None, help="default: 1024 for <= 10 bits, 512 above (evaluate.py:39-46)")
 args = ap.parse_args()
 rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+# PCC_BENCH_REHEARSE=1: the N-rank sweep on ONE GPU (every rank on device 0, collectives over gloo on host tensors) -- a check of
+# the sharded control flow where no multi-GPU node is at hand, never a measurement
+rehearse = world > 1 and os.environ.get("PCC_BENCH_REHEARSE", "0") == "1"
+gpu = 0 if rehearse else local
 if world > 1:
     frames.pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))    # own cores, before the first GPU call
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-torch.cuda.set_device(local)
-dev = torch.device("cuda", local)
+    if rehearse:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu))
+torch.cuda.set_device(gpu)
+dev = torch.device("cuda", gpu)
+coll = torch.device("cpu") if rehearse else dev           # where the collectives' tensors live
+
+
+def barrier():
+    dist.barrier() if rehearse else dist.barrier(device_ids=[gpu])
+
+
 model = bench.build_model(dev)
 q = torch.tensor([[0.5, 0.5]], device=dev)
 clouds = {}
@@ -50,7 +64,7 @@ for i in range(len(args.bits)):
     if i % world == rank:
         frame_blocks[i] = model.blocks_of(cloud(i), block_size(i))
         local_sizes[i] = [int(b.shape[0]) for b in frame_blocks[i]]
-sizes = frames.gather_block_sizes(local_sizes, dev, rank, world)
+sizes = frames.gather_block_sizes(local_sizes, coll, rank, world)
 balance = frames.load_balance(sizes, world)
 
 
@@ -78,12 +92,12 @@ mine = frames.assign([n for _, _, n in items], world)[rank]
 if mine:
     process(*items[mine[0]][:2])                       # warm-up on this rank's first item (allocator, weight packing)
 if world > 1:
-    dist.barrier(device_ids=[local])
+    barrier()
 torch.cuda.synchronize()
 t_wall0 = time.time()
-recs, totals = frames.run_sharded_blocks(sizes, process, dev, rank, world)
+recs, totals = frames.run_sharded_blocks(sizes, process, coll, rank, world)
 torch.cuda.synchronize()
-wall = torch.tensor([time.time() - t_wall0], dtype=torch.float64, device=dev)
+wall = torch.tensor([time.time() - t_wall0], dtype=torch.float64, device=coll)
 if world > 1:
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)        # the sweep ends when the slowest rank ends
 wall = float(wall.item())
@@ -101,6 +115,8 @@ if rank == 0:
     print(f"{len(totals)} frames as {len(recs)} (frame, block) items over {world} rank(s): {tot} points in {wall:.3f} s wall (max over "
           f"ranks, includes the block-local D1 report) = {tot / wall / 1e6:.2f} M points/s; point load max/mean over ranks {balance:.3f}; "
           f"coding time alone, perfectly balanced: {tot / busy * world / 1e6:.1f} M points/s")
+if rank == 0 and rehearse:
+    print(f"REHEARSAL: {world} ranks shared one GPU over gloo -- control flow only, the rates above are not measurements")
 if world > 1:
-    dist.barrier(device_ids=[local])
+    barrier()
     dist.destroy_process_group()

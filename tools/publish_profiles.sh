@@ -15,4 +15,7 @@ grep -v amdgpu.ids $M/eval_frames.txt > $P/${R}_eval_frames_blocks_1gpu.txt
 [ -f $M/host_timeline.txt ] && cp $M/host_timeline.txt $P/${R}_host_timeline.txt
 [ -f $M/host_reads.txt ] && grep -v amdgpu.ids $M/host_reads.txt > $P/${R}_host_reads_per_step.txt
 [ -f $M/sq_by_kernel.txt ] && cp $M/sq_by_kernel.txt $P/${R}_sq_mfma_busy_by_kernel.txt
+[ -f $M/train_gpu_gaps.txt ] && cp $M/train_gpu_gaps.txt $P/${R}_train_step_gpu_gaps.txt
+[ -f $M/train_attribution.txt ] && grep -v amdgpu.ids $M/train_attribution.txt > $P/${R}_train_step_by_layer.txt
+[ -f $M/train_host_by_node.txt ] && grep -v "amdgpu.ids\|Warn\|warn" $M/train_host_by_node.txt > $P/${R}_train_step_host_by_node.txt
 ls -la $P | grep ${R}_ | wc -l

@@ -2636,8 +2636,10 @@ static int launch_mfma(const ConvArgs& a_in, int tiles_bound_extra, hipStream_t 
   // a serial loop of 100-160 chunks at ~2 us per chunk on a handful of CUs.  Cut the reduction over ksplit workgroups
   // (partial tiles in the library scratch, summed in fixed order): the chain gets ksplit times shorter and the grid fills.
   int ksplit = 1;
-  if (split && g_splitk && MODE == MODE_CONV && a.hdr && !a.pair_in && (a.cout & 3) == 0) {
-    const int depth = 27 * a.ppo;                      // chunks of a 3x3x3 map (the maps that reach here; 5x5x5 take the pair form)
+  // (round 4: also the K = 1 products with a very deep reduction -- the data gradient of a generative transposed convolution is
+  //  dT [n, 125 * cout] x Wflat^T: 500 chunks in one workgroup per 128 rows, 45 workgroups, 0.58 ms for 23 GFLOP)
+  if (split && g_splitk && MODE == MODE_CONV && !a.pair_in && !a.rows && (a.cout & 3) == 0) {
+    const int depth = (a.hdr ? 27 : 1) * a.ppo;        // chunks of a 3x3x3 map (the maps that reach here; 5x5x5 take the pair form)
     if (tiles(128) * gy < 256 && depth >= 64) {
       ksplit = depth / g_splitk_chunks;                // ~40 chunks per workgroup
       if (ksplit > 8) ksplit = 8;

@@ -27,6 +27,15 @@ __device__ inline float4 load4(const float* __restrict__ row, int width, int col
   return v;
 }
 
+// the same for rows whose pitch is a multiple of 4 floats, WITHOUT a branch: an absent pair (row < 0) or a column beyond the
+// row reads element 0 and is zeroed by a select.  (With load4 inside `cond ? load : 0` the compiler built a branch per load and
+// waited for each: 527 branches and 54 `s_waitcnt vmcnt(0)` in k_wgrad_bf, eight serialised memory latencies per 32 pairs.)
+__device__ __forceinline__ float4 load4v(const float* __restrict__ base, int row, int width, int col) {
+  const bool ok = row >= 0 && col < width;
+  const float4 v = *reinterpret_cast<const float4*>(base + (ok ? (long long)row * width + col : 0ll));
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 struct WgradArgs {
   const float* x;        // [n_in, cin]
   const float* g;        // [n_out, cout]
@@ -91,6 +100,7 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
   const long long p_lo = (long long)slice * per;
   const long long p_hi = min(pos_count, p_lo + per);
 
+  const bool vec = ((a.cin | a.cout) & 3) == 0;
   const int wm = w >> 1, wn = w & 1;                // full tile: 2x2 waves, each 64x64 of the 128x128 tile
   const int half = lane >> 5, r31 = lane & 31;
   f32x16 acc[2][2];
@@ -115,10 +125,16 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
 #pragma unroll
       for (int q = 0; q < (NARROW ? 1 : 4); ++q) {
         const int c = (part + 8 * q) * 4;
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), gv = xv;
-        if (ir >= 0) {
-          xv = load4(a.x + (long long)ir * a.cin, a.cin, m0 + c);
-          gv = load4(a.g + (long long)orow * a.cout, a.cout, n0 + c);
+        float4 xv, gv;
+        if (vec) {                                   // wave-uniform: rows of 4-float multiples, branch-free loads
+          xv = load4v(a.x, ir, a.cin, m0 + c);
+          gv = load4v(a.g, ir >= 0 ? orow : -1, a.cout, n0 + c);
+        } else {
+          xv = make_float4(0.f, 0.f, 0.f, 0.f); gv = xv;
+          if (ir >= 0) {
+            xv = load4(a.x + (long long)ir * a.cin, a.cin, m0 + c);
+            gv = load4(a.g + (long long)orow * a.cout, a.cout, n0 + c);
+          }
         }
         *reinterpret_cast<float4*>(&Xs[r * LD + c]) = xv;
         *reinterpret_cast<float4*>(&Gs[r * LD + c]) = gv;
@@ -285,7 +301,17 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_bf(WgradArgs a) {
   const long long p_lo = (long long)slice * per;
   const long long p_hi = min(pos_count, p_lo + per);
 
-  const int wm = w >> 1, wn = w & 1;
+  // wave -> 32 x 32 blocks of the 128 x 128 tile: 2 x 2 waves of 2 x 2 blocks; a tile that is at most 64 wide in one direction is
+  // cut the other way (4 x 1 waves of 1 x 2 blocks, or 1 x 4 of 2 x 1; 2 x 2 of 1 x 1 when both are), so that all four waves
+  // multiply (128 -> 64: two of the four waves did all the MFMAs)
+  const bool thin_m = a.cin - m0 <= 64, thin_n = a.cout - n0 <= 64;
+  int bm[2], bn[2];
+  bool vm[2], vn[2];
+  if (!thin_m && !thin_n) { bm[0] = (w >> 1) * 2; bm[1] = bm[0] + 1; bn[0] = (w & 1) * 2; bn[1] = bn[0] + 1; vm[1] = vn[1] = true; }
+  else if (!thin_m) { bm[0] = w; bm[1] = w; bn[0] = 0; bn[1] = 1; vm[1] = false; vn[1] = true; }
+  else if (!thin_n) { bm[0] = 0; bm[1] = 1; bn[0] = w; bn[1] = w; vm[1] = true; vn[1] = false; }
+  else { bm[0] = bm[1] = w >> 1; bn[0] = bn[1] = w & 1; vm[1] = vn[1] = false; }
+  vm[0] = vn[0] = true;
   const int half = lane >> 5, r31 = lane & 31;
   f32x16 acc[2][2];
 #pragma unroll
@@ -298,35 +324,34 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_bf(WgradArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) sub_on[i][j] = m0 + (wm * 2 + i) * 32 < a.cin && n0 + (wn * 2 + j) * 32 < a.cout;
+    for (int j = 0; j < 2; ++j) sub_on[i][j] = vm[i] && vn[j] && m0 + bm[i] * 32 < a.cin && n0 + bn[j] * 32 < a.cout;
 
   // A step = 32 pairs: `issue` starts the global loads of a step's rows into registers, `commit` splits them and writes the
   // transposed LDS images, `compute` multiplies.  Inside a compacted sub-block the loads of step n + 1 are issued before step n
   // is multiplied (the first version waited for every step's rows -- a full memory latency per 32 pairs -- and the 16-bit
   // MFMAs bought nothing: 209 us per launch against 199 for the fp32-input kernel).
   const int pp = tid & 15, cg = tid >> 4;            // pairs 2 pp, 2 pp + 1 of the staged 32; channels cg * 8 .. + 7
-  float4 rx0[2], rx1[2], rg0[2], rg1[2];
-  auto issue = [&](const int* l_in, const int* l_out, int cnt) {
+  struct Stage { float4 x0[2], x1[2], g0[2], g1[2]; };
+  auto issue = [&](Stage& st, const int* l_in, const int* l_out, int cnt) {
     const int r0 = 2 * pp, r1 = r0 + 1;
     const int i0 = r0 < cnt ? l_in[r0] : -1, i1 = r1 < cnt ? l_in[r1] : -1;
     const int o0 = r0 < cnt ? l_out[r0] : -1, o1 = r1 < cnt ? l_out[r1] : -1;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 2; ++q) {                    // (cin, cout multiples of 4: the dispatcher sends other shapes to k_wgrad)
       const int c = cg * 8 + 4 * q;
-      rx0[q] = i0 >= 0 ? load4(a.x + (long long)i0 * a.cin, a.cin, m0 + c) : z4;
-      rx1[q] = i1 >= 0 ? load4(a.x + (long long)i1 * a.cin, a.cin, m0 + c) : z4;
-      rg0[q] = i0 >= 0 ? load4(a.g + (long long)o0 * a.cout, a.cout, n0 + c) : z4;
-      rg1[q] = i1 >= 0 ? load4(a.g + (long long)o1 * a.cout, a.cout, n0 + c) : z4;
+      st.x0[q] = load4v(a.x, i0, a.cin, m0 + c);
+      st.x1[q] = load4v(a.x, i1, a.cin, m0 + c);
+      st.g0[q] = load4v(a.g, i0 >= 0 ? o0 : -1, a.cout, n0 + c);
+      st.g1[q] = load4v(a.g, i1 >= 0 ? o1 : -1, a.cout, n0 + c);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](const Stage& st) {
     __syncthreads();                                 // previous step's fragment reads are done
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int c = cg * 8 + 4 * q;
-      const float xa[4] = {rx0[q].x, rx0[q].y, rx0[q].z, rx0[q].w}, xb[4] = {rx1[q].x, rx1[q].y, rx1[q].z, rx1[q].w};
-      const float ga[4] = {rg0[q].x, rg0[q].y, rg0[q].z, rg0[q].w}, gb[4] = {rg1[q].x, rg1[q].y, rg1[q].z, rg1[q].w};
+      const float xa[4] = {st.x0[q].x, st.x0[q].y, st.x0[q].z, st.x0[q].w}, xb[4] = {st.x1[q].x, st.x1[q].y, st.x1[q].z, st.x1[q].w};
+      const float ga[4] = {st.g0[q].x, st.g0[q].y, st.g0[q].z, st.g0[q].w}, gb[4] = {st.g1[q].x, st.g1[q].y, st.g1[q].z, st.g1[q].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned h, m, l;
@@ -352,13 +377,13 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_bf(WgradArgs a) {
       for (int p = 0; p < 3; ++p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const unsigned char* src = Xt + p * WB_PLANE + ((wm * 2 + i) * 32 + r31) * WB_ROW + kb * 32 + half * 16;
+          const unsigned char* src = Xt + p * WB_PLANE + (bm[i] * 32 + r31) * WB_ROW + kb * 32 + half * 16;
           const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
           af[p][i] = __builtin_bit_cast(wg_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const unsigned char* src = Gt + p * WB_PLANE + ((wn * 2 + j) * 32 + r31) * WB_ROW + kb * 32 + half * 16;
+          const unsigned char* src = Gt + p * WB_PLANE + (bn[j] * 32 + r31) * WB_ROW + kb * 32 + half * 16;
           const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
           bf[p][j] = __builtin_bit_cast(wg_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
         }
@@ -377,10 +402,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_bf(WgradArgs a) {
           }
     }
   };
+  Stage sa, sb;
   auto step = [&](const int* l_in, const int* l_out, int cnt) {       // (un-pipelined: the tail of the list)
     __syncthreads();                                                    // the list is complete
-    issue(l_in, l_out, cnt);
-    commit();
+    issue(sa, l_in, l_out, cnt);
+    commit(sa);
     compute();
   };
 
@@ -420,12 +446,22 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_bf(WgradArgs a) {
     int g = 0;
     if (pending >= WG_PAIRS) {
       __syncthreads();                               // the list is complete
-      issue(c_in, c_out, WG_PAIRS);
-      for (; pending - g >= WG_PAIRS; g += WG_PAIRS) {
-        commit();                                    // rows of step g -> LDS
-        if (pending - (g + WG_PAIRS) >= WG_PAIRS) issue(c_in + g + WG_PAIRS, c_out + g + WG_PAIRS, WG_PAIRS);   // in flight during the MFMAs
+      // two register stages: the rows of steps n + 1 AND n + 2 are in flight while step n is multiplied (with one stage the
+      // loads were outstanding during a third of a step only and the kernel gathered at 1.2 TB/s)
+      const int full = pending / WG_PAIRS;           // steps of this sub-block
+      issue(sa, c_in, c_out, WG_PAIRS);
+      if (full > 1) issue(sb, c_in + WG_PAIRS, c_out + WG_PAIRS, WG_PAIRS);
+      for (int st = 0; st < full; st += 2) {
+        commit(sa);                                  // rows of step st -> LDS
+        if (st + 2 < full) issue(sa, c_in + (st + 2) * WG_PAIRS, c_out + (st + 2) * WG_PAIRS, WG_PAIRS);
         compute();
+        if (st + 1 < full) {
+          commit(sb);
+          if (st + 3 < full) issue(sb, c_in + (st + 3) * WG_PAIRS, c_out + (st + 3) * WG_PAIRS, WG_PAIRS);
+          compute();
+        }
       }
+      g = full * WG_PAIRS;
     }
     const int rem = pending - g;
     __syncthreads();
@@ -442,10 +478,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_bf(WgradArgs a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int co = n0 + (wn * 2 + j) * 32 + r31;
+      if (!sub_on[i][j]) continue;
+      const int co = n0 + bn[j] * 32 + r31;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int ci = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int ci = m0 + bm[i] * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
         if (ci < a.cin && co < a.cout) dst[(long long)ci * a.cout + co] = acc[i][j][e];
       }
     }
@@ -501,7 +538,7 @@ extern "C" int pcc_conv_wgrad(const float* feat_in, int64_t n_in, int32_t cin, c
   // wide layers: six bf16 terms on the 16-bit pipe (k_wgrad_bf); env PCC_WGRAD_BF=0 keeps the fp32-input MFMA kernel
   static const bool bf_on = getenv("PCC_WGRAD_BF") ? atoi(getenv("PCC_WGRAD_BF")) != 0 : true;
   if (cin <= 32 && cout <= 32) k_wgrad<true><<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
-  else if (bf_on) k_wgrad_bf<<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
+  else if (bf_on && ((cin | cout) & 3) == 0) k_wgrad_bf<<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
   else k_wgrad<false><<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
   PCC_LAUNCH_CHECK();
   k_wgrad_reduce<<<(unsigned)pcc_cdiv(elems, 256), 256, 0, s>>>(a.partial, elems, a.nslices, dW);
@@ -534,10 +571,12 @@ struct WgradThinArgs {
 
 template <int LPR>       // lanes per row = cin / 4
 __global__ void __launch_bounds__(256, 2) k_wgrad_thin(WgradThinArgs a) {
-  constexpr int RPI = 256 / LPR;                    // rows per iteration of a workgroup
+  constexpr int RPI = 256 / LPR;                    // rows per accumulation sub-step of a workgroup
   constexpr int CIN = LPR * 4;
+  constexpr int GS = 29;                            // words per row of the exchange buffer (odd: rows fall on different banks)
+  constexpr int RED = 4 * WT_KMAX * CIN;
   __shared__ __attribute__((aligned(16))) int4 s_seg[WT_KMAX];     // {lo, hi of (nbr offset - pos_begin), pos_begin, pos_count}
-  __shared__ __attribute__((aligned(16))) float red[4 * WT_KMAX * CIN];
+  __shared__ __attribute__((aligned(16))) float buf[(256 * GS > RED) ? 256 * GS : RED];   // g values [row][k]; at the end: red[w][k][ci]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid < WT_KMAX) {                               // segment that lists the INVERSE offset of k
     long long base = 0; int pb = 0, pc = 0;
@@ -561,34 +600,51 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_thin(WgradThinArgs a) {
   __syncthreads();
   const int rg = tid / LPR, l = tid % LPR;
   long long per = (a.n + a.nblocks - 1) / a.nblocks;
-  per = (per + RPI - 1) / RPI * RPI;
+  per = (per + 255) / 256 * 256;
   const long long lo = (long long)blockIdx.x * per;
   const long long hi = min(a.n, lo + per);
   float4 acc[WT_KMAX];
 #pragma unroll
   for (int k = 0; k < WT_KMAX; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long long i = lo + rg; i < hi; i += RPI) {
-    const int4* seg = s_seg;
-    asm volatile("" : "+v"(seg));                   // the 27 segment records stay in LDS (hoisted they cost 108 SGPRs and spill)
-    const float4 xv = *reinterpret_cast<const float4*>(a.x + i * CIN + 4 * l);
-    int j[WT_KMAX];
+  // 256 rows at a time.  Phase 1, thread = row: the row's K inverse neighbours and their gradient values -- every load instruction
+  // of a wave covers 64 consecutive rows (the first version had a thread per (row, 4 channels): 4 / 16 lanes asked for the same
+  // word and a wave's 54 map / gradient loads served 16 / 4 rows: 0.44 ms for the 992 k-row head).  The values go through LDS
+  // to phase 2, thread = (row, 4 channels), which streams the feature rows and accumulates.
+  for (long long i0 = lo; i0 < hi; i0 += 256) {
+    {
+      const long long i = i0 + tid;
+      const int4* seg = s_seg;
+      asm volatile("" : "+v"(seg));                 // the segment records stay in LDS (hoisted they cost 108 SGPRs and spill)
+      int j[WT_KMAX];
 #pragma unroll
-    for (int k = 0; k < WT_KMAX; ++k) {
-      const int4 sg = seg[k];
-      const long long off = (((long long)(unsigned)sg.x) | ((long long)sg.y << 32)) + i;
-      const unsigned q = (unsigned)(i - sg.z);
-      j[k] = (k < a.K && q < (unsigned)sg.w) ? a.nbr[off] : -1;
+      for (int k = 0; k < WT_KMAX; ++k) {
+        const int4 sg = seg[k];
+        const long long off = (((long long)(unsigned)sg.x) | ((long long)sg.y << 32)) + i;
+        const unsigned q = (unsigned)(i - sg.z);
+        j[k] = (i < hi && k < a.K && q < (unsigned)sg.w) ? a.nbr[off] : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < WT_KMAX; ++k) buf[tid * GS + k] = j[k] >= 0 ? a.g[j[k]] : 0.f;
     }
-    float gv[WT_KMAX];
+    __syncthreads();
+#pragma unroll 1
+    for (int sub = 0; sub < LPR; ++sub) {
+      const int r = sub * RPI + rg;
+      const long long i = i0 + r;
+      if (i < hi) {
+        const float4 xv = *reinterpret_cast<const float4*>(a.x + i * CIN + 4 * l);
 #pragma unroll
-    for (int k = 0; k < WT_KMAX; ++k) gv[k] = j[k] >= 0 ? a.g[j[k]] : 0.f;
-#pragma unroll
-    for (int k = 0; k < WT_KMAX; ++k) {
-      acc[k].x = fmaf(xv.x, gv[k], acc[k].x); acc[k].y = fmaf(xv.y, gv[k], acc[k].y);
-      acc[k].z = fmaf(xv.z, gv[k], acc[k].z); acc[k].w = fmaf(xv.w, gv[k], acc[k].w);
+        for (int k = 0; k < WT_KMAX; ++k) {
+          const float gv = buf[r * GS + k];
+          acc[k].x = fmaf(xv.x, gv, acc[k].x); acc[k].y = fmaf(xv.y, gv, acc[k].y);
+          acc[k].z = fmaf(xv.z, gv, acc[k].z); acc[k].w = fmaf(xv.w, gv, acc[k].w);
+        }
+      }
     }
+    __syncthreads();
   }
   // lanes holding the same channels: xor butterfly over the row index inside the wave (fixed tree)
+  float* red = buf;
 #pragma unroll
   for (int k = 0; k < WT_KMAX; ++k) {
 #pragma unroll
@@ -607,10 +663,29 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_thin(WgradThinArgs a) {
   }
 }
 
+// sum of many partial blocks: 16 elements x 16 slice lanes per workgroup, every lane adds its slices in ascending order, the 16
+// lane sums are added in lane order (k_wgrad_reduce walks ALL slices in one thread: 0.35 ms for 1024 blocks of 432 values)
+__global__ void __launch_bounds__(256) k_wgrad_reduce_wide(const float* __restrict__ partial, long long elems, int nslices,
+                                                           float* __restrict__ dW) {
+  __shared__ float s[16][17];
+  const int el = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const long long e = (long long)blockIdx.x * 16 + el;
+  float v = 0.f;
+  if (e < elems)
+    for (int sl = sg; sl < nslices; sl += 16) v += partial[(long long)sl * elems + e];
+  s[sg][el] = v;
+  __syncthreads();
+  if (sg == 0 && e < elems) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += s[q][el];
+    dW[e] = t;
+  }
+}
+
 static bool wgrad_thin_ok(int K, int cin) { return K >= 1 && K <= WT_KMAX && (K & 1) && (cin == 16 || cin == 32 || cin == 64); }
 static int wgrad_thin_blocks(int64_t n, int cin) {
-  const int rpi = 256 / (cin / 4);
-  int64_t b = pcc_cdiv(n, (int64_t)rpi * 4);
+  int64_t b = pcc_cdiv(n, 512);                  // at least two 256-row rounds per workgroup
   if (b < 1) b = 1;
   if (b > WT_MAX_BLOCKS) b = WT_MAX_BLOCKS;
   return (int)b;
@@ -644,7 +719,7 @@ extern "C" int pcc_conv_wgrad_self(const float* feat, int64_t n, int32_t cin, co
   else if (cin == 32) k_wgrad_thin<8><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
   else k_wgrad_thin<16><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
   PCC_LAUNCH_CHECK();
-  k_wgrad_reduce<<<(unsigned)pcc_cdiv(elems, 256), 256, 0, s>>>(a.partial, elems, a.nblocks, dW);
+  k_wgrad_reduce_wide<<<(unsigned)pcc_cdiv(elems, 16), 256, 0, s>>>(a.partial, elems, a.nblocks, dW);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

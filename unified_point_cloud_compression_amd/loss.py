@@ -36,13 +36,15 @@ class ColorLoss:
     def __call__(self, gt, pred):
         prediction, q_map = pred["prediction"], pred["q_map"]
         gcs, pcs = gt._cset, prediction._cset
-        rows = _lookup_rows(pcs, gcs.keys, gcs.n)                  # prediction row of every GT voxel (-1: not decoded)
-        # mean over the overlapping voxels x channels, written with a 0/1 weight instead of boolean-mask indexing: a mask index
-        # makes torch count its rows on the host (a device->host wait here and again in the backward pass)
+        # The overlapping voxels are enumerated from the PREDICTION side: the ground-truth row of every decoded voxel (-1: none),
+        # the ground-truth colours gathered (no gradient), the prediction's own rows used in place -- so the backward pass has no
+        # scatter in it.  A 0/1 weight replaces boolean-mask indexing (which makes torch count the mask on the host, in both
+        # directions).  Same pairs and weights as `loss.py:84-111`; mean over overlapping voxels x channels.
+        rows = _lookup_rows(gcs, pcs.keys, pcs.n)
         ov = (rows >= 0).to(torch.float32).unsqueeze(1)
-        pred_colors = prediction._canonical_features().index_select(0, rows.clamp(min=0))
-        gt_colors = gt._canonical_features()
-        batch = gcs.keys[:gcs.n] >> 48
+        gt_colors = gt._canonical_features().index_select(0, rows.clamp(min=0))
+        pred_colors = prediction._canonical_features()
+        batch = pcs.keys[:pcs.n] >> 48
         d = (gt_colors - pred_colors) * ov
         e = d * d if self.l2 else d.abs()
         return (e * q_map[batch, 1].unsqueeze(1)).sum() / (ov.sum() * gt_colors.shape[1])

@@ -38,6 +38,9 @@ class UnifiedModel(CompressionModel):
         prediction, points (ground-truth coordinates at strides 4, 2, 1), occ_predictions, q_map, likelihoods."""
         feats = torch.cat([torch.ones((x.C.shape[0], 1), device=x.device), x.F], dim=1)
         x = SparseTensor(coordinates=x.C, features=feats, device=x.device)
+        chain = x._cset.stride_chain_begin(self.stride_chain())      # g_a's and h_a's output sets: one batch of launches, one read
+        if chain is not None:
+            S.resolve(chain)
         coords = SparseTensor._from_canonical(x._cset, torch.ones((x._cset.n, 1), device=x.device))
         y, k = self.g_a(x)
         y_hat, likelihoods = self.entropy_model(y, q)

@@ -25,13 +25,25 @@ from .blocks import MinkowskiGDN
 
 
 def batch_segments(cset):
-    """Row ranges per batch index of a canonical set: ([begin_0, ..., end], batch ids)."""
-    bmax = cset.bounds.bmax
-    if bmax == 0:
-        return [0, cset.n], [0]
-    q = torch.arange(0, bmax + 2, device=cset.device, dtype=torch.int64) << 48
-    pos = torch.searchsorted(cset.keys[:cset.n], q).tolist()
-    return pos, list(range(bmax + 1))
+    """Row ranges per batch index of a canonical set: ([begin_0, ..., end], batch ids).  Cached on the set."""
+    return batch_segments_many([cset])[0]
+
+
+def batch_segments_many(csets):
+    """`batch_segments` of several sets with ONE device->host read for all of them (the analysis transform knows its three
+    sets before its first feature kernel)."""
+    todo = [cs for cs in csets if cs.bounds.bmax > 0 and "segments" not in cs._derived]
+    if todo:
+        pos = [torch.searchsorted(cs.keys[:cs.n], torch.arange(0, cs.bounds.bmax + 2, device=cs.device, dtype=torch.int64) << 48)
+               for cs in todo]
+        flat = (torch.cat(pos) if len(pos) > 1 else pos[0]).tolist()
+        at = 0
+        for cs in todo:
+            m = cs.bounds.bmax + 2
+            cs._derived["segments"] = flat[at:at + m]
+            at += m
+    return [([0, cs.n], [0]) if cs.bounds.bmax == 0 else (cs._derived["segments"], list(range(cs.bounds.bmax + 1)))
+            for cs in csets]
 
 
 def count_per_batch(x):
@@ -60,11 +72,12 @@ class AnalysisTransform(nn.Module):
 
     count_per_batch = staticmethod(count_per_batch)
 
-    def plan(self, cs):
-        """Coordinate-only pre-pass (inference): every output set, kernel map and pair list of the transform depends on the
+    def plan(self, cs, backward=False):
+        """Coordinate-only pre-pass: every output set, kernel map and pair list of the transform depends on the
         input COORDINATES alone, so they are all queued before the first feature kernel and the sizes the host needs (pair
         counts of the three 5x5x5 128-channel layers) come back in ONE read instead of one per layer."""
         pend = []
+        first = True
         for seq in (self.down_conv_1, self.down_conv_2, self.down_conv_3):
             for m in seq:
                 if isinstance(m, ME.MinkowskiConvolution):
@@ -73,13 +86,22 @@ class AnalysisTransform(nn.Module):
                         kmap = cs.kernel_map(out, m.kernel_size)
                         if S.wants_pairs(m.kernel_volume, m.in_channels, m.out_channels):
                             pend.append(kmap.pair_plan_begin())
+                        # training: the data gradient of a strided layer runs the forward kernel over the INVERSE map
+                        # (`autograd.SparseConvFn.backward`); its pair plan is queued here so that its size comes back with
+                        # the forward plans' instead of stopping the backward pass for a read of its own
+                        if (backward and not first and m.stride != 1 and m.kernel_size % 2 == 1
+                                and S.wants_pairs(m.kernel_volume, m.out_channels, m.in_channels)):
+                            pend.append(out.kernel_map(cs, m.kernel_size, step=cs.ts).pair_plan_begin())
                     cs = out
+                    first = False
         S.resolve(*pend)
 
     def forward(self, x):
         """x -> (y, k) with k = rows per batch at strides [4, 2, 1] (`model/transforms.py:68-97`)."""
-        if not torch.is_grad_enabled():
-            self.plan(x._cset)
+        self.plan(x._cset, backward=torch.is_grad_enabled())
+        if x._cset.bounds.bmax > 0:                  # batched input (training): the three sets' row ranges in one read
+            c1 = x._cset.stride(x._cset.ts * 2)
+            batch_segments_many([x._cset, c1, c1.stride(c1.ts * 2)])
         k = [count_per_batch(x)]
         x = self.down_conv_1(x)
         k.append(count_per_batch(x))
@@ -168,7 +190,8 @@ class SparseSynthesisTransform(nn.Module):
             # torch count the mask on the host in the forward AND in the backward pass (two device->host waits per level)
             idx, _, n = S.prune(torch.arange(cs.n, dtype=torch.int64, device=f.device), cs.n, None, mask, n_keep)
             keys = cs.keys.index_select(0, idx)
-            return SparseTensor._from_canonical(S.CoordSet(keys, n, cs.ts, cs.bounds), f.index_select(0, idx))
+            from ..autograd import RowSelectFn
+            return SparseTensor._from_canonical(S.CoordSet(keys, n, cs.ts, cs.bounds), RowSelectFn.apply(f, idx))
         keys, feats, n = S.prune(cs.keys, cs.n, f, mask, n_keep)
         return SparseTensor._from_canonical(S.CoordSet(keys, n, cs.ts, cs.bounds), feats)
 

@@ -439,6 +439,15 @@ int pcc_eb_encode(const float* z, int64_t n, int32_t c, const float* eb_packed, 
  *   lik = max(|sigmoid(sg up) - sigmoid(sg lo)|, 1e-9),  lo / up = logits(v -+ .5),  sg = -sign(lo + up) (no gradient)
  * backward: dv [n, c] (nullable) and d_packed [c, 58], the gradient of the packed parameters (eb_packed layout: softplus /
  * tanh already applied -- the caller differentiates those reparametrisations), rows summed in a fixed order. */
+/* Quantisation-offset network of the training forward (reference model/entropy_models.py:210-233 `quant_nn`, call sites
+ * :318-322): a 2 -> 10 -> 10 -> 1 perceptron with ReLUs per element on (scale, stddev), one kernel per direction.
+ * params [pcc_quant_mlp_params() = 151]: W1 [10][2] | b1 [10] | W2 [10][10] | b2 [10] | W3 [10] | b3 (torch.nn.Linear layouts).
+ * bwd: d_scale / d_stddev nullable; d_params [151] summed in a fixed order (deterministic). */
+int32_t pcc_quant_mlp_params(void);
+size_t pcc_quant_mlp_ws_bytes(int64_t n);
+int pcc_quant_mlp_fwd(const float* scale, const float* stddev, int64_t n, const float* params, float* out, void* stream);
+int pcc_quant_mlp_bwd(const float* scale, const float* stddev, const float* grad_out, int64_t n, const float* params,
+                      float* d_scale, float* d_stddev, float* d_params, void* ws, size_t ws_bytes, void* stream);
 int pcc_eb_lik_fwd(const float* v, int64_t n, int32_t c, const float* eb_packed, float* lik, void* stream);
 int pcc_eb_lik_bwd(const float* v, const float* grad_lik, int64_t n, int32_t c, const float* eb_packed, float* dv,
                    float* d_packed, void* stream);
@@ -457,13 +466,15 @@ int pcc_conv_wgrad(const float* feat_in, int64_t n_in, int32_t cin, const float*
                    void* ws, size_t ws_bytes, void* stream);
 int pcc_convt_scatter_rows(const float* grad_out, const int32_t* first, const int32_t* pair_ids, int64_t n_out,
                            int32_t cout, float* dT /*[n_in*K, cout]*/, void* stream);
-/* One-logit convolution over a set mapped onto itself (reference model/transforms.py:146-161, predict_*[2]; odd K <= 27,
- * cin in {16,32,64}, cout = 1, stride 1): dW[k][ci] = sum_i feat[i][ci] * grad_out[nbr_{K-1-k}(i)] -- input-stationary, the feature
- * rows are streamed once.  hdr/nbr: the map of the set onto ITSELF (the caller guarantees in_set == out_set). */
+/* Convolution over a set mapped onto ITSELF with 1 or 16 output channels (reference model/transforms.py:146-161, predict_*[0] /
+ * predict_*[2]; odd K <= 27, stride 1; cout 1 with cin in {16,32,64}, cout 16 with cin in {16,32}): dW[k][ci][co] = sum_i feat[i][ci] * grad_out[nbr_{K-1-k}(i)][co] --
+ * input-stationary, the feature rows are streamed once, only the thin gradient rows are gathered.  hdr/nbr: the map of the set
+ * onto ITSELF (the caller guarantees in_set == out_set). */
 int pcc_conv_wgrad_self_supported(int32_t K, int32_t cin, int32_t cout);
-size_t pcc_conv_wgrad_self_ws_bytes(int64_t n, int32_t K, int32_t cin);
-int pcc_conv_wgrad_self(const float* feat, int64_t n, int32_t cin, const float* grad_out /*[n]*/, int32_t K, const int32_t* hdr,
-                        const int32_t* nbr, float* dW /*[K,cin]*/, void* ws, size_t ws_bytes, void* stream);
+size_t pcc_conv_wgrad_self_ws_bytes(int64_t n, int32_t K, int32_t cin, int32_t cout);
+int pcc_conv_wgrad_self(const float* feat, int64_t n, int32_t cin, const float* grad_out /*[n,cout]*/, int32_t cout, int32_t K,
+                        const int32_t* hdr, const int32_t* nbr, float* dW /*[K,cin,cout]*/, void* ws, size_t ws_bytes,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 8f-1  rANS entropy coder + CDF tables  (CompressAI `_CXX`: `pmf_to_quantized_cdf`, `BufferedRansEncoder`,

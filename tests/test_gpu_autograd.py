@@ -76,8 +76,8 @@ def test_conv_gradients(cin, cout, ks, stride, act):
     _check(mod, x, run, pairs, len(out_keys), act, W, b, f)
 
 
-@pytest.mark.parametrize("cin", [16, 32, 64])
-def test_one_logit_self_map_weight_gradient_equals_the_pair_list_form(cin):
+@pytest.mark.parametrize("cin,cout", [(16, 1), (32, 1), (64, 1), (32, 16), (16, 16)])
+def test_self_map_weight_gradient_equals_the_pair_list_form(cin, cout):
     """`pcc_conv_wgrad_self` (input-stationary, inverse offsets of the set's own map) against `pcc_conv_wgrad` on the same map
     and against the float64 sum over the oracle's pairs; a set large enough for several workgroup chunks and ragged tails."""
     from unified_point_cloud_compression_amd import lib as L
@@ -85,20 +85,21 @@ def test_one_logit_self_map_weight_gradient_equals_the_pair_list_form(cin):
     keys = cloud_keys(cin, 40, 0.12, 1, batch=3)
     rng = np.random.default_rng(cin)
     f = rng.standard_normal((len(keys), cin)).astype(np.float32)
-    g = rng.standard_normal((len(keys), 1)).astype(np.float32)
+    g = rng.standard_normal((len(keys), cout)).astype(np.float32)
     import unified_point_cloud_compression_amd.MinkowskiEngine as ME
     cs = ME.SparseTensor(coordinates=t(co.unpack_keys(keys)), features=t(f))._cset      # rows in key order (keys are canonical)
     kmap = cs.kernel_map(cs, 3)
-    assert L.load().pcc_conv_wgrad_self_supported(27, cin, 1)
-    a = n(S.conv_wgrad_self(t(f), t(g), 27, cin, kmap))
-    b = n(S.conv_wgrad(t(f), t(g), 27, cin, 1, kmap))
-    ref = np.zeros((27, cin, 1))
+    assert L.load().pcc_conv_wgrad_self_supported(27, cin, cout)
+    a = n(S.conv_wgrad_self(t(f), t(g), 27, cin, kmap, cout))
+    b = n(S.conv_wgrad(t(f), t(g), 27, cin, cout, kmap))
+    ref = np.zeros((27, cin, cout))
     for k, (i, o) in enumerate(codec.kernel_map_pairs(keys, keys, 3, 1)):
         if len(i):
-            ref[k, :, 0] = f[i].astype(np.float64).T @ g[o, 0].astype(np.float64)
+            ref[k] = f[i].astype(np.float64).T @ g[o].astype(np.float64)
     assert_close(a, b, atol=2e-4, rtol=2e-4, what="self form vs pair-list form")
     assert_close(a, ref.astype(np.float32), atol=2e-4, rtol=2e-4, what="self form vs float64 pairs")
     assert not L.load().pcc_conv_wgrad_self_supported(27, cin, 2) and not L.load().pcc_conv_wgrad_self_supported(8, cin, 1)
+    assert not L.load().pcc_conv_wgrad_self_supported(27, 64, 16)
 
 
 @pytest.mark.parametrize("cin,cout,ks", [(16, 16, 5), (128, 32, 5), (32, 32, 2), (192, 192, 2)])
@@ -182,3 +183,39 @@ def test_factorised_prior_likelihood_kernels_match_the_torch_chain():
     for nme, gt in res["torch"][2].items():
         gk = res["kernel"][2][nme]
         assert_close(n(gk), n(gt), atol=1e-5 * max(1.0, float(gt.abs().max())), rtol=2e-4, what=f"gradient of {nme}")
+
+
+def test_quant_offset_network_kernels_match_the_torch_layers():
+    """`pcc_quant_mlp_fwd/bwd` (`quant_nn`, reference `model/entropy_models.py:210-233`) against the same network as torch layers:
+    outputs, input gradients and all six parameter gradients (sums over 300 k elements: relative tolerance)."""
+    from unified_point_cloud_compression_amd.autograd import QuantMlpFn
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(2, 10), torch.nn.ReLU(), torch.nn.Linear(10, 10), torch.nn.ReLU(),
+                              torch.nn.Linear(10, 1)).to(dev())
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    rng = np.random.default_rng(5)
+    s0 = rng.uniform(0.2, 3.0, (2345, 128)).astype(np.float32)
+    d0 = rng.uniform(0.1, 9.0, (2345, 128)).astype(np.float32)
+    go = rng.standard_normal((2345, 128)).astype(np.float32)
+    s1, d1 = t(s0).requires_grad_(True), t(d0).requires_grad_(True)
+    ref = net(torch.stack([s1, d1], dim=-1)).squeeze(-1)
+    ref.backward(t(go))
+    ref_grads = [p.grad.clone() for p in net.parameters()]
+    ref_ds, ref_dd = s1.grad.clone(), d1.grad.clone()
+    for p in net.parameters():
+        p.grad = None
+    s2, d2 = t(s0).requires_grad_(True), t(d0).requires_grad_(True)
+    out = QuantMlpFn.apply(s2, d2, net[0].weight, net[0].bias, net[2].weight, net[2].bias, net[4].weight, net[4].bias)
+    assert_close(n(out), n(ref.detach()), atol=1e-5, rtol=1e-5, what="offsets")
+    out.backward(t(go))
+    assert_close(n(s2.grad), n(ref_ds), atol=1e-5, rtol=1e-5, what="d scale")
+    assert_close(n(d2.grad), n(ref_dd), atol=1e-5, rtol=1e-5, what="d stddev")
+    for p, r in zip(net.parameters(), ref_grads):
+        scale = float(r.abs().max()) + 1e-6
+        assert_close(n(p.grad) / scale, n(r) / scale, atol=2e-5, rtol=0, what="parameter gradient")
+    # no gradient for the (detached) gain, as the training forward calls it
+    d3 = t(d0).requires_grad_(True)
+    QuantMlpFn.apply(t(s0), d3, net[0].weight, net[0].bias, net[2].weight, net[2].bias, net[4].weight, net[4].bias).sum().backward()
+    assert d3.grad is not None

@@ -100,7 +100,7 @@ class SparseConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 if (WGRAD_SELF and in_set is out_set and kmap is not None and kmap.rows is None and module.stride == 1
                         and g.shape[0] == feats.shape[0] and L.load().pcc_conv_wgrad_self_supported(K, cin, cout)):
-                    g_kernel = S.conv_wgrad_self(feats, g, K, cin, kmap)
+                    g_kernel = S.conv_wgrad_self(feats, g, K, cin, kmap, cout)
                 else:
                     g_kernel = S.conv_wgrad(feats, g, K, cin, cout, kmap)
             if ctx.needs_input_grad[0]:
@@ -203,6 +203,41 @@ class GaussLikFn(torch.autograd.Function):
         L.call("pcc_gauss_lik_bwd", L.ptr(v), L.ptr(scale), L.ptr(mean), L.ptr(g), v.numel(), L.ptr(dv), L.ptr(ds), L.ptr(dm),
                L.stream())
         return dv, ds, dm
+
+
+class QuantMlpFn(torch.autograd.Function):
+    """`quant_nn` (2 -> 10 -> 10 -> 1, ReLU) on per-element (scale, stddev) pairs as one kernel per direction
+    (`pcc_quant_mlp_fwd/bwd`; reference `model/entropy_models.py:210-233`).  Parameters in torch.nn.Linear layouts."""
+
+    @staticmethod
+    def forward(ctx, scale, stddev, w1, b1, w2, b2, w3, b3):
+        scale, stddev = scale.contiguous(), stddev.contiguous()
+        params = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in (w1, b1, w2, b2, w3, b3)]).contiguous()
+        out = torch.empty_like(stddev)
+        L.call("pcc_quant_mlp_fwd", L.ptr(scale), L.ptr(stddev), stddev.numel(), L.ptr(params), L.ptr(out), L.stream())
+        ctx.save_for_backward(scale, stddev, params)
+        ctx.shapes = [t.shape for t in (w1, b1, w2, b2, w3, b3)]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, stddev, params = ctx.saved_tensors
+        g = g.contiguous()
+        n = stddev.numel()
+        ds = torch.empty_like(scale) if ctx.needs_input_grad[0] else None
+        dd = torch.empty_like(stddev) if ctx.needs_input_grad[1] else None
+        dp = torch.empty_like(params)
+        ws = L.workspace(L.load().pcc_quant_mlp_ws_bytes(n), g.device)
+        L.call("pcc_quant_mlp_bwd", L.ptr(scale), L.ptr(stddev), L.ptr(g), n, L.ptr(params), L.ptr(ds), L.ptr(dd), L.ptr(dp),
+               L.ptr(ws), ws.numel(), L.stream())
+        grads, at = [], 0
+        for shp in ctx.shapes:
+            k = 1
+            for d in shp:
+                k *= d
+            grads.append(dp[at:at + k].view(shp))
+            at += k
+        return (ds, dd, *grads)
 
 
 class EbLikFn(torch.autograd.Function):

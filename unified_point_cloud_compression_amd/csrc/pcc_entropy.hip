@@ -338,3 +338,147 @@ extern "C" int pcc_gauss_lik_bwd(const float* v, const float* scale, const float
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Quantisation-offset network of the training forward (`quant_nn`, reference `model/entropy_models.py:210-233`, call sites
+// `:318-322`): per ELEMENT of the latent a 2 -> 10 -> 10 -> 1 perceptron on (gain, standard deviation).  As torch layers it is
+// three GEMMs with 1.6 M rows and 2 / 10 / 10 columns per direction plus the ReLUs; their weight gradients reduce over all
+// elements into 10 x 10 outputs, which hipBLASLt runs on ONE 16 x 16 tile (0.54 ms of the training step), and the chain is
+// ~25 launches.  Here: one element-wise kernel per direction, the 151 parameters in registers / scalar loads, hidden layers
+// recomputed in the backward pass, parameter gradients summed per thread, per wave (xor butterfly), per workgroup and then
+// over the workgroups in index order: deterministic.
+//   params: W1 [10][2] | b1 [10] | W2 [10][10] | b2 [10] | W3 [10] | b3      (torch.nn.Linear layouts, row = output)
+// ------------------------------------------------------------------------------------------
+static constexpr int QM_H = 10;
+static constexpr int QM_W1 = 0, QM_B1 = 20, QM_W2 = 30, QM_B2 = 130, QM_W3 = 140, QM_B3 = 150, QM_PARAMS = 151;
+static constexpr int QM_BLOCKS = 1024;
+
+__device__ __forceinline__ float qm_forward(const float* __restrict__ p, float s, float d, float (&h1)[QM_H], float (&h2)[QM_H]) {
+#pragma unroll
+  for (int j = 0; j < QM_H; ++j) h1[j] = fmaxf(fmaf(p[QM_W1 + 2 * j], s, fmaf(p[QM_W1 + 2 * j + 1], d, p[QM_B1 + j])), 0.f);
+#pragma unroll
+  for (int j = 0; j < QM_H; ++j) {
+    float t = p[QM_B2 + j];
+#pragma unroll
+    for (int i = 0; i < QM_H; ++i) t = fmaf(p[QM_W2 + QM_H * j + i], h1[i], t);
+    h2[j] = fmaxf(t, 0.f);
+  }
+  float o = p[QM_B3];
+#pragma unroll
+  for (int j = 0; j < QM_H; ++j) o = fmaf(p[QM_W3 + j], h2[j], o);
+  return o;
+}
+
+__global__ void __launch_bounds__(256) k_quant_mlp_fwd(const float* __restrict__ scale, const float* __restrict__ stddev,
+                                                       long long n, const float* __restrict__ params, float* __restrict__ out) {
+  __shared__ float p[QM_PARAMS];
+  if (threadIdx.x < QM_PARAMS) p[threadIdx.x] = params[threadIdx.x];
+  __syncthreads();
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float h1[QM_H], h2[QM_H];
+  out[t] = qm_forward(p, scale[t], stddev[t], h1, h2);
+}
+
+__global__ void __launch_bounds__(256) k_quant_mlp_bwd(const float* __restrict__ scale, const float* __restrict__ stddev,
+                                                       const float* __restrict__ go, long long n, const float* __restrict__ params,
+                                                       float* __restrict__ d_scale, float* __restrict__ d_stddev,
+                                                       float* __restrict__ partial /*[gridDim.x][151]*/) {
+  __shared__ float p[QM_PARAMS];
+  __shared__ float red[4][QM_PARAMS];
+  if (threadIdx.x < QM_PARAMS) p[threadIdx.x] = params[threadIdx.x];
+  __syncthreads();
+  float acc[QM_PARAMS];
+#pragma unroll
+  for (int i = 0; i < QM_PARAMS; ++i) acc[i] = 0.f;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+    const float s = scale[t], d = stddev[t], g = go[t];
+    float h1[QM_H], h2[QM_H];
+    qm_forward(p, s, d, h1, h2);
+    acc[QM_B3] += g;
+    float dh2[QM_H], dh1[QM_H];
+#pragma unroll
+    for (int j = 0; j < QM_H; ++j) {
+      acc[QM_W3 + j] = fmaf(g, h2[j], acc[QM_W3 + j]);
+      dh2[j] = h2[j] > 0.f ? g * p[QM_W3 + j] : 0.f;
+      acc[QM_B2 + j] += dh2[j];
+    }
+#pragma unroll
+    for (int i = 0; i < QM_H; ++i) dh1[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < QM_H; ++j)
+#pragma unroll
+      for (int i = 0; i < QM_H; ++i) {
+        acc[QM_W2 + QM_H * j + i] = fmaf(dh2[j], h1[i], acc[QM_W2 + QM_H * j + i]);
+        dh1[i] = fmaf(p[QM_W2 + QM_H * j + i], dh2[j], dh1[i]);
+      }
+    float ds = 0.f, dd = 0.f;
+#pragma unroll
+    for (int i = 0; i < QM_H; ++i) {
+      const float e = h1[i] > 0.f ? dh1[i] : 0.f;
+      acc[QM_B1 + i] += e;
+      acc[QM_W1 + 2 * i] = fmaf(e, s, acc[QM_W1 + 2 * i]);
+      acc[QM_W1 + 2 * i + 1] = fmaf(e, d, acc[QM_W1 + 2 * i + 1]);
+      ds = fmaf(p[QM_W1 + 2 * i], e, ds);
+      dd = fmaf(p[QM_W1 + 2 * i + 1], e, dd);
+    }
+    if (d_scale) d_scale[t] = ds;
+    if (d_stddev) d_stddev[t] = dd;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < QM_PARAMS; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) red[w][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < QM_PARAMS)
+    partial[(long long)blockIdx.x * QM_PARAMS + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// d_params[i] = sum over the workgroups' partial sums, in workgroup order (one workgroup; 151 x <= 1024 values)
+__global__ void __launch_bounds__(256) k_quant_mlp_sum(const float* __restrict__ partial, int nblocks, float* __restrict__ d_params) {
+  if (threadIdx.x >= QM_PARAMS) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * QM_PARAMS + threadIdx.x];
+  d_params[threadIdx.x] = s;
+}
+
+static int qm_blocks(int64_t n) {
+  int64_t b = pcc_cdiv(n, 1024);                 // >= 4 elements per thread
+  return (int)(b < 1 ? 1 : (b > QM_BLOCKS ? QM_BLOCKS : b));
+}
+
+extern "C" int32_t pcc_quant_mlp_params(void) { return QM_PARAMS; }
+extern "C" size_t pcc_quant_mlp_ws_bytes(int64_t n) { return (size_t)qm_blocks(n) * QM_PARAMS * sizeof(float) + 256; }
+
+extern "C" int pcc_quant_mlp_fwd(const float* scale, const float* stddev, int64_t n, const float* params, float* out, void* stream) {
+  PCC_REQUIRE(params && n >= 0 && (n == 0 || (scale && stddev && out)), "pcc_quant_mlp_fwd: bad arguments");
+  if (n == 0) return PCC_OK;
+  k_quant_mlp_fwd<<<(unsigned)pcc_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(scale, stddev, n, params, out);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_quant_mlp_bwd(const float* scale, const float* stddev, const float* grad_out, int64_t n, const float* params,
+                                 float* d_scale, float* d_stddev, float* d_params, void* ws, size_t ws_bytes, void* stream) {
+  PCC_REQUIRE(params && d_params && n >= 0 && (n == 0 || (scale && stddev && grad_out && ws)), "pcc_quant_mlp_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    PCC_CHECK_HIP(hipMemsetAsync(d_params, 0, QM_PARAMS * sizeof(float), s));
+    return PCC_OK;
+  }
+  if (ws_bytes < pcc_quant_mlp_ws_bytes(n)) {
+    pcc_set_error("pcc_quant_mlp_bwd: workspace too small");
+    return PCC_EWS;
+  }
+  const int nb = qm_blocks(n);
+  k_quant_mlp_bwd<<<(unsigned)nb, 256, 0, s>>>(scale, stddev, grad_out, n, params, d_scale, d_stddev, (float*)ws);
+  PCC_LAUNCH_CHECK();
+  k_quant_mlp_sum<<<1, 256, 0, s>>>((const float*)ws, nb, d_params);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}

@@ -683,6 +683,129 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce_wide(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same input-stationary form for a 16-column gradient (the heads' FIRST convolution over the largest candidate set,
+// 32 -> 16 on ~1 M rows: 0.94 ms per training step through the pair-list kernel, which gathers BOTH rows of its 13 M pairs):
+//     dW[k][ci][co] = sum_i x[i][ci] * g[nbr_{K-1-k}(i)][co]
+// on v_mfma_f32_16x16x4_f32 with both operands straight from global memory: A[ci][row] = one float of a feature row per lane
+// (rows streamed in order), B[row][co] = one float of the 64-byte gradient row of the row's inverse neighbour.  A wave owns the
+// offsets w, w + 4, ... (<= 7) of a 64-row group: their inverse-neighbour indices are read row-per-lane (one coalesced load
+// per offset) and handed to the (row, column) lanes of each 4-row MFMA step by a cross-lane read.  No LDS, no barrier.
+// ------------------------------------------------------------------------------------------
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+static constexpr int WS16_KPW = 7;                  // offsets per wave
+static constexpr int WS16_MAX_BLOCKS = 1024;
+
+template <int CIN>
+__global__ void __launch_bounds__(256, 2) k_wgrad_self16(WgradThinArgs a) {
+  constexpr int NB = CIN / 16;
+  __shared__ __attribute__((aligned(16))) int4 s_seg[WT_KMAX + 1];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid <= WT_KMAX) {
+    long long base = 0; int pb = 0, pc = 0;
+    const int kk = a.K - 1 - tid;
+    if (tid < a.K) {
+      const int nseg = a.hdr[HDR_NSEG];
+      bool found = false;
+      for (int s = 0; s < nseg && !found; ++s) {
+        const int* sg = a.hdr + HDR_SEG0 + s * SEG_WORDS;
+        for (int j = 0; j < sg[SEG_K_COUNT]; ++j)
+          if (a.hdr[HDR_KOFFS + sg[SEG_KOFF_BEGIN] + j] == kk) {
+            pb = sg[SEG_POS_BEGIN]; pc = sg[SEG_POS_COUNT];
+            base = (((long long)(unsigned)sg[SEG_NBR_LO]) | ((long long)sg[SEG_NBR_HI] << 32)) + (long long)j * pc - pb;
+            found = true;
+            break;
+          }
+      }
+    }
+    s_seg[tid] = make_int4((int)(unsigned)(base & 0xFFFFFFFFll), (int)(base >> 32), pb, pc);
+  }
+  __syncthreads();
+  long long per = (a.n + a.nblocks - 1) / a.nblocks;
+  per = (per + 63) / 64 * 64;
+  const long long lo = (long long)blockIdx.x * per;
+  const long long hi = min(a.n, lo + per);
+  const int c16 = lane & 15, rq = lane >> 4;
+  // this wave's offsets and their segment records (wave-uniform: scalar registers)
+  long long sbase[WS16_KPW];
+  int spb[WS16_KPW], spc[WS16_KPW];
+#pragma unroll
+  for (int u = 0; u < WS16_KPW; ++u) {
+    const int k = w + 4 * u;
+    const int4 sg = s_seg[k < a.K ? k : WT_KMAX];      // (record WT_KMAX: empty range)
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane(sg.x), bhi = (unsigned)__builtin_amdgcn_readfirstlane(sg.y);
+    sbase[u] = ((long long)blo) | ((long long)(int)bhi << 32);
+    spb[u] = __builtin_amdgcn_readfirstlane(sg.z);
+    spc[u] = k < a.K ? __builtin_amdgcn_readfirstlane(sg.w) : 0;
+  }
+  wg_f32x4 acc[WS16_KPW][NB];
+#pragma unroll
+  for (int u = 0; u < WS16_KPW; ++u)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[u][b] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int DEPTH = 4;                              // 4-row MFMA steps whose gradient rows are in flight
+  for (long long r0 = lo; r0 < hi; r0 += 64) {
+    const long long i = r0 + lane;                      // row-per-lane: the inverse neighbours of this wave's offsets
+    int jv[WS16_KPW];
+#pragma unroll
+    for (int u = 0; u < WS16_KPW; ++u) {
+      const unsigned q = (unsigned)(i - spb[u]);
+      const bool ok = i < hi && q < (unsigned)spc[u];
+      const int v = a.nbr[ok ? sbase[u] + i : 0];
+      jv[u] = ok ? v : -1;
+    }
+    // the 16 x NB feature operands of the group: all loads issued up front (rows beyond the chunk read row `lo`, zeroed at use)
+    float araw[16][NB];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const long long row = r0 + 4 * s + rq;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) araw[s][b] = a.x[(row < hi ? row : lo) * CIN + 16 * b + c16];
+    }
+    // gradient rows: a ring of DEPTH steps in flight (raw values + a presence mask; the zero of an absent pair is selected at
+    // use, so nothing waits on a load before its step is multiplied -- the first version waited per step: 1.09 ms, slower than
+    // the pair-list kernel it replaces)
+    float graw[DEPTH][WS16_KPW];
+    unsigned gmask[DEPTH];
+    auto issue = [&](int s, float (&gr)[WS16_KPW], unsigned& m) {
+      m = 0;
+#pragma unroll
+      for (int u = 0; u < WS16_KPW; ++u) {
+        const int j = __shfl(jv[u], 4 * s + rq, 64);
+        gr[u] = a.g[(long long)(j >= 0 ? j : 0) * 16 + c16];
+        m |= (j >= 0 ? 1u : 0u) << u;
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) issue(s, graw[s], gmask[s]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const bool rok = r0 + 4 * s + rq < hi;
+      float av[NB], gv[WS16_KPW];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) av[b] = rok ? araw[s][b] : 0.f;
+#pragma unroll
+      for (int u = 0; u < WS16_KPW; ++u) gv[u] = ((gmask[s % DEPTH] >> u) & 1u) ? graw[s % DEPTH][u] : 0.f;
+      if (s + DEPTH < 16) issue(s + DEPTH, graw[s % DEPTH], gmask[s % DEPTH]);
+#pragma unroll
+      for (int u = 0; u < WS16_KPW; ++u)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b], gv[u], acc[u][b], 0, 0, 0);
+    }
+  }
+  // D layout: column (co) = lane & 15, row (ci) = 4 * (lane >> 4) + e
+  float* dst = a.partial + (long long)blockIdx.x * a.K * CIN * 16;
+#pragma unroll
+  for (int u = 0; u < WS16_KPW; ++u) {
+    const int k = w + 4 * u;
+    if (k >= a.K) continue;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[((long long)k * CIN + 16 * b + 4 * rq + e) * 16 + c16] = acc[u][b][e];
+  }
+}
+
 static bool wgrad_thin_ok(int K, int cin) { return K >= 1 && K <= WT_KMAX && (K & 1) && (cin == 16 || cin == 32 || cin == 64); }
 static int wgrad_thin_blocks(int64_t n, int cin) {
   int64_t b = pcc_cdiv(n, 512);                  // at least two 256-row rounds per workgroup
@@ -690,34 +813,50 @@ static int wgrad_thin_blocks(int64_t n, int cin) {
   if (b > WT_MAX_BLOCKS) b = WT_MAX_BLOCKS;
   return (int)b;
 }
-
-extern "C" int pcc_conv_wgrad_self_supported(int32_t K, int32_t cin, int32_t cout) { return cout == 1 && wgrad_thin_ok(K, cin); }
-
-extern "C" size_t pcc_conv_wgrad_self_ws_bytes(int64_t n, int32_t K, int32_t cin) {
-  return (size_t)wgrad_thin_blocks(n, cin) * (size_t)K * cin * sizeof(float) + 256;
+static int wgrad_self16_blocks(int64_t n) {
+  int64_t b = pcc_cdiv(n, 512);
+  if (b < 1) b = 1;
+  if (b > WS16_MAX_BLOCKS) b = WS16_MAX_BLOCKS;
+  return (int)b;
 }
 
-extern "C" int pcc_conv_wgrad_self(const float* feat, int64_t n, int32_t cin, const float* grad_out, int32_t K,
+extern "C" int pcc_conv_wgrad_self_supported(int32_t K, int32_t cin, int32_t cout) {
+  return wgrad_thin_ok(K, cin) && (cout == 1 || (cout == 16 && cin <= 32));
+}
+
+extern "C" size_t pcc_conv_wgrad_self_ws_bytes(int64_t n, int32_t K, int32_t cin, int32_t cout) {
+  const size_t blocks = cout == 1 ? (size_t)wgrad_thin_blocks(n, cin) : (size_t)wgrad_self16_blocks(n);
+  return blocks * (size_t)K * cin * (size_t)cout * sizeof(float) + 256;
+}
+
+extern "C" int pcc_conv_wgrad_self(const float* feat, int64_t n, int32_t cin, const float* grad_out, int32_t cout, int32_t K,
                                    const int32_t* hdr, const int32_t* nbr, float* dW, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  PCC_REQUIRE(dW && wgrad_thin_ok(K, cin), "pcc_conv_wgrad_self: odd K <= 27 and cin in {16, 32, 64} (see pcc_conv_wgrad_self_supported)");
-  const long long elems = (long long)K * cin;
+  PCC_REQUIRE(dW && pcc_conv_wgrad_self_supported(K, cin, cout),
+              "pcc_conv_wgrad_self: odd K <= 27; cout 1 with cin in {16, 32, 64} or cout 16 with cin in {16, 32} (pcc_conv_wgrad_self_supported)");
+  const long long elems = (long long)K * cin * cout;
   if (n <= 0) {
     PCC_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)elems * sizeof(float), s));
     return PCC_OK;
   }
   PCC_REQUIRE(feat && grad_out && hdr && nbr && ws, "pcc_conv_wgrad_self: NULL array");
   PCC_REQUIRE(n < (1ll << 31), "pcc_conv_wgrad_self: too many rows");
-  if (ws_bytes < pcc_conv_wgrad_self_ws_bytes(n, K, cin)) {
+  if (ws_bytes < pcc_conv_wgrad_self_ws_bytes(n, K, cin, cout)) {
     pcc_set_error("pcc_conv_wgrad_self: workspace too small");
     return PCC_EWS;
   }
   WgradThinArgs a;
   a.x = feat; a.g = grad_out; a.hdr = hdr; a.nbr = nbr; a.partial = (float*)ws; a.n = n; a.cin = cin; a.K = K;
-  a.nblocks = wgrad_thin_blocks(n, cin);
-  if (cin == 16) k_wgrad_thin<4><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
-  else if (cin == 32) k_wgrad_thin<8><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
-  else k_wgrad_thin<16><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
+  if (cout == 1) {
+    a.nblocks = wgrad_thin_blocks(n, cin);
+    if (cin == 16) k_wgrad_thin<4><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
+    else if (cin == 32) k_wgrad_thin<8><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
+    else k_wgrad_thin<16><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
+  } else {
+    a.nblocks = wgrad_self16_blocks(n);
+    if (cin == 16) k_wgrad_self16<16><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
+    else k_wgrad_self16<32><<<(unsigned)a.nblocks, 256, 0, s>>>(a);
+  }
   PCC_LAUNCH_CHECK();
   k_wgrad_reduce_wide<<<(unsigned)pcc_cdiv(elems, 16), 256, 0, s>>>(a.partial, elems, a.nblocks, dW);
   PCC_LAUNCH_CHECK();

@@ -84,8 +84,12 @@ SIGNATURES = {
     "pcc_conv_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "pcc_conv_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_conv_wgrad_self_supported": (C.c_int, [_i32, _i32, _i32]),
-    "pcc_conv_wgrad_self_ws_bytes": (_sz, [_i64, _i32, _i32]),
-    "pcc_conv_wgrad_self": (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _p, _sz, _p]),
+    "pcc_quant_mlp_params": (_i32, []),
+    "pcc_quant_mlp_ws_bytes": (_sz, [_i64]),
+    "pcc_quant_mlp_fwd": (C.c_int, [_p, _p, _i64, _p, _p, _p]),
+    "pcc_quant_mlp_bwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "pcc_conv_wgrad_self_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "pcc_conv_wgrad_self": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     "pcc_convt_scatter_rows": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "pcc_convt_fwd_csr_grid": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _i64, _p, _p, _i32, _f32, _p, _p, _p, C.POINTER(_i32), _p, _p, _i32, _p, _p]),
     "pcc_set_t_chunk_bytes": (C.c_int, [_i64]),

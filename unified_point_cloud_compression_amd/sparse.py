@@ -900,14 +900,14 @@ def conv_wgrad(feats_in, grad_out, K, cin, cout, kmap):
     return dW
 
 
-def conv_wgrad_self(feats, grad_out, K, cin, kmap):
-    """dW [K, cin, 1] of a one-logit odd-kernel convolution over a set mapped onto itself (`kmap` = that self map):
-    input-stationary, dW[k][ci] = sum_i feats[i][ci] * grad_out[nbr_{K-1-k}(i)]."""
+def conv_wgrad_self(feats, grad_out, K, cin, kmap, cout=1):
+    """dW [K, cin, cout] (cout 1 or 16) of an odd-kernel convolution over a set mapped onto itself (`kmap` = that self map):
+    input-stationary, dW[k][ci][co] = sum_i feats[i][ci] * grad_out[nbr_{K-1-k}(i)][co]."""
     feats, grad_out = feats.contiguous(), grad_out.contiguous()
     n = feats.shape[0]
-    dW = torch.empty((K, cin, 1), dtype=torch.float32, device=feats.device)
-    ws = L.workspace(L.load().pcc_conv_wgrad_self_ws_bytes(n, K, cin), feats.device)
-    L.call("pcc_conv_wgrad_self", L.ptr(feats), n, cin, L.ptr(grad_out), K, L.ptr(kmap.hdr), L.ptr(kmap.nbr), L.ptr(dW),
+    dW = torch.empty((K, cin, cout), dtype=torch.float32, device=feats.device)
+    ws = L.workspace(L.load().pcc_conv_wgrad_self_ws_bytes(n, K, cin, cout), feats.device)
+    L.call("pcc_conv_wgrad_self", L.ptr(feats), n, cin, L.ptr(grad_out), cout, K, L.ptr(kmap.hdr), L.ptr(kmap.nbr), L.ptr(dW),
            L.ptr(ws), ws.numel(), L.stream())
     return dW
 

@@ -16,25 +16,43 @@ struct SelState { unsigned prefix, mask; int remaining; int pad; };
 // histogram of the digit below the prefix found so far, then one workgroup picks the digit holding the `remaining`-th largest
 // candidate.  With 11 bits the first digit is sign + exponent + 2 mantissa bits, so occupancy logits no longer pile onto two or
 // three bins of the LDS histogram (same-address atomics of a wave serialise).
+// Round 4: ALL batch segments of a call go through the same launches (blockIdx.y = segment; a training batch of 4 cubes x 3
+// levels was 130 launches per step, ~11 per segment).  The arithmetic per segment is unchanged.
 static constexpr int SEL_MAXBINS = 2048;
-static constexpr int SEL_WS_HDR = 256 + SEL_MAXBINS * 4 + 256;      // state | histogram | pad
 static constexpr int SEL_B = 2048;                                    // rows per workgroup of the count / compact passes (256 x 8)
+static constexpr int SEL_MAXSEG = 48;                                 // segments per batch of launches (table passed by value)
+static constexpr int SEL_SEG_WS = 256 + SEL_MAXBINS * 4;              // per segment: state | histogram
 
-__global__ void k_sel_init(SelState* st, int* hist, int k) {
-  if (threadIdx.x == 0) { st->prefix = 0; st->mask = 0; st->remaining = k; st->pad = 0; }
+// mode: 0 = select the k largest, 1 = keep every row (k >= n), 2 = keep none (k <= 0)
+struct SelSeg { long long b0, out_base; int n, k, mode, blk0; };
+struct SelTable { int nseg, pad; SelSeg s[SEL_MAXSEG]; };
+
+__device__ inline SelState* sel_state(void* ws, int seg) { return (SelState*)((char*)ws + (size_t)seg * SEL_SEG_WS); }
+__device__ inline int* sel_hist(void* ws, int seg) { return (int*)((char*)ws + (size_t)seg * SEL_SEG_WS + 256); }
+
+__global__ void k_sel_init(void* ws, SelTable t) {
+  const int seg = blockIdx.y;
+  SelState* st = sel_state(ws, seg);
+  int* hist = sel_hist(ws, seg);
+  if (threadIdx.x == 0) { st->prefix = 0; st->mask = 0; st->remaining = t.s[seg].k; st->pad = 0; }
   for (int i = threadIdx.x; i < SEL_MAXBINS; i += blockDim.x) hist[i] = 0;
 }
 
 template <int BITS>
-__global__ void __launch_bounds__(256) k_sel_hist(const float* __restrict__ logits, long long stride, long long n,
-                                                  int shift, const SelState* __restrict__ st, int* __restrict__ hist) {
+__global__ void __launch_bounds__(256) k_sel_hist(const float* __restrict__ logits, long long stride, int shift, void* ws, SelTable t) {
   constexpr int NB = 1 << BITS;
   __shared__ int h[NB];
+  const int seg = blockIdx.y;
+  const SelSeg sg = t.s[seg];
+  if (sg.mode != 0 || (long long)blockIdx.x * 256 >= sg.n) return;
   for (int i = threadIdx.x; i < NB; i += 256) h[i] = 0;
   __syncthreads();
+  const SelState* st = sel_state(ws, seg);
+  int* hist = sel_hist(ws, seg);
   const unsigned prefix = st->prefix, mask = st->mask;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const unsigned u = f2u(logits[i * stride]);
+  const float* lg = logits + sg.b0 * stride;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < sg.n; i += (long long)gridDim.x * 256) {
+    const unsigned u = f2u(lg[i * stride]);
     if ((u & mask) == prefix) atomicAdd(&h[(u >> shift) & (NB - 1)], 1);
   }
   __syncthreads();
@@ -44,9 +62,13 @@ __global__ void __launch_bounds__(256) k_sel_hist(const float* __restrict__ logi
 
 // pick the digit holding the `remaining`-th largest candidate (bins walked from the top); clears hist for the next pass.
 // 256 threads: thread t owns the NB/256 bins below NB - t * per; an exclusive scan over the threads finds the owner.
-__global__ void __launch_bounds__(256) k_sel_pick(SelState* st, int* hist, int shift, int bits) {
+__global__ void __launch_bounds__(256) k_sel_pick(void* ws, int shift, int bits, SelTable t) {
   __shared__ int wsum[4];
   __shared__ int h[SEL_MAXBINS];
+  const int seg = blockIdx.y;
+  if (t.s[seg].mode != 0) return;
+  SelState* st = sel_state(ws, seg);
+  int* hist = sel_hist(ws, seg);
   const int nb = 1 << bits, per = nb >> 8;
   for (int i = threadIdx.x; i < nb; i += 256) { h[i] = hist[i]; hist[i] = 0; }
   __syncthreads();
@@ -56,7 +78,7 @@ __global__ void __launch_bounds__(256) k_sel_pick(SelState* st, int* hist, int s
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int inc = mine;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+  for (int d = 1; d < 64; d <<= 1) { const int tt = __shfl_up(inc, d); if (lane >= d) inc += tt; }
   if (lane == 63) wsum[w] = inc;
   __syncthreads();
   int before = inc - mine;
@@ -96,33 +118,40 @@ __device__ inline int sel_block_scan(int v, int* total, int* wsum) {
   return base + inc - v;
 }
 
-__global__ void __launch_bounds__(256) k_sel_count(const float* __restrict__ logits, long long stride, long long n,
-                                                   const SelState* __restrict__ st, int2* __restrict__ cnt) {
+__global__ void __launch_bounds__(256) k_sel_count(const float* __restrict__ logits, long long stride, void* ws, SelTable t,
+                                                   int2* __restrict__ cnt) {
   __shared__ int wsum[4];
-  const unsigned T = st->prefix;
+  const int seg = blockIdx.y;
+  const SelSeg sg = t.s[seg];
+  if (sg.mode != 0 || (long long)blockIdx.x * SEL_B >= sg.n) return;
+  const unsigned T = sel_state(ws, seg)->prefix;
+  const float* lg = logits + sg.b0 * stride;
   const long long base = (long long)blockIdx.x * SEL_B + (long long)threadIdx.x * 8;
   int gt = 0, eq = 0;
 #pragma unroll
   for (int q = 0; q < 8; ++q)
-    if (base + q < n) {
-      const unsigned u = f2u(logits[(base + q) * stride]);
+    if (base + q < sg.n) {
+      const unsigned u = f2u(lg[(base + q) * stride]);
       gt += u > T; eq += u == T;
     }
   int tg, te;
   sel_block_scan(gt, &tg, wsum);
   sel_block_scan(eq, &te, wsum);
-  if (threadIdx.x == 0) cnt[blockIdx.x] = make_int2(tg, te);
+  if (threadIdx.x == 0) cnt[sg.blk0 + blockIdx.x] = make_int2(tg, te);
 }
 
-// one workgroup: per counted workgroup b the equal values before it and the rows kept before it (exclusive scans, chunked)
-__global__ void __launch_bounds__(256) k_sel_offsets(const int2* __restrict__ cnt, int nblk, const SelState* __restrict__ st,
-                                                     int2* __restrict__ before) {
+// one workgroup per segment: per counted workgroup b the equal values before it and the rows kept before it (exclusive scans)
+__global__ void __launch_bounds__(256) k_sel_offsets(const int2* __restrict__ cnt, void* ws, SelTable t, int2* __restrict__ before) {
   __shared__ int wsum[4];
-  const int rem = st->remaining;
+  const int seg = blockIdx.y;
+  const SelSeg sg = t.s[seg];
+  if (sg.mode != 0) return;
+  const int nblk = (sg.n + SEL_B - 1) / SEL_B;
+  const int rem = sel_state(ws, seg)->remaining;
   int carry_eq = 0, carry_keep = 0;
   for (int b0 = 0; b0 < nblk; b0 += 256) {
     const int b = b0 + (int)threadIdx.x;
-    const int2 c = b < nblk ? cnt[b] : make_int2(0, 0);
+    const int2 c = b < nblk ? cnt[sg.blk0 + b] : make_int2(0, 0);
     int tot;
     const int eqb = carry_eq + sel_block_scan(c.y, &tot, wsum);
     carry_eq += tot;
@@ -130,25 +159,38 @@ __global__ void __launch_bounds__(256) k_sel_offsets(const int2* __restrict__ cn
     const int kept = c.x + (room <= 0 ? 0 : (room < c.y ? room : c.y));
     const int keepb = carry_keep + sel_block_scan(kept, &tot, wsum);
     carry_keep += tot;
-    if (b < nblk) before[b] = make_int2(eqb, keepb);
+    if (b < nblk) before[sg.blk0 + b] = make_int2(eqb, keepb);
   }
 }
 
-__global__ void __launch_bounds__(256) k_sel_compact(const float* __restrict__ logits, long long stride, long long n,
-                                                     const SelState* __restrict__ st, const int2* __restrict__ before,
-                                                     const int64_t* __restrict__ keys, unsigned char* __restrict__ mask,
-                                                     int64_t* __restrict__ keys_out) {
+__global__ void __launch_bounds__(256) k_sel_compact(const float* __restrict__ logits, long long stride, void* ws, SelTable t,
+                                                     const int2* __restrict__ before, const int64_t* __restrict__ keys,
+                                                     unsigned char* __restrict__ mask, int64_t* __restrict__ keys_out) {
   __shared__ int wsum[4];
+  const int seg = blockIdx.y;
+  const SelSeg sg = t.s[seg];
+  if ((long long)blockIdx.x * SEL_B >= sg.n) return;
+  const long long base = (long long)blockIdx.x * SEL_B + (long long)threadIdx.x * 8;
+  if (sg.mode != 0) {                                                  // every row / no row
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (base + q < sg.n) {
+        mask[sg.b0 + base + q] = sg.mode == 1 ? 1 : 0;
+        if (sg.mode == 1 && keys_out) keys_out[sg.out_base + base + q] = keys[sg.b0 + base + q];
+      }
+    return;
+  }
+  const SelState* st = sel_state(ws, seg);
   const unsigned T = st->prefix;
   const int rem = st->remaining;
-  const int2 bf = before[blockIdx.x];
-  const long long base = (long long)blockIdx.x * SEL_B + (long long)threadIdx.x * 8;
+  const int2 bf = before[sg.blk0 + blockIdx.x];
+  const float* lg = logits + sg.b0 * stride;
   unsigned u[8];
   int eq = 0;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    u[q] = base + q < n ? f2u(logits[(base + q) * stride]) : 0u;
-    eq += (base + q < n) && u[q] == T;
+    u[q] = base + q < sg.n ? f2u(lg[(base + q) * stride]) : 0u;
+    eq += (base + q < sg.n) && u[q] == T;
   }
   int tot;
   int eq_rank = bf.x + sel_block_scan(eq, &tot, wsum);
@@ -156,37 +198,27 @@ __global__ void __launch_bounds__(256) k_sel_compact(const float* __restrict__ l
   int kc = 0;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const bool in = base + q < n;
+    const bool in = base + q < sg.n;
     const bool e = in && u[q] == T;
     keep[q] = in && (u[q] > T || (e && eq_rank < rem));
     eq_rank += e;
     kc += keep[q];
   }
-  int pos = bf.y + sel_block_scan(kc, &tot, wsum);
+  long long pos = sg.out_base + bf.y + sel_block_scan(kc, &tot, wsum);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    if (base + q >= n) break;
-    mask[base + q] = keep[q] ? 1 : 0;
+    if (base + q >= sg.n) break;
+    mask[sg.b0 + base + q] = keep[q] ? 1 : 0;
     if (keep[q]) {
-      if (keys_out) keys_out[pos] = keys[base + q];
+      if (keys_out) keys_out[pos] = keys[sg.b0 + base + q];
       ++pos;
     }
   }
 }
 
-__global__ void k_fill_u8(unsigned char* p, long long n, unsigned char v) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-
-__global__ void k_copy_i64(const int64_t* __restrict__ in, long long n, int64_t* __restrict__ out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = in[i];
-}
-
 extern "C" size_t pcc_topk_ws_bytes(int64_t n) {
-  if (n <= 0) return SEL_WS_HDR;
-  return SEL_WS_HDR + 2 * pcc_align_up((size_t)pcc_cdiv(n, SEL_B) * sizeof(int2)) + 256;
+  if (n < 0) n = 0;
+  return (size_t)SEL_MAXSEG * SEL_SEG_WS + 2 * pcc_align_up((size_t)(pcc_cdiv(n, SEL_B) + SEL_MAXSEG) * sizeof(int2)) + 256;
 }
 
 // keys / keys_out nullable: the mask alone (pcc_topk_mask).  keys_out receives the kept rows' keys batch after batch
@@ -195,48 +227,54 @@ static int topk_impl(const float* logits, int64_t stride_elems, const int64_t* h
                      const int64_t* keys, uint8_t* mask, int64_t* keys_out, void* ws, size_t ws_bytes, hipStream_t s) {
   PCC_REQUIRE(h_seg_begin && h_k && nb >= 0, "pcc_topk: bad arguments");
   int64_t out_base = 0;
-  for (int b = 0; b < nb; ++b) {
-    const int64_t b0 = h_seg_begin[b], n = h_seg_begin[b + 1] - b0, k = h_k[b];
-    if (n <= 0) continue;
-    PCC_REQUIRE(logits && mask && stride_elems >= 1, "pcc_topk: NULL array");
-    PCC_REQUIRE(n < (1ll << 31), "pcc_topk: too many rows");
-    const unsigned g = (unsigned)pcc_cdiv(n, 256);
-    if (k <= 0 || k >= n) {
-      k_fill_u8<<<g, 256, 0, s>>>(mask + b0, n, k >= n ? 1 : 0);
-      PCC_LAUNCH_CHECK();
-      if (k >= n && keys_out) {
-        k_copy_i64<<<g, 256, 0, s>>>(keys + b0, n, keys_out + out_base);
-        PCC_LAUNCH_CHECK();
-      }
-      if (k >= n) out_base += n;
-      continue;
+  int b = 0;
+  while (b < nb) {
+    SelTable t;
+    t.nseg = 0; t.pad = 0;
+    int blk = 0;
+    long long max_n = 0;
+    bool any_select = false;
+    for (; b < nb && t.nseg < SEL_MAXSEG; ++b) {
+      const int64_t b0 = h_seg_begin[b], n = h_seg_begin[b + 1] - b0, k = h_k[b];
+      if (n <= 0) continue;
+      PCC_REQUIRE(logits && mask && stride_elems >= 1, "pcc_topk: NULL array");
+      PCC_REQUIRE(n < (1ll << 31), "pcc_topk: too many rows");
+      SelSeg& sg = t.s[t.nseg++];
+      sg.b0 = b0; sg.out_base = out_base; sg.n = (int)n;
+      sg.mode = k >= n ? 1 : (k <= 0 ? 2 : 0);
+      sg.k = (int)(k < 0 ? 0 : (k > n ? n : k));
+      sg.blk0 = blk;
+      blk += (int)pcc_cdiv(n, SEL_B);
+      if (sg.mode == 0) any_select = true;
+      if (n > max_n) max_n = n;
+      out_base += sg.k;
     }
-    if (ws_bytes < pcc_topk_ws_bytes(n)) {
+    if (t.nseg == 0) continue;
+    const size_t need = (size_t)SEL_MAXSEG * SEL_SEG_WS + 2 * pcc_align_up((size_t)blk * sizeof(int2));
+    if (ws_bytes < need) {
       pcc_set_error("pcc_topk: workspace too small");
       return PCC_EWS;
     }
-    SelState* st = (SelState*)ws;
-    int* hist = (int*)((char*)ws + 256);
-    const int nblk = (int)pcc_cdiv(n, SEL_B);
-    int2* cnt = (int2*)((char*)ws + SEL_WS_HDR);
-    int2* before = (int2*)((char*)cnt + pcc_align_up((size_t)nblk * sizeof(int2)));
-    const float* lg = logits + b0 * stride_elems;
-    k_sel_init<<<1, 256, 0, s>>>(st, hist, (int)k);
-    PCC_LAUNCH_CHECK();
+    int2* cnt = (int2*)((char*)ws + (size_t)SEL_MAXSEG * SEL_SEG_WS);
+    int2* before = (int2*)((char*)cnt + pcc_align_up((size_t)blk * sizeof(int2)));
+    const unsigned ny = (unsigned)t.nseg;
+    const unsigned g = (unsigned)pcc_cdiv(max_n, 256);
     const unsigned gh = g < 1024 ? g : 1024;
-    k_sel_hist<11><<<gh, 256, 0, s>>>(lg, stride_elems, n, 21, st, hist);
-    k_sel_pick<<<1, 256, 0, s>>>(st, hist, 21, 11);
-    k_sel_hist<11><<<gh, 256, 0, s>>>(lg, stride_elems, n, 10, st, hist);
-    k_sel_pick<<<1, 256, 0, s>>>(st, hist, 10, 11);
-    k_sel_hist<10><<<gh, 256, 0, s>>>(lg, stride_elems, n, 0, st, hist);
-    k_sel_pick<<<1, 256, 0, s>>>(st, hist, 0, 10);
+    const unsigned gb = (unsigned)pcc_cdiv(max_n, SEL_B);
+    if (any_select) {
+      k_sel_init<<<dim3(1, ny), 256, 0, s>>>(ws, t);
+      k_sel_hist<11><<<dim3(gh, ny), 256, 0, s>>>(logits, stride_elems, 21, ws, t);
+      k_sel_pick<<<dim3(1, ny), 256, 0, s>>>(ws, 21, 11, t);
+      k_sel_hist<11><<<dim3(gh, ny), 256, 0, s>>>(logits, stride_elems, 10, ws, t);
+      k_sel_pick<<<dim3(1, ny), 256, 0, s>>>(ws, 10, 11, t);
+      k_sel_hist<10><<<dim3(gh, ny), 256, 0, s>>>(logits, stride_elems, 0, ws, t);
+      k_sel_pick<<<dim3(1, ny), 256, 0, s>>>(ws, 0, 10, t);
+      PCC_LAUNCH_CHECK();
+      k_sel_count<<<dim3(gb, ny), 256, 0, s>>>(logits, stride_elems, ws, t, cnt);
+      k_sel_offsets<<<dim3(1, ny), 256, 0, s>>>(cnt, ws, t, before);
+    }
+    k_sel_compact<<<dim3(gb, ny), 256, 0, s>>>(logits, stride_elems, ws, t, before, keys, mask, keys_out);
     PCC_LAUNCH_CHECK();
-    k_sel_count<<<(unsigned)nblk, 256, 0, s>>>(lg, stride_elems, n, st, cnt);
-    k_sel_offsets<<<1, 256, 0, s>>>(cnt, nblk, st, before);
-    k_sel_compact<<<(unsigned)nblk, 256, 0, s>>>(lg, stride_elems, n, st, before, keys ? keys + b0 : nullptr, mask + b0,
-                                                keys_out ? keys_out + out_base : nullptr);
-    PCC_LAUNCH_CHECK();
-    out_base += k;
   }
   return PCC_OK;
 }

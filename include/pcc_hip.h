@@ -249,6 +249,12 @@ int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
  * `packed`; a buffer smaller than pcc_conv_packed_elems(K, cin, cout) is refused (PCC_EWS), never written past. */
 int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
                           int64_t packed_cap, void* stream);
+/* The same pack read through a transposed / offset-reversed view of a stored kernel: W'[k][ci][co] = W[flip ? K-1-k : k][co][ci]
+ * when `transpose` (W stored [K][cout][cin]), else W[flip ? K-1-k : k][ci][co] -- the kernels of the data gradient
+ * (reference train.py:221-227 back-propagates through every ME convolution) without a copy in front.  MFMA layout only
+ * (cin a multiple of 32, cout > 16); other shapes are refused. */
+int pcc_conv_pack_weights_ex(const float* W, int32_t K, int32_t cin, int32_t cout, int32_t transpose, int32_t flip, float* packed,
+                             int64_t packed_cap, void* stream);
 size_t pcc_conv_ws_bytes(int64_t n_in, int32_t K, int32_t cin, int32_t cout);
 /* Occupancy head `predict_i` (model/transforms.py:141-160) in one pass over the features:
  *   logits = conv_k3(relu(conv_k3(x; W0, b0)); W2, b2),  W0: cin -> cmid (4 < cmid <= 16), W2: cmid -> 1.
@@ -443,6 +449,11 @@ int pcc_eb_encode(const float* z, int64_t n, int32_t c, const float* eb_packed, 
  * :318-322): a 2 -> 10 -> 10 -> 1 perceptron with ReLUs per element on (scale, stddev), one kernel per direction.
  * params [pcc_quant_mlp_params() = 151]: W1 [10][2] | b1 [10] | W2 [10][10] | b2 [10] | W3 [10] | b3 (torch.nn.Linear layouts).
  * bwd: d_scale / d_stddev nullable; d_params [151] summed in a fixed order (deterministic). */
+/* Focal loss rows of one occupancy level (reference loss.py:115-157 Multiscale_FocalLoss): f[i] = -(occ ? alpha : 1-alpha) *
+ * (1-pt)^gamma * log(pt) * q_map[batch(i)][0] with pt = clip(occ ? p : 1-p, 1e-2, 1), p = sigmoid(logit), and df[i] = d f[i] /
+ * d logit[i].  occ_row: pcc_lookup_rows of the candidate keys in the ground-truth set (>= 0: occupied); keys: the candidates. */
+int pcc_focal_rows(const float* logits, int64_t stride_elems, const int32_t* occ_row, const int64_t* keys, int64_t n,
+                   const float* q_map, int32_t q_pitch, float alpha, float gamma, float* f, float* df, void* stream);
 int32_t pcc_quant_mlp_params(void);
 size_t pcc_quant_mlp_ws_bytes(int64_t n);
 int pcc_quant_mlp_fwd(const float* scale, const float* stddev, int64_t n, const float* params, float* out, void* stream);

@@ -219,3 +219,31 @@ def test_quant_offset_network_kernels_match_the_torch_layers():
     d3 = t(d0).requires_grad_(True)
     QuantMlpFn.apply(t(s0), d3, net[0].weight, net[0].bias, net[2].weight, net[2].bias, net[4].weight, net[4].bias).sum().backward()
     assert d3.grad is not None
+
+
+def test_fused_focal_loss_rows_match_the_torch_chain():
+    """`pcc_focal_rows` (one occupancy level of `Multiscale_FocalLoss`, reference `loss.py:115-157`) against the torch operator
+    chain: the level's mean and the gradient with respect to the logits, with logits far enough out for the clip to bind."""
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    from unified_point_cloud_compression_amd import loss as LS
+    keys = cloud_keys(11, 24, 0.2, 1, batch=3)
+    gt_keys = keys[np.random.default_rng(1).random(len(keys)) < 0.4]
+    rng = np.random.default_rng(2)
+    lg = (rng.standard_normal((len(keys), 1)) * 4).astype(np.float32)
+    q_map = t(np.array([[0.3, 1.0], [2.0, 5.0], [0.7, 9.0]], dtype=np.float32))
+    gt = ME.SparseTensor(coordinates=t(co.unpack_keys(gt_keys)), features=t(np.ones((len(gt_keys), 1), np.float32)))
+    fl = LS.Multiscale_FocalLoss({"id": "f", "alpha": 0.7, "gamma": 2.0})
+    vals, grads = [], []
+    for fused in (True, False):
+        LS.FUSED_FOCAL = fused
+        try:
+            x = t(lg).requires_grad_(True)
+            pred = ME.SparseTensor(coordinates=t(co.unpack_keys(keys)), features=x)
+            out = fl(gt, {"occ_predictions": [pred], "points": [gt], "q_map": q_map})
+            out.backward()
+            vals.append(float(out))
+            grads.append(n(x.grad))
+        finally:
+            LS.FUSED_FOCAL = True
+    assert abs(vals[0] - vals[1]) <= 1e-5 * abs(vals[1])
+    assert_close(grads[0] * len(keys), grads[1] * len(keys), atol=1e-5, rtol=1e-4, what="d loss / d logits")

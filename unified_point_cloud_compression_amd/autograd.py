@@ -35,6 +35,29 @@ def _pad4(t, dim):
     return torch.cat([t, t.new_zeros(shape)], dim=dim)
 
 
+def _pack_view(src3, K, cin, cout, transpose, flip):
+    """Packed weights of the convolution W'[k][ci][co] = src3[flip ? K-1-k : k][co][ci] (transpose) straight from the stored
+    kernel `src3` -- no flip / permute / copy kernels in front of the pack (`pcc_conv_pack_weights_ex`)."""
+    src3 = src3.contiguous()
+    n = L.load().pcc_conv_packed_elems(K, cin, cout)
+    packed = torch.empty(n, dtype=torch.float32, device=src3.device)
+    L.call("pcc_conv_pack_weights_ex", L.ptr(src3), K, cin, cout, 1 if transpose else 0, 1 if flip else 0, L.ptr(packed),
+           packed.numel(), L.stream())
+    return packed
+
+
+def _conv_view(feats, src3, transpose, flip, kmap, n_out):
+    """The data-gradient convolution with the kernel W' = transposed (and offset-reversed) view of the stored kernel `src3`
+    [K, a, b]: W' is [K, b, a].  Shapes the MFMA pack takes directly skip the torch-side view + copy; others go through
+    `_conv_any`."""
+    K, a, b = src3.shape
+    cin, cout = (b, a) if transpose else (a, b)
+    if cin % 32 == 0 and cout > 16 and feats.shape[1] == cin:
+        return S.conv_forward(feats, _pack_view(src3, K, cin, cout, transpose, flip), None, K, cin, cout, kmap, n_out)
+    w = torch.flip(src3, dims=[0]) if flip else src3
+    return _conv_any(feats, w.permute(0, 2, 1) if transpose else w, kmap, n_out)
+
+
 def _conv_any(feats, w3, kmap, n_out):
     """conv_forward for arbitrary (cin, cout): channel counts the kernels do not take are zero-padded to 4 / 32."""
     K, cin, cout = w3.shape
@@ -105,13 +128,12 @@ class SparseConvFn(torch.autograd.Function):
                     g_kernel = S.conv_wgrad(feats, g, K, cin, cout, kmap)
             if ctx.needs_input_grad[0]:
                 if K == 1:
-                    g_feats = _conv_any(g, w3.permute(0, 2, 1), None, feats.shape[0])
+                    g_feats = _conv_view(g, w3, True, False, None, feats.shape[0])
                 else:
                     if module.kernel_size % 2 == 0:
                         raise L.PccError("backward of even-sized (non-generative) kernels is not supported")
                     inv = out_set.kernel_map(in_set, module.kernel_size, step=in_set.ts)    # roles swapped
-                    wd = torch.flip(w3, dims=[0]).permute(0, 2, 1)                           # W'[k'] = W[K-1-k']^T
-                    g_feats = _conv_any(g, wd, inv, in_set.n)
+                    g_feats = _conv_view(g, w3, True, True, inv, in_set.n)                   # W'[k'] = W[K-1-k']^T
         if g_kernel is not None and kernel.dim() == 2:
             g_kernel = g_kernel[0]
         return g_feats, g_kernel, g_bias, None, None, None, None, None, None
@@ -168,14 +190,15 @@ class GdnFn(torch.autograd.Function):
             gamma = m.gamma_reparam(g_leaf)
         with torch.no_grad():
             ax = x.abs()
-            n = _conv_any(ax, gamma.detach().t().unsqueeze(0).contiguous(), None, x.shape[0]) + beta.detach()
+            g3 = gamma.detach().unsqueeze(0).contiguous()                  # [1, co, ci]: norm = |x| gamma^T
+            n = _conv_view(ax, g3, True, False, None, x.shape[0]) + beta.detach()
             if m.inverse:
                 u = g * x
                 dx0 = g * n
             else:
                 u = -(g * x) / (n * n)
                 dx0 = g / n
-            dx = dx0 + torch.sign(x) * _conv_any(u, gamma.detach().unsqueeze(0).contiguous(), None, x.shape[0])
+            dx = dx0 + torch.sign(x) * _conv_view(u, g3, False, False, None, x.shape[0])
             d_beta = u.sum(dim=0)
             d_gamma = S.conv_wgrad(ax, u.contiguous(), 1, ax.shape[1], u.shape[1], None)[0].t()      # [ci][co] = sum |x|_ci u_co
         gb, gg = torch.autograd.grad([beta, gamma], [b_leaf, g_leaf], [d_beta, d_gamma.contiguous()])
@@ -238,6 +261,28 @@ class QuantMlpFn(torch.autograd.Function):
             grads.append(dp[at:at + k].view(shp))
             at += k
         return (ds, dd, *grads)
+
+
+class FocalRowsFn(torch.autograd.Function):
+    """Sum over the rows of one occupancy level of the focal loss terms (`pcc_focal_rows`; reference `loss.py:115-157`):
+    forward = one kernel + one sum, backward = one multiply (the derivative with respect to the logits is produced by the
+    forward kernel)."""
+
+    @staticmethod
+    def forward(ctx, logits, occ_row, keys, q_map, alpha, gamma):       # logits: 1-D (a column view is fine)
+        n = logits.shape[0]
+        f = torch.empty(n, dtype=torch.float32, device=logits.device)
+        df = torch.empty(n, dtype=torch.float32, device=logits.device)
+        q_map = q_map.to(torch.float32).contiguous()
+        L.call("pcc_focal_rows", logits.data_ptr(), logits.stride(0), L.ptr(occ_row), L.ptr(keys), n, L.ptr(q_map), q_map.stride(0),
+               float(alpha), float(gamma), L.ptr(f), L.ptr(df), L.stream())
+        ctx.save_for_backward(df)
+        return f.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (df,) = ctx.saved_tensors
+        return df * g, None, None, None, None, None
 
 
 class EbLikFn(torch.autograd.Function):

@@ -2426,6 +2426,36 @@ __global__ void k_pack_mfma(const float* __restrict__ W, int K, int cin, int cou
   out[t] = (col < cout) ? W[((long long)kid * cin + ci) * cout + col] : 0.f;
 }
 
+// The same for cin a multiple of 32 with the three bf16 planes of the split path written in the same pass (round 4: pack + split
+// were two launches per weight and a training step packs ~45 weights), reading the source through strides: W'[k][ci][co] =
+// W[kk * sk + ci * sci + co * sco], kk = K-1-k when `flip` -- the data gradient's transposed / offset-reversed kernels are
+// packed straight from the parameter (no torch flip / permute / copy in front).  One thread = two consecutive channels.
+__global__ void k_pack_mfma_split(const float* __restrict__ W, int K, int cin, int cout, int cout_pad, long long sk, long long sci,
+                                  long long sco, int flip, float* __restrict__ out, unsigned* __restrict__ planes) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // pair index of the packed image
+  const long long pairs = (long long)K * cin * cout_pad / 2;
+  if (t >= pairs) return;
+  const int within = (int)(t & 15) * 2;
+  const long long q = t >> 4;                                                 // packed row = (piece, column)
+  const int col = (int)(q % cout_pad);
+  const long long piece = q / cout_pad;
+  const int ppo = cin >> 5;
+  const int kid = (int)(piece / ppo), cbi = (int)(piece % ppo);
+  const int ci = (cbi << 5) + within;
+  const int kk = flip ? K - 1 - kid : kid;
+  float v0 = 0.f, v1 = 0.f;
+  if (col < cout) {
+    const float* w = W + kk * sk + col * sco;
+    v0 = w[ci * sci];
+    v1 = w[(ci + 1) * sci];
+  }
+  *reinterpret_cast<float2*>(out + 2 * t) = make_float2(v0, v1);
+  unsigned h, m, l;
+  bf_split2(v0, v1, h, m, l);
+  unsigned* d = planes + q * 48 + (t & 15);
+  d[0] = h; d[16] = m; d[32] = l;
+}
+
 // W [K][cin][cout] -> wave16 layout [K][cin/4][16][4] (k-quad major, 16 zero-padded output columns, 4 channels each:
 // the LDS image of k_conv_wave16*, see wave16_w)
 __global__ void k_pack_wave16(const float* __restrict__ W, int K, int cin, int cout, float* __restrict__ out) {
@@ -2449,10 +2479,26 @@ __global__ void k_pack_thin(const float* __restrict__ W, int K, int cin, int cou
   out[t] = W[((long long)k * cin + c) * cout + o];
 }
 
+static int pack_weights_impl(const float* W, int32_t K, int32_t cin, int32_t cout, long long sk, long long sci, long long sco,
+                             int flip, float* packed, int64_t packed_cap, hipStream_t s);
+
 extern "C" int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int32_t cout, float* packed,
                                      int64_t packed_cap, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+  return pack_weights_impl(W, K, cin, cout, (long long)cin * cout, cout, 1, 0, packed, packed_cap, (hipStream_t)stream);
+}
+
+// The pack of W'[k][ci][co] = W[(flip ? K-1-k : k)][co][ci] when `transpose` (W stored [K][cout][cin]: the kernel of the
+// convolution whose data gradient is being computed), else of W itself with the offsets reversed.
+extern "C" int pcc_conv_pack_weights_ex(const float* W, int32_t K, int32_t cin, int32_t cout, int32_t transpose, int32_t flip,
+                                        float* packed, int64_t packed_cap, void* stream) {
+  return pack_weights_impl(W, K, cin, cout, (long long)cin * cout, transpose ? 1 : cout, transpose ? cin : 1, flip ? 1 : 0, packed,
+                           packed_cap, (hipStream_t)stream);
+}
+
+static int pack_weights_impl(const float* W, int32_t K, int32_t cin, int32_t cout, long long sk, long long sci, long long sco,
+                             int flip, float* packed, int64_t packed_cap, hipStream_t s) {
   PCC_REQUIRE(W && packed && K >= 1 && K <= MAXK && cin >= 1 && cout >= 1, "pcc_conv_pack_weights: bad arguments");
+  const bool plain = sk == (long long)cin * cout && sci == cout && sco == 1 && !flip;
   const int64_t total = pcc_conv_packed_elems(K, cin, cout);
   if (packed_cap < total) {   // a buffer sized with another layout's query (round 1: GDN sized by the conv query) is refused
     pcc_set_error("pcc_conv_pack_weights: packed buffer holds %lld floats, the layout needs %lld", (long long)packed_cap, (long long)total);
@@ -2462,9 +2508,15 @@ extern "C" int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int
   switch (conv_kind(K, cin, cout)) {
     case KIND_MFMA: {
       const int64_t base = (int64_t)K * cin * cout_pad_for(cout);
-      k_pack_mfma<<<(unsigned)pcc_cdiv(base, 256), 256, 0, s>>>(W, K, cin, cout, cout_pad_for(cout), cb_log2_for(cin), packed);
-      PCC_LAUNCH_CHECK();
-      PCC_TRY(split_planes(packed, base, cin, s));
+      if (cin % 32 == 0) {
+        k_pack_mfma_split<<<(unsigned)pcc_cdiv(base / 2, 256), 256, 0, s>>>(W, K, cin, cout, cout_pad_for(cout), sk, sci, sco, flip,
+                                                                             packed, (unsigned*)(packed + base));
+        PCC_LAUNCH_CHECK();
+      } else {
+        PCC_REQUIRE(plain, "pcc_conv_pack_weights_ex: transposed / reversed source needs cin a multiple of 32");
+        k_pack_mfma<<<(unsigned)pcc_cdiv(base, 256), 256, 0, s>>>(W, K, cin, cout, cout_pad_for(cout), cb_log2_for(cin), packed);
+        PCC_LAUNCH_CHECK();
+      }
       if (conv_has_h(K, cin, cout)) {
         const int cp = cout_pad_for(cout);
         float* const planes = packed + base + bf_plane_elems(base);
@@ -2473,8 +2525,14 @@ extern "C" int pcc_conv_pack_weights(const float* W, int32_t K, int32_t cin, int
       }
       break;
     }
-    case KIND_WAVE16: k_pack_wave16<<<g, 256, 0, s>>>(W, K, cin, cout, packed); break;
-    case KIND_THIN_T: case KIND_THIN: k_pack_thin<<<g, 256, 0, s>>>(W, K, cin, cout, packed); break;
+    case KIND_WAVE16:
+      PCC_REQUIRE(plain, "pcc_conv_pack_weights_ex: transposed / reversed source is packed for the MFMA layout only");
+      k_pack_wave16<<<g, 256, 0, s>>>(W, K, cin, cout, packed);
+      break;
+    case KIND_THIN_T: case KIND_THIN:
+      PCC_REQUIRE(plain, "pcc_conv_pack_weights_ex: transposed / reversed source is packed for the MFMA layout only");
+      k_pack_thin<<<g, 256, 0, s>>>(W, K, cin, cout, packed);
+      break;
     default:
       pcc_set_error("pcc_conv: unsupported shape cin=%d cout=%d (MFMA path needs cin in {4,8,16} or a multiple of 32)", cin, cout);
       return PCC_EINVAL;

@@ -482,3 +482,45 @@ extern "C" int pcc_quant_mlp_bwd(const float* scale, const float* stddev, const 
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Focal loss of one occupancy level of the training forward (`Multiscale_FocalLoss`, reference `loss.py:115-157`): per
+// candidate row  p = sigmoid(logit),  v = occupied ? p : 1 - p,  pt = clip(v, 1e-2, 1),
+//     f = -(occupied ? alpha : 1 - alpha) * (1 - pt)^gamma * log(pt) * w[batch(row)]
+// and its derivative with respect to the logit (clip passes the gradient inside its range, as torch.clip does).  The torch
+// chain is ~12 launches forward and ~20 backward per level; this is one, the level's mean is a sum of `f` divided by n.
+// occ_row: result of pcc_lookup_rows against the ground-truth set (>= 0: occupied).  w = q_map[batch][0] (row pitch q_pitch).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_focal_rows(const float* __restrict__ logits, long long stride,
+                                                    const int* __restrict__ occ_row, const long long* __restrict__ keys,
+                                                    long long n, const float* __restrict__ q_map, int q_pitch, float alpha,
+                                                    float gamma, float* __restrict__ f, float* __restrict__ df) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const bool occ = occ_row[t] >= 0;
+  const float x = logits[t * stride];
+  const float p = 1.f / (1.f + expf(-x));
+  const float v = occ ? p : 1.f - p;
+  const bool inside = v >= 1e-2f;                      // (v <= 1 always)
+  const float pt = inside ? v : 1e-2f;
+  const float a = occ ? alpha : 1.f - alpha;
+  const float w = q_map[(keys[t] >> 48) * q_pitch];
+  const float om = 1.f - pt;
+  const float pw = powf(om, gamma), lg = logf(pt);
+  f[t] = -a * pw * lg * w;
+  // d f / d pt = -a w ( -gamma om^(gamma-1) log pt + om^gamma / pt )
+  const float pw1 = om > 0.f ? powf(om, gamma - 1.f) : (gamma > 1.f ? 0.f : 1.f);
+  const float dfdpt = -a * w * (-gamma * pw1 * lg + pw / pt);
+  df[t] = inside ? dfdpt * (occ ? 1.f : -1.f) * p * (1.f - p) : 0.f;
+}
+
+extern "C" int pcc_focal_rows(const float* logits, int64_t stride_elems, const int32_t* occ_row, const int64_t* keys, int64_t n,
+                              const float* q_map, int32_t q_pitch, float alpha, float gamma, float* f, float* df, void* stream) {
+  PCC_REQUIRE(n >= 0 && stride_elems >= 1 && q_pitch >= 1 && (n == 0 || (logits && occ_row && keys && q_map && f && df)),
+              "pcc_focal_rows: bad arguments");
+  if (n == 0) return PCC_OK;
+  k_focal_rows<<<(unsigned)pcc_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(logits, stride_elems, occ_row, (const long long*)keys, n,
+                                                                           q_map, q_pitch, alpha, gamma, f, df);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}

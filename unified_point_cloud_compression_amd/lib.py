@@ -63,6 +63,7 @@ SIGNATURES = {
     "pcc_set_thin_z_min_rows": (C.c_int, [_i64]),
     "pcc_conv_packed_elems": (_i64, [_i32, _i32, _i32]),
     "pcc_conv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _i64, _p]),
+    "pcc_conv_pack_weights_ex": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "pcc_conv_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "pcc_conv_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _f32, _p, _sz, _i32, _p, _p]),
     "pcc_conv_head_supported": (C.c_int, [_i32, _i32]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "pcc_conv_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "pcc_conv_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_conv_wgrad_self_supported": (C.c_int, [_i32, _i32, _i32]),
+    "pcc_focal_rows": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _i32, C.c_float, C.c_float, _p, _p, _p]),
     "pcc_quant_mlp_params": (_i32, []),
     "pcc_quant_mlp_ws_bytes": (_sz, [_i64]),
     "pcc_quant_mlp_fwd": (C.c_int, [_p, _p, _i64, _p, _p, _p]),

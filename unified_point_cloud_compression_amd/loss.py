@@ -5,18 +5,25 @@
 tests use exact packed keys on the device (the reference flattens coordinates with float-scaled weights and torch.isin).
 """
 import math
+import os
 
 import torch
 
 from . import lib as L
 from . import sparse as S
 
+FUSED_FOCAL = os.environ.get("PCC_FUSED_FOCAL", "1") != "0"      # focal loss rows as one kernel per level (training step)
 
-def _lookup_rows(cset, query_keys, nq):
+
+def _lookup_rows32(cset, query_keys, nq):
     rows = torch.empty(max(nq, 1), dtype=torch.int32, device=cset.device)
     if nq:
         L.call("pcc_lookup_rows", L.ptr(cset.keys), cset.n, L.ptr(query_keys), nq, L.ptr(rows), L.stream())
-    return rows[:nq].long()
+    return rows[:nq]
+
+
+def _lookup_rows(cset, query_keys, nq):
+    return _lookup_rows32(cset, query_keys, nq).long()
 
 
 class BPPLoss:
@@ -61,6 +68,12 @@ class Multiscale_FocalLoss:
         loss = 0.0
         for prediction, coords in zip(predictions, points):
             pcs, gcs = prediction._cset, coords._cset
+            logit = prediction._canonical_features()[:, 0]
+            if FUSED_FOCAL and logit.is_cuda and pcs.n > 0:        # one kernel + one sum per level (`autograd.FocalRowsFn`)
+                from .autograd import FocalRowsFn
+                occ_row = _lookup_rows32(gcs, pcs.keys, pcs.n)
+                loss = loss + FocalRowsFn.apply(logit, occ_row, pcs.keys, q_map, self.alpha, self.gamma) / pcs.n
+                continue
             occ = _lookup_rows(gcs, pcs.keys, pcs.n) >= 0           # predicted voxel is occupied in the ground truth
             p = torch.sigmoid(prediction._canonical_features()[:, 0])
             pt = torch.clip(torch.where(occ, p, 1 - p), 1e-2, 1)

@@ -313,7 +313,7 @@ def true_geometry_ms(model, pc, q, steps=5, warmup=2):
     return {"ms_per_step_true_geometry": ms, "candidate_rows": [sizes.get(i) for i in range(3)], "lossless_geometry": bool(exact)}
 
 
-def train_step_setup(device):
+def train_step_setup(device, bottleneck_step=True):
     """The training step of BASELINE configs[3] as a callable: `one()` runs forward, losses, backward, gradient clipping and the
     model optimiser's step, then the quantile (aux) loss with the bottleneck optimiser's step, reading both losses as
     `train.py:196-236` does.  4 cubes of 128^3 cut from the benchmark frame, `configs/CVPR_inverse_scaling.yaml` (adaptive
@@ -358,6 +358,8 @@ def train_step_setup(device):
         total.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
         opt.step()
+        if not bottleneck_step:                       # (what rounds 1-3 timed: the model optimiser's half of the step)
+            return value, None
         aux = model.aux_loss()
         aux_value = aux.item()
         aux.backward()
@@ -369,7 +371,7 @@ def train_step_setup(device):
     return one, info
 
 
-def train_step_ms(device, steps=5, warmup=6):
+def train_step_ms(device, steps=10, warmup=6):
     """Auxiliary (BASELINE configs[3], never `value`): wall time of `train_step_setup`'s step."""
     one, info = train_step_setup(device)
     for _ in range(warmup):
@@ -379,7 +381,18 @@ def train_step_ms(device, steps=5, warmup=6):
     for _ in range(steps):
         last = one()
     torch.cuda.synchronize()
-    return {"train_step_ms": (time.time() - t0) / steps * 1e3, "loss": last[0], "aux_loss": last[1], **info}
+    out = {"train_step_ms": (time.time() - t0) / steps * 1e3, "loss": last[0], "aux_loss": last[1], **info}
+    # the same step without the quantile loss / bottleneck optimiser, as rounds 1-3 reported it (comparison across rounds only)
+    one2, _ = train_step_setup(device, bottleneck_step=False)
+    for _ in range(warmup):
+        one2()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        one2()
+    torch.cuda.synchronize()
+    out["train_step_ms_without_bottleneck_step"] = (time.time() - t0) / steps * 1e3
+    return out
 
 
 def self_launch(args):

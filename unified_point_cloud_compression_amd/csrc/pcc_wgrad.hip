@@ -488,6 +488,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_bf(WgradArgs a) {
     }
 }
 
+__global__ void k_wgrad_reduce_wide(const float* __restrict__ partial, long long elems, int nslices, float* __restrict__ dW);
 __global__ void k_wgrad_reduce(const float* __restrict__ partial, long long elems, int nslices, float* __restrict__ dW) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= elems) return;
@@ -541,7 +542,8 @@ extern "C" int pcc_conv_wgrad(const float* feat_in, int64_t n_in, int32_t cin, c
   else if (bf_on && ((cin | cout) & 3) == 0) k_wgrad_bf<<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
   else k_wgrad<false><<<dim3((unsigned)a.nslices, (unsigned)K, tiles), 256, 0, s>>>(a);
   PCC_LAUNCH_CHECK();
-  k_wgrad_reduce<<<(unsigned)pcc_cdiv(elems, 256), 256, 0, s>>>(a.partial, elems, a.nslices, dW);
+  if (a.nslices >= 16) k_wgrad_reduce_wide<<<(unsigned)pcc_cdiv(elems, 16), 256, 0, s>>>(a.partial, elems, a.nslices, dW);
+  else k_wgrad_reduce<<<(unsigned)pcc_cdiv(elems, 256), 256, 0, s>>>(a.partial, elems, a.nslices, dW);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

@@ -241,7 +241,7 @@ def test_fused_focal_loss_rows_match_the_torch_chain():
             pred = ME.SparseTensor(coordinates=t(co.unpack_keys(keys)), features=x)
             out = fl(gt, {"occ_predictions": [pred], "points": [gt], "q_map": q_map})
             out.backward()
-            vals.append(float(out))
+            vals.append(float(out.detach()))
             grads.append(n(x.grad))
         finally:
             LS.FUSED_FOCAL = True

@@ -47,10 +47,19 @@ S.L.call = timed_call
 import unified_point_cloud_compression_amd.autograd as AG  # noqa: E402
 AG.L.call = timed_call
 
-r = bench.train_step_ms(dev, steps=2, warmup=4)
-print("untimed:", r, file=out)
+one, info = bench.train_step_setup(dev)
+for _ in range(5):
+    one()
+torch.cuda.synchronize()
+import time  # noqa: E402
+t0 = time.time()
+for _ in range(5):
+    one()
+torch.cuda.synchronize()
+print("untimed:", {"train_step_ms": (time.time() - t0) / 5 * 1e3, **info}, file=out)
 state["on"] = True
-r2 = bench.train_step_ms(dev, steps=1, warmup=0)
+one()
+torch.cuda.synchronize()
 state["on"] = False
 agg = collections.OrderedDict()
 for name, desc, us in records:
@@ -71,6 +80,8 @@ for name, us in by.most_common():
 
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    bench.train_step_ms(dev, steps=2, warmup=0)
-print("\ntorch profiler, 2 steps + model construction (sorted by device time):", file=out)
+    one()
+    one()
+    torch.cuda.synchronize()
+print("\ntorch profiler, 2 steps (sorted by device time):", file=out)
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=70), file=out)

@@ -449,6 +449,18 @@ int pcc_eb_encode(const float* z, int64_t n, int32_t c, const float* eb_packed, 
  * :318-322): a 2 -> 10 -> 10 -> 1 perceptron with ReLUs per element on (scale, stddev), one kernel per direction.
  * params [pcc_quant_mlp_params() = 151]: W1 [10][2] | b1 [10] | W2 [10][10] | b2 [10] | W3 [10] | b3 (torch.nn.Linear layouts).
  * bwd: d_scale / d_stddev nullable; d_params [151] summed in a fixed order (deterministic). */
+/* GDN backward, element-wise parts (reference model/blocks.py:38-57; the products n = beta + |x| gamma^T, v = u gamma and
+ * d gamma = u^T |x| run on the convolution / weight-gradient entry points):
+ *   pre : GDN y = x / n: u = -g x / n^2, dx0 = g / n;  IGDN y = x n: u = g x, dx0 = g n        (elems = rows * C, a multiple of 4)
+ *   post: dx += sign(x) v
+ *   gamma_eff [C][C] = CompressAI's reparametrisation of gamma_raw (as pcc_gdn_pack applies it)
+ *   reparam_bwd: gradients of the RAW parameters from those of the effective ones (LowerBound's rule); d_gamma_t is [ci][co]
+ *   as pcc_conv_wgrad(|x|, u) returns it, gamma_raw / d_gamma_raw are [co][ci]. */
+int pcc_gdn_bwd_pre(const float* x, const float* g, const float* n, int64_t elems, int32_t inverse, float* u, float* dx0, void* stream);
+int pcc_gdn_bwd_post(float* dx, const float* x, const float* v, int64_t elems, void* stream);
+int pcc_gdn_gamma_eff(const float* gamma_raw, int32_t c, float* gamma_eff, void* stream);
+int pcc_gdn_reparam_bwd(const float* beta_raw, const float* gamma_raw, const float* d_beta, const float* d_gamma_t, int32_t c,
+                        float beta_min, float* d_beta_raw, float* d_gamma_raw, void* stream);
 /* Focal loss rows of one occupancy level (reference loss.py:115-157 Multiscale_FocalLoss): f[i] = -(occ ? alpha : 1-alpha) *
  * (1-pt)^gamma * log(pt) * q_map[batch(i)][0] with pt = clip(occ ? p : 1-p, 1e-2, 1), p = sigmoid(logit), and df[i] = d f[i] /
  * d logit[i].  occ_row: pcc_lookup_rows of the candidate keys in the ground-truth set (>= 0: occupied); keys: the candidates. */

@@ -247,3 +247,45 @@ def test_fused_focal_loss_rows_match_the_torch_chain():
             LS.FUSED_FOCAL = True
     assert abs(vals[0] - vals[1]) <= 1e-5 * abs(vals[1])
     assert_close(grads[0] * len(keys), grads[1] * len(keys), atol=1e-5, rtol=1e-4, what="d loss / d logits")
+
+
+@pytest.mark.parametrize("c,inverse", [(128, False), (128, True), (32, True)])
+def test_gdn_gradients_match_torch_autograd_of_the_formula(c, inverse):
+    """`GdnFn` (fused forward; backward = library products + the element-wise / reparametrisation kernels of round 4) against
+    torch autograd over the GDN1 formula of `model/blocks.py:38-57` on the CPU, and against the torch-operator backward."""
+    import unified_point_cloud_compression_amd.autograd as AG
+    from unified_point_cloud_compression_amd.model.blocks import MinkowskiGDN
+    torch.manual_seed(c + int(inverse))
+    m = MinkowskiGDN(c, inverse=inverse).to(dev())
+    with torch.no_grad():
+        m.gamma.add_(torch.rand_like(m.gamma) * 0.05)
+        m.beta.mul_(1.0 + torch.rand_like(m.beta))
+        m.gamma[0, :4] = 0.0                                            # entries AT the lower bound: the LowerBound gradient rule
+    rng = np.random.default_rng(c)
+    x0 = rng.standard_normal((3001, c)).astype(np.float32)
+    go = rng.standard_normal((3001, c)).astype(np.float32)
+    # reference: torch autograd on the CPU
+    mc = MinkowskiGDN(c, inverse=inverse)
+    mc.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    xc = torch.from_numpy(x0).requires_grad_(True)
+    beta, gamma = mc.beta_reparam(mc.beta), mc.gamma_reparam(mc.gamma)
+    nrm = beta + xc.abs() @ gamma.t()
+    yc = xc * nrm if inverse else xc / nrm
+    yc.backward(torch.from_numpy(go))
+    outs = []
+    for fused in (True, False):
+        AG.GDN_FUSED_BWD = fused
+        try:
+            for p in m.parameters():
+                p.grad = None
+            xg = t(x0).requires_grad_(True)
+            y = m.forward_rows(xg)
+            y.backward(t(go))
+            outs.append((n(y.detach()), n(xg.grad), n(m.beta.grad), n(m.gamma.grad)))
+        finally:
+            AG.GDN_FUSED_BWD = True
+    ref = (yc.detach().numpy(), xc.grad.numpy(), mc.beta.grad.numpy(), mc.gamma.grad.numpy())
+    for name, a, b, r in zip(("y", "dx", "d beta", "d gamma"), outs[0], outs[1], ref):
+        scale = float(np.abs(r).max()) + 1e-12
+        assert_close(a / scale, r / scale, atol=2e-5, rtol=0, what=f"fused {name} vs torch autograd")
+        assert_close(a / scale, b / scale, atol=2e-5, rtol=0, what=f"fused {name} vs torch-operator backward")

@@ -17,6 +17,7 @@ from . import lib as L
 from . import sparse as S
 
 
+GDN_FUSED_BWD = os.environ.get("PCC_GDN_FUSED_BWD", "1") != "0"  # GDN backward: element-wise parts and reparametrisation as kernels
 WGRAD_SELF = os.environ.get("PCC_WGRAD_SELF", "1") != "0"     # one-logit heads: input-stationary weight gradient
 
 
@@ -183,6 +184,36 @@ class GdnFn(torch.autograd.Function):
         x, beta_raw, gamma_raw = ctx.saved_tensors
         m = ctx.module
         g = g.contiguous()
+        c = m.in_channels
+        if not (GDN_FUSED_BWD and c % 32 == 0):
+            return GdnFn._backward_torch(ctx, g)
+        n_rows = x.shape[0]
+        packed, beta_eff = m._pack()                                   # the forward's pack: W[ci][co] = gamma_eff[co][ci] (+ planes)
+        with torch.no_grad():
+            ax = x.abs()
+            with L.arith_scope(L.ARITH_BF6):                           # (the GDN pack carries no fp16 planes: six-term form)
+                n = S.conv_forward(ax, packed, beta_eff, 1, c, c, None, n_rows)                  # beta + |x| gamma^T
+                u, dx = torch.empty_like(x), torch.empty_like(x)
+                L.call("pcc_gdn_bwd_pre", L.ptr(x), L.ptr(g), L.ptr(n), x.numel(), 1 if m.inverse else 0, L.ptr(u), L.ptr(dx),
+                       L.stream())
+                gamma_eff = torch.empty((1, c, c), dtype=torch.float32, device=x.device)
+                L.call("pcc_gdn_gamma_eff", L.ptr(gamma_raw.detach().contiguous()), c, L.ptr(gamma_eff), L.stream())
+                v = S.conv_forward(u, _pack_view(gamma_eff, 1, c, c, False, False), None, 1, c, c, None, n_rows)   # u gamma
+            if ctx.needs_input_grad[0]:
+                L.call("pcc_gdn_bwd_post", L.ptr(dx), L.ptr(x), L.ptr(v), x.numel(), L.stream())
+            d_beta = u.sum(dim=0)
+            d_gamma_t = S.conv_wgrad(ax, u, 1, c, c, None)                                        # [1][ci][co] = sum |x|_ci u_co
+            gb, gg = torch.empty_like(beta_raw), torch.empty_like(gamma_raw)
+            L.call("pcc_gdn_reparam_bwd", L.ptr(beta_raw.detach().contiguous()), L.ptr(gamma_raw.detach().contiguous()), L.ptr(d_beta),
+                   L.ptr(d_gamma_t), c, float(m.beta_min), L.ptr(gb), L.ptr(gg), L.stream())
+        return (dx if ctx.needs_input_grad[0] else None), gb, gg, None
+
+    @staticmethod
+    def _backward_torch(ctx, g):
+        """The same gradients with torch operators around the library's products (channel counts the fused path does not take;
+        `PCC_GDN_FUSED_BWD=0`; the reference the fused path is tested against)."""
+        x, beta_raw, gamma_raw = ctx.saved_tensors
+        m = ctx.module
         with torch.enable_grad():
             b_leaf = beta_raw.detach().requires_grad_(True)
             g_leaf = gamma_raw.detach().requires_grad_(True)

@@ -892,3 +892,103 @@ extern "C" int pcc_convt_scatter_rows(const float* grad_out, const int32_t* firs
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// GDN backward, element-wise parts (reference `model/blocks.py:38-57`, GDN1 form; the matrix products run on the convolution
+// kernels: n = beta + |x| gamma^T, v = u gamma, d gamma = u^T |x|).  The torch chain was ~40 launches per GDN layer, most of
+// them on [C] / [C, C] parameter tensors (the NonNegativeParametrizer and its gradient through autograd.grad).
+//   pre :  GDN  y = x / n : u = -g x / n^2, dx0 = g / n        IGDN  y = x n : u = g x, dx0 = g n
+//   post:  dx = dx0 + sign(x) v
+//   gamma_eff = max(gamma_raw, bound)^2 - 2^-36 (CompressAI's reparametrisation, as pcc_gdn_pack applies it)
+//   reparam_bwd: d raw = [raw >= bound or d eff < 0] * 2 max(raw, bound) * d eff   (LowerBound's gradient rule)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gdn_bwd_pre(const float4* __restrict__ x, const float4* __restrict__ g,
+                                                     const float4* __restrict__ n, long long total4, int inverse,
+                                                     float4* __restrict__ u, float4* __restrict__ dx0) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total4) return;
+  const float4 xv = x[t], gv = g[t], nv = n[t];
+  float4 uo, d0;
+  if (inverse) {
+    uo = make_float4(gv.x * xv.x, gv.y * xv.y, gv.z * xv.z, gv.w * xv.w);
+    d0 = make_float4(gv.x * nv.x, gv.y * nv.y, gv.z * nv.z, gv.w * nv.w);
+  } else {
+    uo = make_float4(-(gv.x * xv.x) / (nv.x * nv.x), -(gv.y * xv.y) / (nv.y * nv.y), -(gv.z * xv.z) / (nv.z * nv.z),
+                     -(gv.w * xv.w) / (nv.w * nv.w));
+    d0 = make_float4(gv.x / nv.x, gv.y / nv.y, gv.z / nv.z, gv.w / nv.w);
+  }
+  u[t] = uo;
+  dx0[t] = d0;
+}
+
+__device__ __forceinline__ float sgn1(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void __launch_bounds__(256) k_gdn_bwd_post(float4* __restrict__ dx, const float4* __restrict__ x,
+                                                      const float4* __restrict__ v, long long total4) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total4) return;
+  const float4 xv = x[t], vv = v[t];
+  float4 d = dx[t];
+  d.x += sgn1(xv.x) * vv.x; d.y += sgn1(xv.y) * vv.y; d.z += sgn1(xv.z) * vv.z; d.w += sgn1(xv.w) * vv.w;
+  dx[t] = d;
+}
+
+__global__ void k_gdn_gamma_eff(const float* __restrict__ gamma_raw, int cc, float bound, float pedestal, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cc) return;
+  const float gq = fmaxf(gamma_raw[t], bound);
+  out[t] = gq * gq - pedestal;
+}
+
+// d_gamma_t: [ci][co] as pcc_conv_wgrad(|x|, u) returns it; gamma_raw / d_gamma_raw: [co][ci]
+__global__ void k_gdn_reparam_bwd(const float* __restrict__ beta_raw, const float* __restrict__ gamma_raw,
+                                  const float* __restrict__ d_beta, const float* __restrict__ d_gamma_t, int c, float beta_bound,
+                                  float gamma_bound, float* __restrict__ d_beta_raw, float* __restrict__ d_gamma_raw) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < c) {
+    const float r = beta_raw[t], d = d_beta[t];
+    d_beta_raw[t] = (r >= beta_bound || d < 0.f) ? 2.f * fmaxf(r, beta_bound) * d : 0.f;
+  }
+  if (t >= c * c) return;
+  const int co = t / c, ci = t - co * c;
+  const float r = gamma_raw[t], d = d_gamma_t[ci * c + co];
+  d_gamma_raw[t] = (r >= gamma_bound || d < 0.f) ? 2.f * fmaxf(r, gamma_bound) * d : 0.f;
+}
+
+extern "C" int pcc_gdn_bwd_pre(const float* x, const float* g, const float* n, int64_t elems, int32_t inverse, float* u, float* dx0,
+                               void* stream) {
+  PCC_REQUIRE(elems >= 0 && elems % 4 == 0 && (elems == 0 || (x && g && n && u && dx0)), "pcc_gdn_bwd_pre: bad arguments");
+  if (elems == 0) return PCC_OK;
+  k_gdn_bwd_pre<<<(unsigned)pcc_cdiv(elems / 4, 256), 256, 0, (hipStream_t)stream>>>((const float4*)x, (const float4*)g, (const float4*)n,
+                                                                                   elems / 4, inverse, (float4*)u, (float4*)dx0);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_gdn_bwd_post(float* dx, const float* x, const float* v, int64_t elems, void* stream) {
+  PCC_REQUIRE(elems >= 0 && elems % 4 == 0 && (elems == 0 || (dx && x && v)), "pcc_gdn_bwd_post: bad arguments");
+  if (elems == 0) return PCC_OK;
+  k_gdn_bwd_post<<<(unsigned)pcc_cdiv(elems / 4, 256), 256, 0, (hipStream_t)stream>>>((float4*)dx, (const float4*)x, (const float4*)v, elems / 4);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_gdn_gamma_eff(const float* gamma_raw, int32_t c, float* gamma_eff, void* stream) {
+  PCC_REQUIRE(gamma_raw && gamma_eff && c >= 1, "pcc_gdn_gamma_eff: bad arguments");
+  const double pedestal = 1.0 / 68719476736.0;   // 2^-36, as pcc_gdn_pack
+  k_gdn_gamma_eff<<<(unsigned)pcc_cdiv((int64_t)c * c, 256), 256, 0, (hipStream_t)stream>>>(gamma_raw, c * c, (float)sqrt(pedestal),
+                                                                                          (float)pedestal, gamma_eff);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}
+
+extern "C" int pcc_gdn_reparam_bwd(const float* beta_raw, const float* gamma_raw, const float* d_beta, const float* d_gamma_t,
+                                   int32_t c, float beta_min, float* d_beta_raw, float* d_gamma_raw, void* stream) {
+  PCC_REQUIRE(beta_raw && gamma_raw && d_beta && d_gamma_t && d_beta_raw && d_gamma_raw && c >= 1, "pcc_gdn_reparam_bwd: bad arguments");
+  const double pedestal = 1.0 / 68719476736.0;
+  k_gdn_reparam_bwd<<<(unsigned)pcc_cdiv((int64_t)c * c, 256), 256, 0, (hipStream_t)stream>>>(
+      beta_raw, gamma_raw, d_beta, d_gamma_t, c, (float)sqrt((double)beta_min + pedestal), (float)sqrt(pedestal), d_beta_raw,
+      d_gamma_raw);
+  PCC_LAUNCH_CHECK();
+  return PCC_OK;
+}

@@ -85,6 +85,10 @@ SIGNATURES = {
     "pcc_conv_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "pcc_conv_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "pcc_conv_wgrad_self_supported": (C.c_int, [_i32, _i32, _i32]),
+    "pcc_gdn_bwd_pre": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "pcc_gdn_bwd_post": (C.c_int, [_p, _p, _p, _i64, _p]),
+    "pcc_gdn_gamma_eff": (C.c_int, [_p, _i32, _p, _p]),
+    "pcc_gdn_reparam_bwd": (C.c_int, [_p, _p, _p, _p, _i32, C.c_float, _p, _p, _p]),
     "pcc_focal_rows": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _i32, C.c_float, C.c_float, _p, _p, _p]),
     "pcc_quant_mlp_params": (_i32, []),
     "pcc_quant_mlp_ws_bytes": (_sz, [_i64]),

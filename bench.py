@@ -313,7 +313,7 @@ def true_geometry_ms(model, pc, q, steps=5, warmup=2):
     return {"ms_per_step_true_geometry": ms, "candidate_rows": [sizes.get(i) for i in range(3)], "lossless_geometry": bool(exact)}
 
 
-def train_step_setup(device, bottleneck_step=True):
+def train_step_setup(device, bottleneck_step=True, fused_adam=False):
     """The training step of BASELINE configs[3] as a callable: `one()` runs forward, losses, backward, gradient clipping and the
     model optimiser's step, then the quantile (aux) loss with the bottleneck optimiser's step, reading both losses as
     `train.py:196-236` does.  4 cubes of 128^3 cut from the benchmark frame, `configs/CVPR_inverse_scaling.yaml` (adaptive
@@ -343,8 +343,9 @@ def train_step_setup(device, bottleneck_step=True):
     q = torch.tensor([[0.4, 0.7]] * nb, device=device)
     Lam = torch.tensor([[5.0, 400.0]] * nb, device=device)
     # `train.py:96-112`: the model's parameters and the bottleneck's quantiles have an optimiser each
-    opt = torch.optim.Adam([p for nme, p in model.named_parameters() if not nme.endswith(".quantiles")], lr=1e-4)
-    opt_aux = torch.optim.Adam([p for nme, p in model.named_parameters() if nme.endswith(".quantiles")], lr=1e-3)
+    kw = {"fused": True} if fused_adam else {}     # (reference: the default `optim.Adam(params, lr=...)`, `train.py:67-75`)
+    opt = torch.optim.Adam([p for nme, p in model.named_parameters() if not nme.endswith(".quantiles")], lr=1e-4, **kw)
+    opt_aux = torch.optim.Adam([p for nme, p in model.named_parameters() if nme.endswith(".quantiles")], lr=1e-3, **kw)
     loss_fn = Loss(copy.deepcopy(loss_cfg))
     coords, feats = coords.to(device), feats.float().to(device)
 
@@ -392,6 +393,22 @@ def train_step_ms(device, steps=10, warmup=6):
         one2()
     torch.cuda.synchronize()
     out["train_step_ms_without_bottleneck_step"] = (time.time() - t0) / steps * 1e3
+    # the full step with torch's single-kernel Adam (`fused=True`: same update rule, one launch per optimiser instead of ~25
+    # foreach launches and a host->device copy of the step scalars) -- an implementation switch of torch, reported beside the
+    # reference's default construction, never instead of it
+    try:
+        one3, _ = train_step_setup(device, fused_adam=True)
+        for _ in range(warmup):
+            one3()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(steps):
+            one3()
+        torch.cuda.synchronize()
+        out["train_step_ms_fused_adam"] = (time.time() - t0) / steps * 1e3
+    except (RuntimeError, TypeError) as e:            # (a torch build without the fused kernel)
+        out["train_step_ms_fused_adam"] = None
+        out["fused_adam_error"] = str(e)[:120]
     return out
 
 

@@ -19,7 +19,7 @@ echo "host" >> $O/progress.txt
 timeout -k 10 200 python tools/sync_sites.py > $O/host_reads.txt 2>&1
 timeout -k 10 200 python tools/host_timeline.py $O/host_timeline.txt > $O/host_timeline.log 2>&1
 echo "train step" >> $O/progress.txt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 tools/train_profile.py 10 > $O/train_profile.txt 2>&1 && python profiles/summarize.py $O/train 48 > $O/train_kernel_stats.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 tools/train_profile.py 10 > $O/train_profile.txt 2>&1 && python profiles/summarize.py $O/train 48 > $O/train_kernel_stats.txt 2>&1 && sed -i '2a # (tools/train_profile.py 10 = bench.train_step_ms: 6 + 10 steps each of the full step, the step without the bottleneck optimiser half, and the full step with fused Adam -- averaged together)' $O/train_kernel_stats.txt
 timeout -k 10 200 python3 tools/step_timeline.py $O/train/*/*_kernel_trace.csv 25 2 "k_wgrad_thin<4>" gaps > $O/train_gaps_all.txt 2>&1; (tail -n 1 $O/train_gaps_all.txt; grep idle $O/train_gaps_all.txt | sort -k3 -n -r | head -20) > $O/train_gpu_gaps.txt
 timeout -k 10 300 python3 tools/train_attribution.py $O/train_attribution.txt > $O/train_attribution.log 2>&1
 timeout -k 10 300 python3 tools/train_backward_cpu.py > $O/train_host_by_node.txt 2>&1

@@ -124,6 +124,7 @@ T_CHUNKED = os.environ.get("PCC_T_CHUNKED", "0") != "0"            # composite l
 #   (measured round 2: bit-identical, 10 GB less memory, but +3.5 ms per step -- 125 chunk pairs of launches, children near
 #   chunk borders visited twice, and the Infinity Cache does not speed the gather up enough to pay for it: off)
 T_CHUNKED_MIN_BYTES = 256 << 20
+BATCH_BOUNDS = os.environ.get("PCC_BATCH_BOUNDS", "1") != "0"   # batched sets: per-batch row ranges of an expanded set read with its size
 CSR_SLOTS = os.environ.get("PCC_CSR_SLOTS", "1") != "0"      # composite levels: 7-wide pair lists in one pass (per-workgroup slots)
 STENCIL_FROM_GRID = os.environ.get("PCC_STENCIL_FROM_GRID", "1") != "0"   # composite levels: 3x3x3 neighbours from the bitmap, no nbr table
 HEAD_FUSED = os.environ.get("PCC_HEAD_FUSED", "1") != "0"      # occupancy heads with <= 16 hidden channels: conv + ReLU + projection in one kernel
@@ -397,19 +398,30 @@ class CoordSet:
         ws = L.workspace(lib.pcc_grid_ws_bytes(words), dev)
         L.call("pcc_coords_expand_grid", L.ptr(self.keys), self.n, ksize, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
                L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+        # batched sets: the per-batch row ranges of the new set (top-k runs per batch) come back with its size
+        entries = ob.bmax + 2 if (BATCH_BOUNDS and 0 < ob.bmax <= 6) else 0
+        if entries:
+            seg_a, seg_b = L.counter(4), L.counter(4)
+            L.call("pcc_batch_bounds", L.ptr(out), L.cptr(cnt), entries, L.cptr(seg_a), L.cptr(seg_b), L.stream())
 
         def finish(v):
+            segs = None
+            if v and isinstance(v[0], (list, tuple)):            # [[n], ranges 0-3, ranges 4-7]
+                segs = (list(v[1]) + list(v[2]))[:entries]
+                v = v[0]
             n = int(v[0])
             cs = CoordSet(out[:n].clone() if n < out.numel() // 2 else out, n, ts_out, ob)
             cs._grid = (bits, rank, h)
             cs._on_lattice = self._on_lattice
+            if segs is not None:
+                cs._derived["segments"] = [int(x) for x in segs]
             self._derived[key] = cs
             if want_csr:
                 self._derived[("csr", ksize, ts_out)] = self.csr_for(cs.keys, n, ksize, ts_out)
             return cs
         if ksize == 2 and self.ts == 2 * ts_out and self._on_lattice:
             return _ready(finish([8 * self.n]))
-        return Pending(cnt, finish)
+        return Pending([cnt, seg_a, seg_b] if entries else cnt, finish)
 
     def expand(self, ksize, ts_out, want_csr=True):
         """Output set of a generative transposed conv (a3-i): unique{c + off_k*ts_out}, plus (want_csr) the transposed

@@ -99,11 +99,11 @@ extern "C" int pcc_keys_unpack(const int64_t* keys, int64_t n, int32_t* coords, 
 // index is >= e, e in [0, entries) (entries = batches + 1: the last one is the row count).  Queued behind the kernel that
 // produces the set, so the ranges come back with the set's size in the SAME host read (`model/transforms.py:228-254` selects
 // the top-k per batch; the training step read the ranges of every level's candidate set on their own).
-__global__ void k_batch_bounds(const long long* __restrict__ keys, const long long* __restrict__ d_n, int entries,
+__global__ void k_batch_bounds(const long long* __restrict__ keys, const long long* __restrict__ d_n, long long n_host, int entries,
                                long long* __restrict__ out_a, long long* __restrict__ out_b) {
   const int e = threadIdx.x;
   if (e >= entries) return;
-  const long long n = *d_n, target = (long long)e << 48;
+  const long long n = d_n ? *d_n : n_host, target = (long long)e << 48;
   long long lo = 0, hi = n;
   while (lo < hi) {
     const long long mid = (lo + hi) >> 1;
@@ -112,11 +112,11 @@ __global__ void k_batch_bounds(const long long* __restrict__ keys, const long lo
   if (e < 4) out_a[e] = lo; else out_b[e - 4] = lo;
 }
 
-extern "C" int pcc_batch_bounds(const int64_t* keys, const int64_t* d_n, int32_t entries, int64_t* out_a, int64_t* out_b,
-                                void* stream) {
-  PCC_REQUIRE(keys && d_n && out_a && entries >= 1 && entries <= 8 && (entries <= 4 || out_b), "pcc_batch_bounds: bad arguments");
-  k_batch_bounds<<<1, 64, 0, (hipStream_t)stream>>>((const long long*)keys, (const long long*)d_n, entries, (long long*)out_a,
-                                                    (long long*)out_b);
+extern "C" int pcc_batch_bounds(const int64_t* keys, const int64_t* d_n, int64_t n_host, int32_t entries, int64_t* out_a,
+                                int64_t* out_b, void* stream) {
+  PCC_REQUIRE(keys && out_a && n_host >= 0 && entries >= 1 && entries <= 8 && (entries <= 4 || out_b), "pcc_batch_bounds: bad arguments");
+  k_batch_bounds<<<1, 64, 0, (hipStream_t)stream>>>((const long long*)keys, (const long long*)d_n, n_host, entries,
+                                                    (long long*)out_a, (long long*)out_b);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

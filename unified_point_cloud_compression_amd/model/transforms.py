@@ -29,6 +29,21 @@ def batch_segments(cset):
     return batch_segments_many([cset])[0]
 
 
+def batch_segments_begin(cs):
+    """Queue the batch ranges of a set whose size the host knows (`pcc_batch_bounds`); returns a Pending for `S.resolve` (the
+    caller reads it together with whatever else it waits for), or None when there is nothing to read."""
+    if cs.bounds.bmax == 0 or "segments" in cs._derived or cs.bounds.bmax > 6 or cs.n == 0 or not S.BATCH_BOUNDS:
+        return None
+    entries = cs.bounds.bmax + 2
+    a, b = L.counter(4), L.counter(4)
+    L.call("pcc_batch_bounds", L.ptr(cs.keys), None, cs.n, entries, L.cptr(a), L.cptr(b), L.stream())
+
+    def finish(v):
+        cs._derived["segments"] = [int(x) for x in (list(v[0]) + list(v[1]))[:entries]]
+        return cs._derived["segments"]
+    return S.Pending([a, b], finish)
+
+
 def batch_segments_many(csets):
     """`batch_segments` of several sets with ONE device->host read for all of them (the analysis transform knows its three
     sets before its first feature kernel)."""
@@ -72,7 +87,7 @@ class AnalysisTransform(nn.Module):
 
     count_per_batch = staticmethod(count_per_batch)
 
-    def plan(self, cs, backward=False):
+    def plan(self, cs, backward=False, extra=()):
         """Coordinate-only pre-pass: every output set, kernel map and pair list of the transform depends on the
         input COORDINATES alone, so they are all queued before the first feature kernel and the sizes the host needs (pair
         counts of the three 5x5x5 128-channel layers) come back in ONE read instead of one per layer."""
@@ -89,19 +104,20 @@ class AnalysisTransform(nn.Module):
                         # training: the data gradient of a strided layer runs the forward kernel over the INVERSE map
                         # (`autograd.SparseConvFn.backward`); its pair plan is queued here so that its size comes back with
                         # the forward plans' instead of stopping the backward pass for a read of its own
-                        if (backward and not first and m.stride != 1 and m.kernel_size % 2 == 1
+                        if (backward and not first and m.kernel_size % 2 == 1
                                 and S.wants_pairs(m.kernel_volume, m.out_channels, m.in_channels)):
                             pend.append(out.kernel_map(cs, m.kernel_size, step=cs.ts).pair_plan_begin())
                     cs = out
                     first = False
-        S.resolve(*pend)
+        S.resolve(*pend, *[p for p in extra if p is not None])
 
     def forward(self, x):
         """x -> (y, k) with k = rows per batch at strides [4, 2, 1] (`model/transforms.py:68-97`)."""
-        self.plan(x._cset, backward=torch.is_grad_enabled())
-        if x._cset.bounds.bmax > 0:                  # batched input (training): the three sets' row ranges in one read
+        extra = []
+        if x._cset.bounds.bmax > 0:                  # batched input (training): the three sets' row ranges, read with the plans
             c1 = x._cset.stride(x._cset.ts * 2)
-            batch_segments_many([x._cset, c1, c1.stride(c1.ts * 2)])
+            extra = [batch_segments_begin(c) for c in (x._cset, c1, c1.stride(c1.ts * 2))]
+        self.plan(x._cset, backward=torch.is_grad_enabled(), extra=extra)
         k = [count_per_batch(x)]
         x = self.down_conv_1(x)
         k.append(count_per_batch(x))

@@ -402,7 +402,7 @@ class CoordSet:
         entries = ob.bmax + 2 if (BATCH_BOUNDS and 0 < ob.bmax <= 6) else 0
         if entries:
             seg_a, seg_b = L.counter(4), L.counter(4)
-            L.call("pcc_batch_bounds", L.ptr(out), L.cptr(cnt), entries, L.cptr(seg_a), L.cptr(seg_b), L.stream())
+            L.call("pcc_batch_bounds", L.ptr(out), L.cptr(cnt), 0, entries, L.cptr(seg_a), L.cptr(seg_b), L.stream())
 
         def finish(v):
             segs = None

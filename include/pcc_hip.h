@@ -70,10 +70,10 @@ int pcc_keys_pack_i32(const int32_t* coords, int64_t n, int64_t* keys, void* str
 int pcc_keys_pack_f32(const float* coords, int64_t n, int64_t* keys, void* stream);
 int pcc_keys_unpack(const int64_t* keys, int64_t n, int32_t* coords, void* stream);
 /* Row ranges per batch index of a canonical key array whose row count *d_n may still be on the device: out[e] = first row with batch
- * index >= e for e in [0, entries), entries <= 8 (out_a: entries 0-3, out_b: 4-7; 4 int64 each).  Lets a caller read a derived
+ * index >= e for e in [0, entries), entries <= 12 (out_a: entries 0-3, out_b: 4-7, out_c: 8-11; 4 int64 each).  Lets a caller read a derived
  * set's size and its per-batch ranges (reference model/transforms.py:228-254: top-k per batch) in one host read. */
 int pcc_batch_bounds(const int64_t* keys, const int64_t* d_n /*nullable: then n_host rows*/, int64_t n_host, int32_t entries,
-                     int64_t* out_a, int64_t* out_b, void* stream);
+                     int64_t* out_a, int64_t* out_b, int64_t* out_c, void* stream);
 
 /* LSD radix sort of keys (stable), optional payload perm_out[i] = input index of output i.
  * Only 8-bit digits intersecting `bit_mask` (bits that may differ between keys) are sorted. */

@@ -196,3 +196,25 @@ def test_decode_finish_matches_the_torch_chain():
     C = t(co.unpack_keys(keys).astype(np.int32))
     want = torch.cat([C[:, 1:4].to(torch.float32), torch.clamp(torch.round(ft * 255), 0.0, 255.0) / 255], dim=1)
     assert np.array_equal(n(out), n(want), equal_nan=True)
+
+
+@pytest.mark.parametrize("batch", [3, 8])
+def test_batch_ranges_from_the_bounds_kernel_equal_searchsorted(batch):
+    """`pcc_batch_bounds` (per-batch row ranges read together with a set's size; top-k runs per batch, reference
+    `model/transforms.py:228-254`): for a set whose size the host knows and for a generative expansion whose size is still on
+    the device, against torch.searchsorted over the keys.  A batch of 8 is the reference's training batch size."""
+    import unified_point_cloud_compression_amd.MinkowskiEngine as ME
+    from unified_point_cloud_compression_amd import sparse as S
+    from unified_point_cloud_compression_amd.model.transforms import batch_segments_begin
+    keys = cloud_keys(batch, 10, 0.25, 2, batch=batch)
+    x = ME.SparseTensor(coordinates=t(co.unpack_keys(keys)), features=t(np.ones((len(keys), 1), np.float32)), tensor_stride=2)
+    cs = x._cset
+
+    def ref(c):
+        q = torch.arange(0, c.bounds.bmax + 2, device=c.device, dtype=torch.int64) << 48
+        return torch.searchsorted(c.keys[:c.n], q).tolist()
+    S.resolve(batch_segments_begin(cs))
+    assert cs._derived["segments"] == ref(cs)
+    ex = cs.expand(5, 1)                                   # size read together with its ranges
+    assert ex._derived.get("segments") == ref(ex)
+    assert ex._derived["segments"][-1] == ex.n

@@ -96,11 +96,11 @@ extern "C" int pcc_keys_unpack(const int64_t* keys, int64_t n, int32_t* coords, 
 }
 
 // Row ranges per batch index of a canonical key array whose row count is still on the device: out[e] = first row whose batch
-// index is >= e, e in [0, entries) (entries = batches + 1: the last one is the row count).  Queued behind the kernel that
+// index is >= e, e in [0, entries) (entries = batches + 1 <= 12: the last one is the row count).  Queued behind the kernel that
 // produces the set, so the ranges come back with the set's size in the SAME host read (`model/transforms.py:228-254` selects
 // the top-k per batch; the training step read the ranges of every level's candidate set on their own).
 __global__ void k_batch_bounds(const long long* __restrict__ keys, const long long* __restrict__ d_n, long long n_host, int entries,
-                               long long* __restrict__ out_a, long long* __restrict__ out_b) {
+                               long long* __restrict__ out_a, long long* __restrict__ out_b, long long* __restrict__ out_c) {
   const int e = threadIdx.x;
   if (e >= entries) return;
   const long long n = d_n ? *d_n : n_host, target = (long long)e << 48;
@@ -109,14 +109,15 @@ __global__ void k_batch_bounds(const long long* __restrict__ keys, const long lo
     const long long mid = (lo + hi) >> 1;
     if (keys[mid] < target) lo = mid + 1; else hi = mid;
   }
-  if (e < 4) out_a[e] = lo; else out_b[e - 4] = lo;
+  if (e < 4) out_a[e] = lo; else if (e < 8) out_b[e - 4] = lo; else out_c[e - 8] = lo;
 }
 
 extern "C" int pcc_batch_bounds(const int64_t* keys, const int64_t* d_n, int64_t n_host, int32_t entries, int64_t* out_a,
-                                int64_t* out_b, void* stream) {
-  PCC_REQUIRE(keys && out_a && n_host >= 0 && entries >= 1 && entries <= 8 && (entries <= 4 || out_b), "pcc_batch_bounds: bad arguments");
+                                int64_t* out_b, int64_t* out_c, void* stream) {
+  PCC_REQUIRE(keys && out_a && n_host >= 0 && entries >= 1 && entries <= 12 && (entries <= 4 || out_b) && (entries <= 8 || out_c),
+              "pcc_batch_bounds: bad arguments");
   k_batch_bounds<<<1, 64, 0, (hipStream_t)stream>>>((const long long*)keys, (const long long*)d_n, n_host, entries,
-                                                    (long long*)out_a, (long long*)out_b);
+                                                    (long long*)out_a, (long long*)out_b, (long long*)out_c);
   PCC_LAUNCH_CHECK();
   return PCC_OK;
 }

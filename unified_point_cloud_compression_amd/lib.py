@@ -32,7 +32,7 @@ SIGNATURES = {
     "pcc_keys_pack_i32": (C.c_int, [_p, _i64, _p, _p]),
     "pcc_keys_pack_f32": (C.c_int, [_p, _i64, _p, _p]),
     "pcc_keys_unpack": (C.c_int, [_p, _i64, _p, _p]),
-    "pcc_batch_bounds": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
+    "pcc_batch_bounds": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p]),
     "pcc_sort_ws_bytes": (_sz, [_i64]),
     "pcc_sort_keys": (C.c_int, [_p, _i64, _u64, _p, _p, _p, _sz, _p]),
     "pcc_unique_ws_bytes": (_sz, [_i64]),

@@ -32,16 +32,16 @@ def batch_segments(cset):
 def batch_segments_begin(cs):
     """Queue the batch ranges of a set whose size the host knows (`pcc_batch_bounds`); returns a Pending for `S.resolve` (the
     caller reads it together with whatever else it waits for), or None when there is nothing to read."""
-    if cs.bounds.bmax == 0 or "segments" in cs._derived or cs.bounds.bmax > 6 or cs.n == 0 or not S.BATCH_BOUNDS:
+    if cs.bounds.bmax == 0 or "segments" in cs._derived or cs.bounds.bmax > 10 or cs.n == 0 or not S.BATCH_BOUNDS:
         return None
     entries = cs.bounds.bmax + 2
-    a, b = L.counter(4), L.counter(4)
-    L.call("pcc_batch_bounds", L.ptr(cs.keys), None, cs.n, entries, L.cptr(a), L.cptr(b), L.stream())
+    a, b, c = L.counter(4), L.counter(4), L.counter(4)
+    L.call("pcc_batch_bounds", L.ptr(cs.keys), None, cs.n, entries, L.cptr(a), L.cptr(b), L.cptr(c), L.stream())
 
     def finish(v):
-        cs._derived["segments"] = [int(x) for x in (list(v[0]) + list(v[1]))[:entries]]
+        cs._derived["segments"] = [int(x) for x in (list(v[0]) + list(v[1]) + list(v[2]))[:entries]]
         return cs._derived["segments"]
-    return S.Pending([a, b], finish)
+    return S.Pending([a, b, c], finish)
 
 
 def batch_segments_many(csets):

@@ -399,15 +399,15 @@ class CoordSet:
         L.call("pcc_coords_expand_grid", L.ptr(self.keys), self.n, ksize, h, L.ptr(bits), L.ptr(rank), L.ptr(out),
                L.cptr(cnt), L.ptr(ws), ws.numel(), L.stream())
         # batched sets: the per-batch row ranges of the new set (top-k runs per batch) come back with its size
-        entries = ob.bmax + 2 if (BATCH_BOUNDS and 0 < ob.bmax <= 6) else 0
+        entries = ob.bmax + 2 if (BATCH_BOUNDS and 0 < ob.bmax <= 10) else 0
         if entries:
-            seg_a, seg_b = L.counter(4), L.counter(4)
-            L.call("pcc_batch_bounds", L.ptr(out), L.cptr(cnt), 0, entries, L.cptr(seg_a), L.cptr(seg_b), L.stream())
+            seg_a, seg_b, seg_c = L.counter(4), L.counter(4), L.counter(4)
+            L.call("pcc_batch_bounds", L.ptr(out), L.cptr(cnt), 0, entries, L.cptr(seg_a), L.cptr(seg_b), L.cptr(seg_c), L.stream())
 
         def finish(v):
             segs = None
-            if v and isinstance(v[0], (list, tuple)):            # [[n], ranges 0-3, ranges 4-7]
-                segs = (list(v[1]) + list(v[2]))[:entries]
+            if v and isinstance(v[0], (list, tuple)):            # [[n], ranges 0-3, ranges 4-7, ranges 8-11]
+                segs = (list(v[1]) + list(v[2]) + list(v[3]))[:entries]
                 v = v[0]
             n = int(v[0])
             cs = CoordSet(out[:n].clone() if n < out.numel() // 2 else out, n, ts_out, ob)
@@ -421,7 +421,7 @@ class CoordSet:
             return cs
         if ksize == 2 and self.ts == 2 * ts_out and self._on_lattice:
             return _ready(finish([8 * self.n]))
-        return Pending([cnt, seg_a, seg_b] if entries else cnt, finish)
+        return Pending([cnt, seg_a, seg_b, seg_c] if entries else cnt, finish)
 
     def expand(self, ksize, ts_out, want_csr=True):
         """Output set of a generative transposed conv (a3-i): unique{c + off_k*ts_out}, plus (want_csr) the transposed

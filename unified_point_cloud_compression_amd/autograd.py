@@ -8,6 +8,14 @@ The reference back-propagates through every `ME.MinkowskiConvolution` / `Minkows
   * the WEIGHT gradient is `pcc_conv_wgrad` (MFMA GEMM whose reduction runs over the pair list, deterministic);
   * the bias gradient is a column sum.
 Fused activations are differentiated from the saved output.
+
+Round 4 (the training step of BASELINE configs[3] is bound by launch count and host reads as much as by kernels):
+  * stride-1 odd kernels over a set mapped onto itself with 1 or 16 output channels take the input-stationary weight gradient
+    `pcc_conv_wgrad_self` (feature rows streamed once, only the thin gradient rows gathered);
+  * the data gradient's transposed / offset-reversed kernels are packed straight from the parameter (`_pack_view`);
+  * `RowSelectFn` (rows a top-k keeps, scatter-free backward), `QuantMlpFn` (`quant_nn`, one kernel per direction),
+    `FocalRowsFn` (one occupancy level of the focal loss), `GdnFn.backward` (library products + four element-wise kernels,
+    the reparametrisation's gradient included) replace chains of 10-40 torch launches each.
 """
 import os
 

@@ -62,6 +62,30 @@ def test_topk_prune_keys_equals_mask_then_prune(rows):
         assert np.array_equal(n(mask), want) and np.array_equal(n(ko), keys[want]) and cnt == int(want.sum())
 
 
+def test_topk_many_segments_in_one_call():
+    """Round 4: all batch segments of a call share the launches (segment = grid y, 48 per batch of launches).  130 segments of
+    ragged sizes -- empty ones, k = 0, k >= rows, ties -- against the oracle, mask and compacted keys, so that the chunking over
+    more than 48 segments and the per-segment output offsets are covered."""
+    from unified_point_cloud_compression_amd import sparse as S
+    rng = np.random.default_rng(130)
+    sizes = rng.integers(0, 5000, 130)
+    sizes[[3, 50, 129]] = 0
+    cut = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    rows = int(cut[-1])
+    logits = rng.standard_normal(rows).astype(np.float32)
+    logits[rng.integers(0, rows, rows // 4)] = np.float32(0.5)
+    ks = [int(rng.integers(0, s + 3)) if s else int(rng.integers(0, 3)) for s in sizes]
+    ks[7], ks[60] = 0, int(sizes[60]) + 9
+    batch = np.repeat(np.arange(130), sizes)
+    keys = np.sort(rng.choice(10 ** 12, rows, replace=False)).astype(np.int64)
+    want = ops.topk_mask(logits, ks, batch)
+    mask, ko, cnt = S.topk_prune_keys(t(logits)[:, None], cut.tolist(), ks, t(keys))
+    assert cnt == int(want.sum())
+    assert np.array_equal(n(mask), want)
+    assert np.array_equal(n(ko), keys[want])
+    assert np.array_equal(n(S.topk_mask(t(logits)[:, None], cut.tolist(), ks)), want)
+
+
 def test_prune_rows():
     from unified_point_cloud_compression_amd import sparse as S
     rng = np.random.default_rng(1)

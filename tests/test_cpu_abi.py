@@ -40,6 +40,26 @@ def test_size_queries_are_pure_host_functions():
     assert L.pcc_gdn_packed_elems(128) == 128 * 128 * 5 // 2 and L.pcc_gdn_packed_elems(24) == 0
 
 
+def test_round4_training_queries_are_pure_host_functions():
+    """Support predicates and workspace queries of the round-4 training entry points (no launch, no GPU needed)."""
+    from unified_point_cloud_compression_amd import lib
+    L = lib.load()
+    # self-mapped weight gradient: odd K <= 27; one logit from 16 / 32 / 64 channels, 16 columns from 16 / 32
+    assert L.pcc_conv_wgrad_self_supported(27, 16, 1) and L.pcc_conv_wgrad_self_supported(27, 64, 1)
+    assert L.pcc_conv_wgrad_self_supported(27, 32, 16) and L.pcc_conv_wgrad_self_supported(1, 16, 16)
+    assert not L.pcc_conv_wgrad_self_supported(27, 64, 16) and not L.pcc_conv_wgrad_self_supported(8, 32, 1)
+    assert not L.pcc_conv_wgrad_self_supported(125, 32, 1) and not L.pcc_conv_wgrad_self_supported(27, 32, 3)
+    # partial blocks: >= 1, bounded, and the query covers them (K * cin * cout floats per block)
+    small, big = L.pcc_conv_wgrad_self_ws_bytes(100, 27, 16, 1), L.pcc_conv_wgrad_self_ws_bytes(10 ** 7, 27, 16, 1)
+    assert 27 * 16 * 4 <= small < big <= 1024 * 27 * 16 * 4 + 256
+    assert L.pcc_conv_wgrad_self_ws_bytes(10 ** 7, 27, 32, 16) <= 1024 * 27 * 32 * 16 * 4 + 256
+    assert L.pcc_quant_mlp_params() == 2 * 10 + 10 + 10 * 10 + 10 + 10 + 1
+    assert 151 * 4 <= L.pcc_quant_mlp_ws_bytes(1) < L.pcc_quant_mlp_ws_bytes(10 ** 8) <= 1024 * 151 * 4 + 256
+    # top-k workspace: the per-segment state of one batch of launches + two (greater, equal) count arrays
+    assert L.pcc_topk_ws_bytes(0) >= 48 * (256 + 2048 * 4)
+    assert L.pcc_topk_ws_bytes(10 ** 7) - L.pcc_topk_ws_bytes(0) >= 2 * (10 ** 7 // 2048) * 8
+
+
 def test_no_cpu_fallback():
     import torch
     from unified_point_cloud_compression_amd import lib
